@@ -1,0 +1,65 @@
+"""Seeded case definitions shared by make_golden.py (reference side) and the tests
+(oracle / HIP side).  Pure numpy + torch; no reference import here."""
+import numpy as np
+import torch
+
+# name -> spec for mvgformer_amd.synthetic.build_case + what to record
+LAYER_CASES = {
+    # 5 views, distortion != 0, some queries outside some images, all queries valid
+    "mini5_all": dict(config="mini5", seed=3, layers=2, projattn=True, triangulation=True),
+    # same geometry, about half of the queries pass the 0.1 threshold
+    "mini5_half": dict(config="mini5", seed=9, layers=2, valid_fraction=0.5),
+    # layer 1 ends with NO query above the threshold -> the forced query (0,0) path (dq_decoder.py:620-623)
+    "mini5_empty": dict(config="mini5", seed=8, layers=2, valid_fraction=0.5),
+    # batch of 2 with different validity per item (exercises the pad/scatter logic)
+    "mini5_b2": dict(config="mini5", seed=13, layers=2, B=2, NQ=6, valid_fraction=0.5),
+    # BASELINE.json configs[0]: 1 sample, 2 views 256x256, 64 queries, 1 layer
+    "cfg1": dict(config="cfg1", seed=0, layers=1),
+}
+
+
+def msda_case(name):
+    """Inputs of the sampling op (value, shapes, starts, loc, weight) for a named case."""
+    if name == "small_f32":
+        rs = np.random.RandomState(101)
+        N, M, D, Lq, P = 2, 8, 32, 37, 8
+        shapes = [(12, 20), (6, 10), (3, 5)]
+        lo, hi = -0.15, 1.15          # ~20 % of the points fall outside [0,1]
+    elif name == "ragged_f32":
+        rs = np.random.RandomState(102)
+        N, M, D, Lq, P = 1, 8, 32, 5, 8
+        shapes = [(7, 13), (1, 9), (5, 1)]   # degenerate 1-row / 1-col levels
+        lo, hi = -0.3, 1.3
+    elif name == "edge_f32":
+        rs = np.random.RandomState(103)
+        N, M, D, Lq, P = 1, 4, 16, 9, 4      # non-default head count / channels / points
+        shapes = [(6, 8), (3, 4)]
+        lo, hi = 0.0, 1.0
+    else:
+        raise KeyError(name)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = rs.standard_normal((N, S, M, D)).astype(np.float32)
+    loc = (lo + (hi - lo) * rs.rand(N, Lq, M, L, P, 2)).astype(np.float32)
+    if name == "edge_f32":
+        # exact texel centres, the -0.5/H and 1+0.5/H borders, and just-outside points
+        H0, W0 = shapes[0]
+        loc[0, 0, :, 0, :, 0] = (3 + 0.5) / W0
+        loc[0, 0, :, 0, :, 1] = (2 + 0.5) / H0
+        loc[0, 1, :, 0, :, 0] = -0.5 / W0
+        loc[0, 2, :, 0, :, 1] = 1.0 + 0.5 / H0
+        loc[0, 3, :, 0, :, 0] = 0.0
+        loc[0, 4, :, 0, :, 1] = 1.0
+        loc[0, 5, :, :, :, :] = -0.01
+        loc[0, 6, :, :, :, :] = 1.01
+    wgt = rs.rand(N, Lq, M, L, P).astype(np.float32)
+    wgt = wgt / wgt.reshape(N, Lq, M, -1).sum(-1)[..., None, None]
+    shapes_t = torch.tensor(shapes, dtype=torch.long)
+    starts = torch.cat([shapes_t.new_zeros(1), (shapes_t[:, 0] * shapes_t[:, 1]).cumsum(0)[:-1]])
+    return dict(value=torch.from_numpy(value), shapes=shapes_t, starts=starts,
+                loc=torch.from_numpy(loc), weight=torch.from_numpy(wgt))
+
+
+def threshold_margin(cls_list, thr):
+    """smallest |prob - thr| over all layers (parity tests need this >> rounding)."""
+    return min(float((c[..., 1] - thr).abs().min()) for c in cls_list)
