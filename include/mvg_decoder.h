@@ -1,0 +1,152 @@
+/*
+ * mvg_decoder.h -- C ABI of libmvgformer_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary of the MVGFormer decoder hot path.  Plain pointers and sizes,
+ * no torch / ATen types.  All pointers are DEVICE pointers unless marked "host".
+ * Every entry point enqueues work on `stream` (a hipStream_t passed as void*;
+ * NULL = the default stream), never synchronises, never allocates, never
+ * mutates its inputs, and returns 0 (hipSuccess) or a hipError_t / MVG_E_* code.
+ * No exception crosses this boundary.
+ *
+ * Reference interfaces replaced (paths relative to the MVGFormer reference tree):
+ *   - pybind module `Deformable` : lib/models/ops/src/vision.cpp:24-27
+ *       deform_forward  : lib/models/ops/src/deform.h:32-50  -> deform_cuda_forward,
+ *                         lib/models/ops/src/cuda/deform_cuda.cu:31-91,
+ *                         kernel lib/models/ops/src/cuda/deform_im2col_cuda.cuh:248-309
+ *       deform_backward : lib/models/ops/src/deform.h:53-72  -> deform_cuda_backward,
+ *                         lib/models/ops/src/cuda/deform_cuda.cu:94-164, kernels cuh:312-930
+ *   - the ATen op chains of ProjAttn.forward (lib/models/ops/modules/projattn.py:115-204),
+ *     DQDecoderLayer.forward (lib/models/dq_decoder.py:850-1045) and the DLT
+ *     triangulation (lib/mvn/utils/multiview.py:170-269) -> the mvg_* stage entry points.
+ *
+ * Layout conventions (see DESIGN.md "Data layout in HBM"):
+ *   image index n = v*B + b (view-major, like dq_decoder.py:560);  Lq = NQ*J joint tokens;
+ *   value / feat : (N_img, S, C) channels-last, level l at rows [start_l, start_l+H_l*W_l);
+ *   dtype code   : MVG_F32 = 0, MVG_BF16 = 1 (bf16 storage, fp32 accumulation).
+ */
+#ifndef MVG_DECODER_H
+#define MVG_DECODER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVG_F32 0
+#define MVG_BF16 1
+
+#define MVG_E_BADARG 10001   /* shape / alignment / dtype not supported            */
+#define MVG_E_NOGPU 10002    /* no gfx950 device visible                            */
+
+/* floats per packed camera record, one record per image n = v*B + b            */
+#define MVG_CAM_STRIDE 48
+/* record layout (float index):
+ *   0..8  R (row-major 3x3)       9..11 T (camera centre, mm)   12 fx 13 fy 14 cx 15 cy
+ *   16..18 k1 k2 k3               19,20 p1 p2
+ *   21..26 crop affine 2x3 (orig px -> network px; lib/utils/transforms.py:72-112)
+ *   27..32 inverse crop affine 2x3 (meta['inv_affine_trans'][:2])
+ *   33,34 wh = 2*center (orig image size)   35 clamp_max (max of wh over the batch)
+ *   36,37 network image size (w,h)          38..47 reserved (0)
+ */
+
+/* Library / device identification.  Returns 0 and fills arch (e.g. "gfx950") if a
+ * usable device is present; MVG_E_NOGPU otherwise.  Host-only. */
+int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
+const char* mvg_version(void);
+
+/* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
+ * value (N,S,M,D); spatial_shapes (L,2) int64 (H,W); level_start_index (L,) int64;
+ * sampling_loc (N,Lq,M,L,P,2) (x,y) in [0,1]; attn_weight (N,Lq,M,L,P); out (N,Lq,M*D).
+ * f32: every tensor float32 (AT_DISPATCH_FLOATING_TYPES' float case, deform_cuda.cu:75).
+ * bf16: value/out bf16, sampling_loc/attn_weight float32, fp32 accumulation. */
+int mvg_msda_forward_f32(const float* value, const int64_t* spatial_shapes,
+                         const int64_t* level_start_index, const float* sampling_loc,
+                         const float* attn_weight, float* out,
+                         int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+int mvg_msda_forward_bf16(const void* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const float* sampling_loc,
+                          const float* attn_weight, void* out,
+                          int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+/* grad_value (N,S,M,D) must be zero-filled by the caller (at::zeros_like, deform_cuda.cu:132);
+ * grad_sampling_loc / grad_attn_weight are fully overwritten.  Deterministic for a fixed
+ * launch geometry only up to the atomic-add order in grad_value (as the reference, cuh:135-162). */
+int mvg_msda_backward_f32(const float* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const float* sampling_loc,
+                          const float* attn_weight, const float* grad_output,
+                          float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                          int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+
+/* ---- stage entry points of the decoder layer ------------------------------------------ */
+
+/* (N_img,C,H,W) NCHW level -> rows [start, start+H*W) of the channels-last pyramid
+ * feat (N_img,S,C).  src dtype f32; dst dtype `dtype`.  (replaces cat+permute, projattn.py:160) */
+int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W,
+                   int S, int start, void* stream);
+
+/* A.1 + A.2 projection (dq_decoder.py:331-397,570-573; cameras.py:167-217): X (B,Lq,3) mm,
+ * cams (V*B, MVG_CAM_STRIDE) -> r (V*B,Lq,2) normalised network-image coords,
+ * ref_lvl (V*B,Lq,L,2) = r * (W_l,H_l)/(W_l-1,H_l-1), inside (V*B,Lq) uint8.
+ * shapes_host: L x (H,W) int64 on the host. */
+int mvg_project(const float* X, const float* cams, const int64_t* shapes_host, int L,
+                float* r, float* ref_lvl, uint8_t* inside, int V, int B, int Lq, void* stream);
+
+/* A.3 step 1 (projattn.py:134,148-153,180): bilinear ref-point features of every level
+ * + (tgt+query_pos) -> ain (V*B*Lq*L, C) in `dtype`.  feat (V*B,S,C) `dtype`;
+ * ref_lvl (V*B,Lq,L,2); x (B,Lq,C) f32; shapes/starts host int64 arrays (L). */
+int mvg_gather_ref(const void* feat, int dtype, const float* ref_lvl, const float* x,
+                   const int64_t* shapes_host, const int64_t* starts_host, void* ain,
+                   int V, int B, int Lq, int L, int S, int C, void* stream);
+
+/* Dense projection out[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) (* rowmask[M]) on MFMA.
+ * a_dtype / w_dtype / out_dtype: MVG_F32 or MVG_BF16 (weights must match the compute
+ * dtype: f32 weights -> fp32 MFMA, bf16 weights -> bf16 MFMA; A is converted on load).
+ * relu: 0/1.  rowmask: NULL or uint8 (M).  lda/ldc in elements. */
+int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype,
+               const float* bias, void* out, int out_dtype, int ldc,
+               const uint8_t* rowmask, int relu, int M, int N, int K, void* stream);
+
+/* A.3 steps 3-6 fused (projattn.py:180-200): oa (V*B*Lq*L, 192) f32 = Linear outputs
+ * [sampling_offsets(128) | attention_weights(64)] per level row; reinterpretation,
+ * softmax(L*P), locations (ref_lvl (V*B*Lq,L,2) + offset/(W,H)) and multi-scale sampling of
+ * value (V*B,S,256).  M=8, D=32, P=8.
+ * samp (V*B*Lq, 256) in `dtype`. */
+int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* ref_lvl,
+                   const int64_t* shapes_host, const int64_t* starts_host, void* samp,
+                   int N_img, int Lq, int L, int S, void* stream);
+
+/* A.4 (dq_decoder.py:770): mean over views of attn (V,B*Lq,C) `dtype` -> (B*Lq,C) `dtype`. */
+int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream);
+
+/* y = LayerNorm(res + h) * gamma + beta, eps 1e-5 (norm2 / norm3, dq_decoder.py:776-778,
+ * mvp_decoder.py:94-98).  res f32 (rows,C); h `h_dtype`; y f32. */
+int mvg_add_layernorm(const float* res, const void* h, int h_dtype, const float* gamma,
+                      const float* beta, float* y, int rows, int C, void* stream);
+
+/* A.5 (dq_decoder.py:889-908,596-623): class head + validity.  tgt (B,NQ*J,C) f32,
+ * Wc (2,C), bc (2) -> prob (B,NQ,2); valid (B,NQ) uint8 = prob[...,1] > threshold
+ * (or the caller-provided `forced_valid` mask when not NULL: training indices);
+ * any_valid: 1 int, must be zeroed by the caller; set to 1 if any query is valid. */
+int mvg_class_head(const float* tgt, const float* Wc, const float* bc, float threshold,
+                   const uint8_t* forced_valid, float* prob, uint8_t* valid, int* any_valid,
+                   int B, int NQ, int J, int C, void* stream);
+
+/* last pose_embed layer (N=3): o (rows,3) f32 = h (rows,C) @ W3 (3,C)^T + b3. */
+int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, float* o,
+                int rows, int C, void* stream);
+
+/* A.6-A.8 (dq_decoder.py:659-717,399-461,119-246,1013-1029; multiview.py:170-269):
+ * 2D refinement, view-softmax confidence, un-crop, 5-iteration undistortion, DLT rows,
+ * smallest right singular vector, masked scatter.
+ * r (V*B,Lq,2); o (V*B,Lq,3) = (dx,dy,conf logit); cams (V*B,STRIDE); valid (B,NQ);
+ * any_valid (1 int: if 0, query (0,0) is forced valid, dq_decoder.py:620-623).
+ * Outputs: new_ref (B,Lq,3) mm; ref2d, proj2d (B,V,Lq,2) network-image px; zeros for
+ * non-valid queries. */
+int mvg_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid,
+                    const int* any_valid, float* new_ref, float* ref2d, float* proj2d,
+                    int V, int B, int NQ, int J, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVG_DECODER_H */

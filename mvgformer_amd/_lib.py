@@ -1,0 +1,101 @@
+"""ctypes binding of libmvgformer_hip.so (the C ABI declared in include/mvg_decoder.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, the product
+path raises.  torch is used only to own device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvgformer_hip.so")
+
+MVG_F32, MVG_BF16 = 0, 1
+CAM_STRIDE = 48
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+# name -> argtypes (restype is always int unless noted); must list EVERY symbol of the header
+SIGNATURES = {
+    "mvg_device_info": [C.c_char_p, _i, C.POINTER(_i)],
+    "mvg_msda_forward_f32": [_vp] * 6 + [_i] * 7 + [_vp],
+    "mvg_msda_forward_bf16": [_vp] * 6 + [_i] * 7 + [_vp],
+    "mvg_msda_backward_f32": [_vp] * 9 + [_i] * 7 + [_vp],
+    "mvg_pack_level": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvg_project": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvg_gather_ref": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mvg_linear": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "mvg_msda_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvg_mean_views": [_vp, _i, _vp, _i, _i, _i, _vp],
+    "mvg_add_layernorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "mvg_class_head": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvg_rowdot3": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "mvg_triangulate": [_vp] * 8 + [_i] * 4 + [_vp],
+}
+
+_lib = None
+
+
+class MvgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvgError(
+            "libmvgformer_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mvgformer_amd/csrc` (there is no CPU fallback for the decoder hot path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.mvg_version.restype = C.c_char_p
+    lib.mvg_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise MvgError("%s failed with code %d" % (what, code))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return MVG_F32
+    if dt == torch.bfloat16:
+        return MVG_BF16
+    raise MvgError("unsupported dtype %s (float32 / bfloat16 only)" % dt)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            # same message as the reference's CPU stub (lib/models/ops/src/deform.h:49)
+            raise RuntimeError("Not implemented on the CPU")
+
+
+def device_info():
+    lib = load()
+    buf = C.create_string_buffer(64)
+    cus = C.c_int(0)
+    rc = lib.mvg_device_info(buf, 64, C.byref(cus))
+    if rc != 0:
+        raise MvgError("no usable AMD GPU (mvg_device_info -> %d)" % rc)
+    return buf.value.decode(), cus.value

@@ -1,0 +1,82 @@
+// Shared device helpers for libmvgformer_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvg_decoder.h"
+
+#define MVG_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// ---- 4-channel vector load / store in either storage type (always fp32 in registers)
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+    u16x4 r = *reinterpret_cast<const u16x4*>(p);
+    f32x4 v;
+    v[0] = bf16_to_f32(r[0]); v[1] = bf16_to_f32(r[1]); v[2] = bf16_to_f32(r[2]); v[3] = bf16_to_f32(r[3]);
+    return v;
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
+    u16x4 r;
+    r[0] = f32_to_bf16(v[0]); r[1] = f32_to_bf16(v[1]); r[2] = f32_to_bf16(v[2]); r[3] = f32_to_bf16(v[3]);
+    *reinterpret_cast<u16x4*>(p) = r;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float load1(const T* p);
+template <> __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void store1(T* p, float v);
+template <> __device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// Levels are passed by value to kernels (L <= MVG_MAX_LEVELS)
+#define MVG_MAX_LEVELS 8
+struct LevelTable {
+  int H[MVG_MAX_LEVELS];
+  int W[MVG_MAX_LEVELS];
+  int start[MVG_MAX_LEVELS];
+  int L;
+};
+
+static inline int mvg_fill_levels(LevelTable* t, const int64_t* shapes_host, const int64_t* starts_host, int L) {
+  if (L < 1 || L > MVG_MAX_LEVELS) return MVG_E_BADARG;
+  t->L = L;
+  for (int l = 0; l < L; ++l) {
+    t->H[l] = (int)shapes_host[2 * l];
+    t->W[l] = (int)shapes_host[2 * l + 1];
+    t->start[l] = (int)starts_host[l];
+  }
+  return 0;
+}
+
+#define MVG_LAUNCH_CHECK()                 \
+  do {                                     \
+    hipError_t _e = hipGetLastError();     \
+    if (_e != hipSuccess) return (int)_e;  \
+  } while (0)
+
+static inline int mvg_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,204 @@
+// Dense projections of the decoder layer on the gfx950 matrix cores.
+//
+//   out[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) * rowmask[M]
+//
+// A is activations (row-major, K contiguous), W an nn.Linear weight (row-major (N,K), K
+// contiguous) -- both operands are "K-major", so both are staged the same way.
+//   fp32 compute : v_mfma_f32_32x32x2_f32   (exact fp32 fmaf chain; 157 TF peak)
+//   bf16 compute : v_mfma_f32_32x32x16_bf16 (fp32 accumulate; 2.5 PF peak)
+// Tile 128x128 per 256-thread workgroup (4 wavefronts as 2x2, 64x64 per wavefront = 2x2 MFMA
+// tiles, 64 accumulator registers).  K is consumed in slabs of 128 BYTES per row (32 fp32 or
+// 64 bf16): with a 144-byte LDS row pitch every ds_read_b128 of a 16-lane group falls on 16
+// distinct 16-byte slots (36 dwords * i mod 64 is a distinct multiple of 4 for i mod 16), i.e.
+// bank-conflict-free, and the same byte offsets (32*g + 16*(lane>>5)) serve both data types:
+// an fp32 lane gets k = 8g+4h..+3 (fed to 4 successive 32x32x2 MFMAs -- the k order inside a
+// slab is permuted identically for A and W, which leaves the sum unchanged), a bf16 lane gets
+// k = 16g+8h..+7 (one 32x32x16 MFMA).
+// Global->register prefetch of slab t+1 overlaps the MFMAs of slab t.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, PITCH = 144;   // bytes per LDS row (128 data + 16 pad)
+
+struct Chunk {
+  f32x4 lo, hi;   // hi only used when converting an fp32 source to bf16 (8 values)
+};
+
+// load one 16-byte LDS chunk worth of K-values for (row, col16) of the current slab
+template <typename TSRC, bool BF16>
+__device__ __forceinline__ Chunk load_chunk(const TSRC* __restrict__ base, long ld, int row, int nrows, int k0,
+                                            int col16) {
+  Chunk c;
+  c.lo = f32x4{0.f, 0.f, 0.f, 0.f};
+  c.hi = c.lo;
+  if (row < nrows) {
+    if constexpr (!BF16) {
+      c.lo = *reinterpret_cast<const f32x4*>(base + (long)row * ld + k0 + col16 * 4);
+    } else if constexpr (sizeof(TSRC) == 2) {
+      c.lo = *reinterpret_cast<const f32x4*>(base + (long)row * ld + k0 + col16 * 8);   // 8 bf16 = 16 B, raw
+    } else {
+      const TSRC* p = base + (long)row * ld + k0 + col16 * 8;
+      c.lo = *reinterpret_cast<const f32x4*>(p);
+      c.hi = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  }
+  return c;
+}
+
+template <typename TSRC, bool BF16>
+__device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const Chunk& c) {
+  f32x4 v = c.lo;
+  if constexpr (BF16 && sizeof(TSRC) == 4) {
+    unsigned w[4];
+    w[0] = (unsigned)f32_to_bf16(c.lo[0]) | ((unsigned)f32_to_bf16(c.lo[1]) << 16);
+    w[1] = (unsigned)f32_to_bf16(c.lo[2]) | ((unsigned)f32_to_bf16(c.lo[3]) << 16);
+    w[2] = (unsigned)f32_to_bf16(c.hi[0]) | ((unsigned)f32_to_bf16(c.hi[1]) << 16);
+    w[3] = (unsigned)f32_to_bf16(c.hi[2]) | ((unsigned)f32_to_bf16(c.hi[3]) << 16);
+    v[0] = __uint_as_float(w[0]); v[1] = __uint_as_float(w[1]); v[2] = __uint_as_float(w[2]); v[3] = __uint_as_float(w[3]);
+  }
+  *reinterpret_cast<f32x4*>(lds + row * PITCH + col16 * 16) = v;
+}
+
+// TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
+template <typename TA, bool BF16, typename TO>
+__global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, long lda, const void* __restrict__ Wv,
+                                                     const float* __restrict__ bias, TO* __restrict__ out, long ldc,
+                                                     const uint8_t* __restrict__ rowmask, int relu, int M, int N,
+                                                     int K) {
+  using TW = typename std::conditional<BF16, bf16_t, float>::type;
+  const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
+  constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
+  __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * PITCH];
+  char* ldsA = lds;
+  char* ldsB = lds + BM * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const TA* Ab = A + (long)m0 * lda;
+  const TW* Wb = W + (long)n0 * K;
+  const int mrows = min(BM, M - m0), nrows = min(BN, N - n0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  Chunk ca[4], cb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
+      cb[i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      store_chunk<TA, BF16>(ldsA, c >> 3, c & 7, ca[i]);
+      store_chunk<TW, BF16>(ldsB, c >> 3, c & 7, cb[i]);
+    }
+  };
+
+  const int nk = K / KSLAB;
+  gload(0);
+  lstore();
+  __syncthreads();
+  const int rl = lane & 31, h = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * KSLAB);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const f32x4*>(ldsA + (wm * 64 + i * 32 + rl) * PITCH + 32 * g + 16 * h);
+        b[i] = *reinterpret_cast<const f32x4*>(ldsB + (wn * 64 + i * 32 + rl) * PITCH + 32 * g + 16 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (BF16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + rl;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < M) {
+          float v = acc[i][j][e] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (rowmask) v = rowmask[row] ? v : 0.f;
+          store1<TO>(out + (long)row * ldc + col, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename TA, bool BF16, typename TO>
+int launch_linear(const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
+                  const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias, (TO*)out, ldc,
+                     rowmask, relu, M, N, K);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
+                          int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {
+  if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return MVG_E_BADARG;
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = (w_dtype == MVG_BF16);
+  if (!bf && w_dtype != MVG_F32) return MVG_E_BADARG;
+  if (K % (bf ? 64 : 32) != 0) return MVG_E_BADARG;
+  const int a_el = (a_dtype == MVG_BF16) ? 2 : 4;
+  if (((long)lda * a_el) % 16 != 0 || (reinterpret_cast<uintptr_t>(A) % 16) != 0 || (reinterpret_cast<uintptr_t>(W) % 16) != 0)
+    return MVG_E_BADARG;
+  if (!bf) {
+    if (a_dtype != MVG_F32) return MVG_E_BADARG;   // fp32 MFMA path takes fp32 activations
+    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    return MVG_E_BADARG;
+  }
+  if (a_dtype == MVG_BF16) {
+    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+  } else if (a_dtype == MVG_F32) {
+    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+  }
+  return MVG_E_BADARG;
+}

@@ -1,0 +1,505 @@
+// Geometry + small per-token kernels of the MVGFormer decoder layer for gfx950:
+// pyramid packing, camera projection, reference-point feature gather, view mean,
+// residual+LayerNorm, class head, last pose-MLP layer, and the fused
+// refine-2D -> undistort -> DLT -> smallest-singular-vector -> scatter kernel.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// NCHW level -> channels-last pyramid rows.  32x32 tile transpose through LDS (padded to
+// 33 columns: conflict-free for the column reads), 128-B coalesced on both sides.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_level_kernel(const float* __restrict__ src, T* __restrict__ feat, int C,
+                                                         int HW, int S, int start) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* sp = src + (long)n * C * HW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, hw = hw0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && hw < HW) ? sp[(long)c * HW + hw] : 0.f;
+  }
+  __syncthreads();
+  T* fp = feat + ((long)n * S + start) * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int hw = hw0 + ty + 8 * i, c = c0 + tx;
+    if (hw < HW && c < C) store1<T>(fp + (long)hw * C + c, tile[tx][ty + 8 * i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// A.1 projection: pinhole + radial/tangential distortion, in-image test, clamp, crop affine.
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ X, const float* __restrict__ cams,
+                                                      LevelTable lv, float* __restrict__ r,
+                                                      float* __restrict__ ref_lvl, uint8_t* __restrict__ inside,
+                                                      int B, int Lq, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % Lq);
+  const int n = (int)(idx / Lq);
+  const int b = n % B;
+  const float* cam = cams + (long)n * MVG_CAM_STRIDE;
+  const float* xp = X + ((long)b * Lq + q) * 3;
+  const float d0 = xp[0] - cam[9], d1 = xp[1] - cam[10], d2 = xp[2] - cam[11];   // cameras.py:188
+  const float xc0 = cam[0] * d0 + cam[1] * d1 + cam[2] * d2;
+  const float xc1 = cam[3] * d0 + cam[4] * d1 + cam[5] * d2;
+  const float xc2 = cam[6] * d0 + cam[7] * d1 + cam[8] * d2;
+  const float zz = xc2 + 1e-5f;                                                    // cameras.py:190
+  float y0 = xc0 / zz, y1 = xc1 / zz;
+  const float r2 = y0 * y0 + y1 * y1;
+  const float radial = 1.f + (cam[16] * r2 + cam[17] * (r2 * r2) + cam[18] * (r2 * r2 * r2));   // :195-198
+  const float tang = cam[19] * y1 + cam[20] * y0;                                  // :200
+  const float corr = radial + 2.f * tang;
+  y0 = y0 * corr + cam[20] * r2;                                                   // :201-204
+  y1 = y1 * corr + cam[19] * r2;
+  float u = cam[12] * y0 + cam[14];                                                // :206
+  float v = cam[13] * y1 + cam[15];
+  const bool in_img = (u >= 0.f) && (v >= 0.f) && (u < cam[33]) && (v < cam[34]);  // dq_decoder.py:374-379
+  u = fminf(fmaxf(u, -1.f), cam[35]);                                              // :382-383
+  v = fminf(fmaxf(v, -1.f), cam[35]);
+  const float nx = cam[21] * u + cam[22] * v + cam[23];                            // transforms.py:135-141
+  const float ny = cam[24] * u + cam[25] * v + cam[26];
+  const float rx = nx / cam[36], ry = ny / cam[37];                                // dq_decoder.py:390-392
+  r[idx * 2] = rx;
+  r[idx * 2 + 1] = ry;
+  for (int l = 0; l < lv.L; ++l) {                                                 // dq_decoder.py:570-573
+    const float Wf = (float)lv.W[l], Hf = (float)lv.H[l];
+    ref_lvl[(idx * lv.L + l) * 2] = (rx * Wf) / (Wf - 1.f);
+    ref_lvl[(idx * lv.L + l) * 2 + 1] = (ry * Hf) / (Hf - 1.f);
+  }
+  inside[idx] = in_img ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// A.2 + A.3(1): bilinear ref-point features (grid_sample, zeros padding, align_corners=False)
+// of every level + query.  One wavefront per (image, query); lane owns 4 channels per 256.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_ref_kernel(const T* __restrict__ feat, const float* __restrict__ ref_lvl,
+                                                         const float* __restrict__ x, LevelTable lv,
+                                                         T* __restrict__ ain, int B, int Lq, int S, int C,
+                                                         int n_pairs) {
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= n_pairs) return;
+  const int lane = threadIdx.x & 63;
+  const int q = pair % Lq, n = pair / Lq, b = n % B;
+  const float* xq = x + ((long)b * Lq + q) * C;
+  const T* fbase = feat + (long)n * S * C;
+  for (int l = 0; l < lv.L; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    const float refx = ref_lvl[((long)pair * lv.L + l) * 2], refy = ref_lvl[((long)pair * lv.L + l) * 2 + 1];
+    const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);                 // projattn.py:134
+    const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+    const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f;                              // grid_sample unnormalize
+    const float iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - x0f, ty = iy - y0f;
+    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+    const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
+    const float w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+    const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
+    const float w11 = (x1ok && y1ok) ? tx * ty : 0.f;
+    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+    const T* p00 = fbase + ((long)lv.start[l] + (long)y0c * W + x0c) * C;
+    const T* p10 = fbase + ((long)lv.start[l] + (long)y0c * W + x1c) * C;
+    const T* p01 = fbase + ((long)lv.start[l] + (long)y1c * W + x0c) * C;
+    const T* p11 = fbase + ((long)lv.start[l] + (long)y1c * W + x1c) * C;
+    T* op = ain + ((long)pair * lv.L + l) * C;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 v = w00 * Vec4<T>::load(p00 + c) + w10 * Vec4<T>::load(p10 + c) + w01 * Vec4<T>::load(p01 + c) +
+                      w11 * Vec4<T>::load(p11 + c);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xq + c);
+      Vec4<T>::store(op + c, v + xv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mean_views_kernel(const T* __restrict__ attn, T* __restrict__ out, int V,
+                                                         long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = Vec4<T>::load(attn + i * 4);
+  for (int v = 1; v < V; ++v) acc += Vec4<T>::load(attn + ((long)v * n4 + i) * 4);
+  Vec4<T>::store(out + i * 4, acc / (float)V);
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// y = LN(res + h): one wavefront per row, C = 256 -> 4 channels per lane (any C % 4 == 0, C <= 1024).
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ res, const T* __restrict__ h,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, int rows, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < C) {
+      v[i] = *reinterpret_cast<const f32x4*>(res + (long)row * C + c) + Vec4<T>::load(h + (long)row * C + c);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (lane * 4 + 256 * i < C) {
+      const f32x4 d = v[i] - mean;
+      ss += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)C + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < C) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), bb = *reinterpret_cast<const f32x4*>(beta + c);
+      *reinterpret_cast<f32x4*>(y + (long)row * C + c) = (v[i] - mean) * rstd * g + bb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// A.5 class head: prob[b,i,:] = mean_j sigmoid(Wc tgt[b, i*J+j] + bc); one wavefront per query.
+__global__ __launch_bounds__(256) void class_head_kernel(const float* __restrict__ tgt, const float* __restrict__ Wc,
+                                                         const float* __restrict__ bc, float threshold,
+                                                         const uint8_t* __restrict__ forced, float* __restrict__ prob,
+                                                         uint8_t* __restrict__ valid, int* __restrict__ any_valid,
+                                                         int nq_total, int J, int C) {
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq_total) return;
+  const int lane = threadIdx.x & 63;
+  float p0 = 0.f, p1 = 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float* t = tgt + ((long)qi * J + j) * C;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 tv = *reinterpret_cast<const f32x4*>(t + c);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + c), w1 = *reinterpret_cast<const f32x4*>(Wc + C + c);
+      a0 += tv[0] * w0[0] + tv[1] * w0[1] + tv[2] * w0[2] + tv[3] * w0[3];
+      a1 += tv[0] * w1[0] + tv[1] * w1[1] + tv[2] * w1[2] + tv[3] * w1[3];
+    }
+    a0 = wave_sum(a0) + bc[0];
+    a1 = wave_sum(a1) + bc[1];
+    p0 += 1.f / (1.f + expf(-a0));
+    p1 += 1.f / (1.f + expf(-a1));
+  }
+  if (lane == 0) {
+    p0 /= (float)J;
+    p1 /= (float)J;
+    prob[2 * (long)qi] = p0;
+    prob[2 * (long)qi + 1] = p1;
+    const bool ok = forced ? (forced[qi] != 0) : (p1 > threshold);   // dq_decoder.py:605
+    valid[qi] = ok ? 1 : 0;
+    if (ok) atomicOr(any_valid, 1);
+  }
+}
+
+// last pose_embed layer: 3 dot products per row, one wavefront per row.
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot3_kernel(const T* __restrict__ h, const float* __restrict__ W3,
+                                                      const float* __restrict__ b3, float* __restrict__ o, int rows,
+                                                      int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 hv = Vec4<T>::load(h + (long)row * C + c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W3 + k * C + c);
+      a[k] += hv[0] * w[0] + hv[1] * w[1] + hv[2] * w[2] + hv[3] * w[3];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) a[k] = wave_sum(a[k]);
+  if (lane < 3) o[(long)row * 3 + lane] = (lane == 0 ? a[0] : lane == 1 ? a[1] : a[2]) + b3[lane];
+}
+
+// ------------------------------------------------------------------------------------------
+// A.6-A.8.  One thread per (batch, query, joint).
+//  - refined 2D = (r + (dx,dy)/img) * img, view confidence = softmax over views of the logit
+//  - un-crop (inverse affine), K^-1, 5 fixed-point undistortion iterations, K
+//  - DLT rows conf*(x*P2 - P0), conf*(y*P2 - P1) with P = K [R | -R T] in fp32 exactly as the
+//    reference builds them; the 4x4 Gram matrix of the 2V rows is accumulated in fp64 and its
+//    smallest eigenvector (= smallest right singular vector of A, torch.linalg.svd's Vh[3]) is
+//    found with cyclic Jacobi rotations in fp64.  Squaring the condition number in fp64
+//    (eps 1.1e-16) leaves far more headroom than an fp32 SVD of A (eps 6e-8) has.
+__device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][4], const int p, const int q) {
+  const double apq = a[p][q];
+  if (fabs(apq) < 1e-300) return;
+  const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // columns p,q of A
+    const double akp = a[k][p], akq = a[k][q];
+    a[k][p] = c * akp - s * akq;
+    a[k][q] = s * akp + c * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // rows p,q of A
+    const double apk = a[p][k], aqk = a[q][k];
+    a[p][k] = c * apk - s * aqk;
+    a[q][k] = s * apk + c * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double vkp = v[k][p], vkq = v[k][q];
+    v[k][p] = c * vkp - s * vkq;
+    v[k][q] = s * vkp + c * vkq;
+  }
+}
+
+__global__ __launch_bounds__(256) void triangulate_kernel(const float* __restrict__ r, const float* __restrict__ o,
+                                                          const float* __restrict__ cams,
+                                                          const uint8_t* __restrict__ valid,
+                                                          const int* __restrict__ any_valid,
+                                                          float* __restrict__ new_ref, float* __restrict__ ref2d,
+                                                          float* __restrict__ proj2d, int V, int B, int NQ, int J) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Lq = NQ * J;
+  if (idx >= (long)B * Lq) return;
+  const int q = (int)(idx % Lq), b = (int)(idx / Lq);
+  const int i = q / J;
+  bool ok = valid[b * NQ + i] != 0;
+  if (!ok && any_valid[0] == 0 && b == 0 && i == 0) ok = true;   // dq_decoder.py:620-623
+
+  // softmax over views of the confidence logit (dq_decoder.py:706-707)
+  float mx = -INFINITY;
+  for (int v = 0; v < V; ++v) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
+
+  double G[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) G[a][c] = 0.0;
+
+  for (int v = 0; v < V; ++v) {
+    const long pair = ((long)v * B + b) * Lq + q;
+    const float* cam = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
+    const float imgw = cam[36], imgh = cam[37];
+    const float rx = r[pair * 2], ry = r[pair * 2 + 1];
+    const float dx = o[pair * 3], dy = o[pair * 3 + 1];
+    const float conf = expf(o[pair * 3 + 2] - mx) / den;
+    const float px = rx * imgw, py = ry * imgh;                                   // dq_decoder.py:699
+    const float kx = (rx + dx / imgw) * imgw, ky = (ry + dy / imgh) * imgh;       // :679-685,696
+    const long oidx = (((long)b * V + v) * Lq + q) * 2;
+    ref2d[oidx] = ok ? kx : 0.f;
+    ref2d[oidx + 1] = ok ? ky : 0.f;
+    proj2d[oidx] = ok ? px : 0.f;
+    proj2d[oidx + 1] = ok ? py : 0.f;
+    // un-crop (dq_decoder.py:414-420)
+    const float uo = cam[27] * kx + cam[28] * ky + cam[29];
+    const float vo = cam[30] * kx + cam[31] * ky + cam[32];
+    // undistort (dq_decoder.py:119-204)
+    const float fx = cam[12], fy = cam[13], cx = cam[14], cy = cam[15];
+    const float k1 = cam[16], k2 = cam[17], k3 = cam[18], p1 = cam[19], p2 = cam[20];
+    const float x0 = uo * (1.f / fx) + (-cx / fx), y0 = vo * (1.f / fy) + (-cy / fy);
+    float x = x0, y = y0;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const float r2 = x * x + y * y;
+      const float icd = 1.f / (1.f + ((k3 * r2 + k2) * r2 + k1) * r2);
+      const float dX = 2.f * p1 * x * y + p2 * (r2 + 2.f * x * x);
+      const float dY = p1 * (r2 + 2.f * y * y) + 2.f * p2 * x * y;
+      x = (x0 - dX) * icd;
+      y = (y0 - dY) * icd;
+    }
+    const float udx = fx * x + cx, udy = fy * y + cy;
+    // P = K [R | -R T]  (dq_decoder.py:223-246)
+    float RT[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      RT[a][0] = cam[3 * a]; RT[a][1] = cam[3 * a + 1]; RT[a][2] = cam[3 * a + 2];
+      RT[a][3] = -(cam[3 * a] * cam[9] + cam[3 * a + 1] * cam[10] + cam[3 * a + 2] * cam[11]);
+    }
+    float a1[4], a2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float P0 = fx * RT[0][c] + cx * RT[2][c];
+      const float P1 = fy * RT[1][c] + cy * RT[2][c];
+      const float P2 = RT[2][c];
+      a1[c] = (P2 * udx - P0) * conf;                                             // multiview.py:196-202
+      a2[c] = (P2 * udy - P1) * conf;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = a; c < 4; ++c) G[a][c] += (double)a1[a] * (double)a1[c] + (double)a2[a] * (double)a2[c];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < a; ++c) G[a][c] = G[c][a];
+
+  double Vm[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Vm[a][c] = (a == c) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
+    const double dg = fabs(G[0][0]) + fabs(G[1][1]) + fabs(G[2][2]) + fabs(G[3][3]);
+    if (off <= 1e-30 * dg) break;
+    jacobi_rotate(G, Vm, 0, 1);
+    jacobi_rotate(G, Vm, 0, 2);
+    jacobi_rotate(G, Vm, 0, 3);
+    jacobi_rotate(G, Vm, 1, 2);
+    jacobi_rotate(G, Vm, 1, 3);
+    jacobi_rotate(G, Vm, 2, 3);
+  }
+  double best = G[0][0];
+  double e0 = Vm[0][0], e1 = Vm[1][0], e2 = Vm[2][0], e3 = Vm[3][0];
+#pragma unroll
+  for (int c = 1; c < 4; ++c) {
+    if (G[c][c] < best) {
+      best = G[c][c];
+      e0 = Vm[0][c]; e1 = Vm[1][c]; e2 = Vm[2][c]; e3 = Vm[3][c];
+    }
+  }
+  float* nr = new_ref + ((long)b * Lq + q) * 3;
+  nr[0] = ok ? (float)(e0 / e3) : 0.f;                                            // multiview.py:220-221
+  nr[1] = ok ? (float)(e1 / e3) : 0.f;
+  nr[2] = ok ? (float)(e2 / e3) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W, int S, int start,
+                   void* stream) {
+  if (!src_nchw || !feat || N_img <= 0 || C <= 0 || H <= 0 || W <= 0 || start < 0 || start + H * W > S) return MVG_E_BADARG;
+  const int HW = H * W;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, N_img);
+  if (dtype == MVG_F32)
+    hipLaunchKernelGGL((pack_level_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src_nchw, (float*)feat, C, HW, S, start);
+  else if (dtype == MVG_BF16)
+    hipLaunchKernelGGL((pack_level_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, src_nchw, (bf16_t*)feat, C, HW, S, start);
+  else
+    return MVG_E_BADARG;
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_project(const float* X, const float* cams, const int64_t* shapes_host, int L, float* r, float* ref_lvl,
+                uint8_t* inside, int V, int B, int Lq, void* stream) {
+  if (!X || !cams || !shapes_host || !r || !ref_lvl || !inside || V <= 0 || B <= 0 || Lq < 0) return MVG_E_BADARG;
+  LevelTable lv;
+  int64_t zeros[MVG_MAX_LEVELS] = {0};
+  int e = mvg_fill_levels(&lv, shapes_host, zeros, L);
+  if (e) return e;
+  const long total = (long)V * B * Lq;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(project_kernel, dim3(mvg_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, X, cams, lv, r,
+                     ref_lvl, inside, B, Lq, total);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_gather_ref(const void* feat, int dtype, const float* ref_lvl, const float* x, const int64_t* shapes_host,
+                   const int64_t* starts_host, void* ain, int V, int B, int Lq, int L, int S, int C, void* stream) {
+  if (!feat || !ref_lvl || !x || !shapes_host || !starts_host || !ain || C % 4 != 0) return MVG_E_BADARG;
+  LevelTable lv;
+  int e = mvg_fill_levels(&lv, shapes_host, starts_host, L);
+  if (e) return e;
+  const long pairs = (long)V * B * Lq;
+  if (pairs == 0) return 0;
+  const int grid = mvg_ceil_div(pairs, 4);
+  if (dtype == MVG_F32)
+    hipLaunchKernelGGL((gather_ref_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)feat, ref_lvl, x,
+                       lv, (float*)ain, B, Lq, S, C, (int)pairs);
+  else if (dtype == MVG_BF16)
+    hipLaunchKernelGGL((gather_ref_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, ref_lvl,
+                       x, lv, (bf16_t*)ain, B, Lq, S, C, (int)pairs);
+  else
+    return MVG_E_BADARG;
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream) {
+  if (!attn || !out || V <= 0 || C % 4 != 0) return MVG_E_BADARG;
+  const long n4 = (long)rows * C / 4;
+  if (n4 == 0) return 0;
+  const int grid = mvg_ceil_div(n4, 256);
+  if (dtype == MVG_F32)
+    hipLaunchKernelGGL((mean_views_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)attn, (float*)out, V, n4);
+  else if (dtype == MVG_BF16)
+    hipLaunchKernelGGL((mean_views_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)attn, (bf16_t*)out, V, n4);
+  else
+    return MVG_E_BADARG;
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_add_layernorm(const float* res, const void* h, int h_dtype, const float* gamma, const float* beta, float* y,
+                      int rows, int C, void* stream) {
+  if (!res || !h || !gamma || !beta || !y || C % 4 != 0 || C > 1024) return MVG_E_BADARG;
+  if (rows == 0) return 0;
+  const int grid = mvg_ceil_div(rows, 4);
+  if (h_dtype == MVG_F32)
+    hipLaunchKernelGGL((add_ln_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, res, (const float*)h, gamma, beta, y, rows, C);
+  else if (h_dtype == MVG_BF16)
+    hipLaunchKernelGGL((add_ln_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, res, (const bf16_t*)h, gamma, beta, y, rows, C);
+  else
+    return MVG_E_BADARG;
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_class_head(const float* tgt, const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
+                   float* prob, uint8_t* valid, int* any_valid, int B, int NQ, int J, int C, void* stream) {
+  if (!tgt || !Wc || !bc || !prob || !valid || !any_valid || C % 4 != 0) return MVG_E_BADARG;
+  const int nq_total = B * NQ;
+  if (nq_total == 0) return 0;
+  hipLaunchKernelGGL(class_head_kernel, dim3(mvg_ceil_div(nq_total, 4)), dim3(256), 0, (hipStream_t)stream, tgt, Wc, bc,
+                     threshold, forced_valid, prob, valid, any_valid, nq_total, J, C);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, float* o, int rows, int C, void* stream) {
+  if (!h || !W3 || !b3 || !o || C % 4 != 0) return MVG_E_BADARG;
+  if (rows == 0) return 0;
+  const int grid = mvg_ceil_div(rows, 4);
+  if (h_dtype == MVG_F32)
+    hipLaunchKernelGGL((rowdot3_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)h, W3, b3, o, rows, C);
+  else if (h_dtype == MVG_BF16)
+    hipLaunchKernelGGL((rowdot3_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, W3, b3, o, rows, C);
+  else
+    return MVG_E_BADARG;
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
+                    float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J, void* stream) {
+  if (!r || !o || !cams || !valid || !any_valid || !new_ref || !ref2d || !proj2d || V <= 0) return MVG_E_BADARG;
+  const long total = (long)B * NQ * J;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, r, o, cams,
+                     valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

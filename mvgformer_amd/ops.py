@@ -1,0 +1,229 @@
+"""Stage-level wrappers over the C ABI: torch tensors in, torch tensors out.
+
+Each function validates what the C side cannot (device, dtype, contiguity), allocates the
+output with torch and enqueues the HIP kernel on torch's current stream.  No host sync.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _i64_host(t):
+    """small int64 table (shapes / starts) as a host ctypes array (no device sync if it is
+    already a CPU tensor / list)."""
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().tolist()
+    flat = np.asarray(t, dtype=np.int64).reshape(-1)
+    return (C.c_int64 * len(flat))(*flat.tolist()), flat
+
+
+class Levels:
+    """Host copy of (spatial_shapes, level_start_index): avoids a D2H sync per call."""
+
+    def __init__(self, spatial_shapes, level_start_index):
+        self.shapes_c, shapes = _i64_host(spatial_shapes)
+        self.starts_c, starts = _i64_host(level_start_index)
+        self.shapes = shapes.reshape(-1, 2)
+        self.starts = starts
+        self.L = len(starts)
+        self.S = int((self.shapes[:, 0] * self.shapes[:, 1]).sum())
+
+
+# --------------------------------------------------------------------------- Deformable op
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    """Deformable.deform_forward (lib/models/ops/src/deform.h:32-50)."""
+    L.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)      # deform_cuda.cu:39-43
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    N, S, M, D = value.shape
+    _, Lq, _, nl, P, _ = sampling_loc.shape
+    lib = L.load()
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    if value.dtype == torch.float32:
+        if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
+            raise RuntimeError("sampling_loc / attn_weight must be float32")
+        rc = lib.mvg_msda_forward_f32(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index), L.ptr(sampling_loc),
+                                      L.ptr(attn_weight), L.ptr(out), N, S, M, D, nl, Lq, P, L.stream_ptr())
+    elif value.dtype == torch.bfloat16:
+        rc = lib.mvg_msda_forward_bf16(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index),
+                                       L.ptr(sampling_loc.float().contiguous()), L.ptr(attn_weight.float().contiguous()),
+                                       L.ptr(out), N, S, M, D, nl, Lq, P, L.stream_ptr())
+    else:
+        raise RuntimeError("deform_forward: float32 / bfloat16 only (got %s)" % value.dtype)
+    L.check(rc, "mvg_msda_forward")
+    return out
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
+    """Deformable.deform_backward (lib/models/ops/src/deform.h:53-72)."""
+    L.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
+    if value.dtype != torch.float32:
+        raise RuntimeError("deform_backward: float32 only")
+    grad_output = grad_output.contiguous()
+    N, S, M, D = value.shape
+    _, Lq, _, nl, P, _ = sampling_loc.shape
+    gv = torch.zeros_like(value)                                             # deform_cuda.cu:132-134
+    gl = torch.empty_like(sampling_loc)
+    ga = torch.empty_like(attn_weight)
+    rc = L.load().mvg_msda_backward_f32(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index),
+                                        L.ptr(sampling_loc), L.ptr(attn_weight), L.ptr(grad_output), L.ptr(gv), L.ptr(gl),
+                                        L.ptr(ga), N, S, M, D, nl, Lq, P, L.stream_ptr())
+    L.check(rc, "mvg_msda_backward_f32")
+    return gv, gl, ga
+
+
+# ----------------------------------------------------------------------------- stage ops
+def pack_pyramid(src_views, levels, dtype):
+    """list of L (N_img,C,H,W) fp32 maps -> channels-last pyramid (N_img,S,C) in `dtype`."""
+    lib = L.load()
+    n_img, Cc = src_views[0].shape[:2]
+    feat = torch.empty((n_img, levels.S, Cc), dtype=dtype, device=src_views[0].device)
+    for l, src in enumerate(src_views):
+        L.require_cuda(src)
+        s = src.float().contiguous()
+        H, W = int(levels.shapes[l, 0]), int(levels.shapes[l, 1])
+        if tuple(s.shape) != (n_img, Cc, H, W):
+            raise RuntimeError("src_views[%d] has shape %s, expected %s" % (l, tuple(s.shape), (n_img, Cc, H, W)))
+        L.check(lib.mvg_pack_level(L.ptr(s), L.ptr(feat), L.dtype_code(dtype), n_img, Cc, H, W, levels.S,
+                                   int(levels.starts[l]), L.stream_ptr()), "mvg_pack_level")
+    return feat
+
+
+def project(X, cams, levels, V, B):
+    Lq = X.shape[1]
+    r = torch.empty((V * B, Lq, 2), dtype=torch.float32, device=X.device)
+    ref_lvl = torch.empty((V * B, Lq, levels.L, 2), dtype=torch.float32, device=X.device)
+    inside = torch.empty((V * B, Lq), dtype=torch.uint8, device=X.device)
+    L.check(L.load().mvg_project(L.ptr(X), L.ptr(cams), levels.shapes_c, levels.L, L.ptr(r), L.ptr(ref_lvl),
+                                 L.ptr(inside), V, B, Lq, L.stream_ptr()), "mvg_project")
+    return r, ref_lvl, inside
+
+
+def gather_ref(feat, r, x, levels, V, B):
+    """r: per-level reference points (n_img, Lq, L, 2)."""
+    n_img, S, Cc = feat.shape
+    Lq = r.shape[1]
+    ain = torch.empty((n_img * Lq * levels.L, Cc), dtype=feat.dtype, device=feat.device)
+    L.check(L.load().mvg_gather_ref(L.ptr(feat), L.dtype_code(feat.dtype), L.ptr(r), L.ptr(x), levels.shapes_c,
+                                    levels.starts_c, L.ptr(ain), V, B, Lq, levels.L, S, Cc, L.stream_ptr()),
+            "mvg_gather_ref")
+    return ain
+
+
+def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None):
+    """out = act(a @ w.T + bias) (* rowmask).  a (M,K) f32|bf16; w (N,K) f32|bf16 (compute type)."""
+    M, K = a.shape
+    N = w.shape[0]
+    out_dtype = out_dtype or (torch.float32 if w.dtype == torch.float32 else torch.bfloat16)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    if a.stride(1) != 1 or not w.is_contiguous() or out.stride(1) != 1:
+        raise RuntimeError("mvg_linear: K-contiguous operands required")
+    L.check(L.load().mvg_linear(L.ptr(a), L.dtype_code(a.dtype), a.stride(0), L.ptr(w), L.dtype_code(w.dtype),
+                                L.ptr(bias), L.ptr(out), L.dtype_code(out.dtype), out.stride(0), L.ptr(rowmask),
+                                1 if relu else 0, M, N, K, L.stream_ptr()), "mvg_linear")
+    return out
+
+
+def msda_fused(value, oa, r, levels):
+    """r: per-level reference points (n_img, Lq, L, 2)."""
+    n_img, S, Cc = value.shape
+    Lq = r.shape[1]
+    samp = torch.empty((n_img * Lq, Cc), dtype=value.dtype, device=value.device)
+    L.check(L.load().mvg_msda_fused(L.ptr(value), L.dtype_code(value.dtype), L.ptr(oa), L.ptr(r), levels.shapes_c,
+                                    levels.starts_c, L.ptr(samp), n_img, Lq, levels.L, S, L.stream_ptr()),
+            "mvg_msda_fused")
+    return samp
+
+
+def mean_views(attn, V):
+    rows = attn.shape[0] // V
+    out = torch.empty((rows, attn.shape[1]), dtype=attn.dtype, device=attn.device)
+    L.check(L.load().mvg_mean_views(L.ptr(attn), L.dtype_code(attn.dtype), L.ptr(out), V, rows, attn.shape[1],
+                                    L.stream_ptr()), "mvg_mean_views")
+    return out
+
+
+def add_layernorm(res, h, gamma, beta):
+    rows, Cc = res.shape
+    y = torch.empty((rows, Cc), dtype=torch.float32, device=res.device)
+    L.check(L.load().mvg_add_layernorm(L.ptr(res), L.ptr(h), L.dtype_code(h.dtype), L.ptr(gamma), L.ptr(beta), L.ptr(y),
+                                       rows, Cc, L.stream_ptr()), "mvg_add_layernorm")
+    return y
+
+
+def class_head(tgt, Wc, bc, threshold, B, NQ, J, forced_valid=None):
+    Cc = tgt.shape[-1]
+    prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=tgt.device)
+    valid = torch.empty((B, NQ), dtype=torch.uint8, device=tgt.device)
+    any_valid = torch.zeros((1,), dtype=torch.int32, device=tgt.device)
+    L.check(L.load().mvg_class_head(L.ptr(tgt), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(prob),
+                                    L.ptr(valid), L.ptr(any_valid), B, NQ, J, Cc, L.stream_ptr()), "mvg_class_head")
+    return prob, valid, any_valid
+
+
+def rowdot3(h, W3, b3):
+    rows, Cc = h.shape
+    o = torch.empty((rows, 3), dtype=torch.float32, device=h.device)
+    L.check(L.load().mvg_rowdot3(L.ptr(h), L.dtype_code(h.dtype), L.ptr(W3), L.ptr(b3), L.ptr(o), rows, Cc,
+                                 L.stream_ptr()), "mvg_rowdot3")
+    return o
+
+
+def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J):
+    Lq = NQ * J
+    dev = r.device
+    new_ref = torch.empty((B, Lq, 3), dtype=torch.float32, device=dev)
+    ref2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
+    proj2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
+    L.check(L.load().mvg_triangulate(L.ptr(r), L.ptr(o), L.ptr(cams), L.ptr(valid), L.ptr(any_valid), L.ptr(new_ref),
+                                     L.ptr(ref2d), L.ptr(proj2d), V, B, NQ, J, L.stream_ptr()), "mvg_triangulate")
+    return new_ref, ref2d, proj2d
+
+
+# ------------------------------------------------------------------------- camera packing
+def pack_cameras(meta, img_size, device):
+    """meta (list[V] of per-view dicts, JointsDataset.py:197-220) -> (V*B, CAM_STRIDE) fp32
+    device tensor, image index n = v*B + b.  The crop affine is the closed form of
+    get_affine_transform(center, scale, 0, img_size) (lib/utils/transforms.py:72-112) that the
+    reference evaluates with numpy/cv2 per view per layer (dq_decoder.py:361-372); here it is
+    computed once per forward."""
+    V = len(meta)
+    B = meta[0]["center"].shape[0]
+    rec = np.zeros((V, B, L.CAM_STRIDE), dtype=np.float32)
+    wh_all = []
+    for v, m in enumerate(meta):
+        cam = {k: t.detach().float().cpu().numpy() for k, t in m["camera"].items()
+               if k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
+        center = m["center"].detach().cpu().numpy().astype(np.float64)            # (B,2)
+        scale = m["scale"].detach().cpu().numpy().astype(np.float32)
+        inv = m["inv_affine_trans"].detach().cpu().numpy().astype(np.float64)[:, :2, :]
+        rec[v, :, 0:9] = cam["R"].reshape(B, 9)
+        rec[v, :, 9:12] = cam["T"].reshape(B, 3)
+        rec[v, :, 12], rec[v, :, 13] = cam["fx"].reshape(B), cam["fy"].reshape(B)
+        rec[v, :, 14], rec[v, :, 15] = cam["cx"].reshape(B), cam["cy"].reshape(B)
+        rec[v, :, 16:19] = cam["k"].reshape(B, 3)
+        rec[v, :, 19:21] = cam["p"].reshape(B, 2)
+        c32 = center.astype(np.float32).astype(np.float64)
+        st = (scale * np.float32(200.0)).astype(np.float64)
+        dw, dh = float(img_size[0]), float(img_size[1])
+        s = np.where(st[:, 0] >= st[:, 1], dw / st[:, 0], dh / st[:, 1])
+        rec[v, :, 21], rec[v, :, 25] = s, s
+        rec[v, :, 23] = dw * 0.5 - s * c32[:, 0]
+        rec[v, :, 26] = dh * 0.5 - s * c32[:, 1]
+        rec[v, :, 27:33] = inv.reshape(B, 6)
+        wh = center * 2.0
+        rec[v, :, 33:35] = wh
+        rec[v, :, 35] = wh.max()                                                   # dq_decoder.py:383 (whole-batch max)
+        rec[v, :, 36], rec[v, :, 37] = dw, dh
+        wh_all.append(wh)
+    return torch.from_numpy(rec.reshape(V * B, L.CAM_STRIDE)).to(device)

@@ -1,0 +1,169 @@
+"""ProjAttn -- projective attention module.  Same constructor, parameters, state-dict keys and
+forward signature as the reference (lib/models/ops/modules/projattn.py:42-204); the compute
+runs on libmvgformer_hip.so.
+
+Two execution paths, both GPU-only (no CPU fallback):
+  * inference (autograd off): gather -> MFMA linears -> fused softmax+locations+sampling
+    kernel -> MFMA output projection.  Locations / attention weights never touch HBM.
+  * training (autograd on): the reference's op chain with torch autograd for the dense parts
+    and DeformFunction (HIP forward + backward kernels) for the sampling.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import ops
+from .functions import DeformFunction
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class WeightCache:
+    """Contiguous copies of module parameters in the compute dtype, rebuilt when a parameter
+    is modified in place (``_version``) or replaced."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, params, dtype, build=None):
+        stamp = tuple((id(p), p._version, p.device) for p in params) + (dtype,)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            t = build(*params) if build is not None else params[0]
+            t = t.detach().to(dtype).contiguous()
+        self._store[key] = (stamp, t)
+        return t
+
+
+class ProjAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, projattn_posembed_mode="use_rayconv"):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("d_model // n_heads should be a power of 2 (the HIP kernels vectorise over head channels)")
+        self.im2col_step = 64
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        if projattn_posembed_mode == "use_rayconv":
+            self.rayconv = nn.Linear(d_model + 3, d_model)
+        elif projattn_posembed_mode == "use_2d_coordconv":
+            self.rayconv = nn.Linear(d_model + 2, d_model)
+        elif projattn_posembed_mode == "ablation_not_use_rayconv":
+            self.rayconv = nn.Linear(d_model, d_model)
+        else:
+            raise ValueError("invalid projective attention posembed mode")
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+        self.projattn_posembed_mode = projattn_posembed_mode
+        self.compute_dtype = torch.float32
+        self._wc = WeightCache()
+
+    def _reset_parameters(self):
+        constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2) \
+            .repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.rayconv.weight.data)
+        constant_(self.rayconv.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    # ------------------------------------------------------------------ native building blocks
+    def fused_supported(self, feat_lvls):
+        return (self.projattn_posembed_mode == "ablation_not_use_rayconv" and self.d_model == 256 and
+                self.n_heads == 8 and self.n_points == 8 and self.n_levels == 1 and 1 <= feat_lvls <= 4)
+
+    def weights(self, dtype):
+        """(Wv, bv, W_oa, b_oa, Wp, bp): value / [offsets|logits] / output projections."""
+        wc = self._wc
+        cat = lambda a, b: torch.cat([a, b], 0)
+        return (wc.get("Wv", (self.rayconv.weight,), dtype),
+                wc.get("bv", (self.rayconv.bias,), torch.float32),
+                wc.get("Woa", (self.sampling_offsets.weight, self.attention_weights.weight), dtype, cat),
+                wc.get("boa", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, cat),
+                wc.get("Wp", (self.output_proj.weight,), dtype),
+                wc.get("bp", (self.output_proj.bias,), torch.float32))
+
+    def native_forward(self, x, r, feat, levels, V, B, rowmask=None):
+        """Inference path on packed inputs.  x (B,Lq,C) f32 = tgt+query_pos; r (V*B,Lq,L,2) the
+        per-level reference points; feat (V*B,S,C) channels-last pyramid in the compute dtype.
+        Returns (V*B*Lq, C)."""
+        dt = feat.dtype
+        Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
+        n_img, S, Cc = feat.shape
+        ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
+        value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
+        oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
+        samp = ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
+        return ops.linear(samp, Wp, bp, out_dtype=dt, rowmask=rowmask)       # projattn.py:203 (+ dq_decoder.py:585)
+
+    # ------------------------------------------------------------------------------- forward
+    def forward(self, query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        """Reference signature (projattn.py:115-117).  query (n_views, Lq, C); reference_points
+        (n_views, Lq, n_levels, 2) already rescaled per level; src_views list of (n_views,C,H,W)."""
+        if not query.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")                  # deform.h:49
+        n_views, Len_q, c = query.shape
+        feat_lvls = len(src_views)
+        if self.projattn_posembed_mode != "ablation_not_use_rayconv":
+            raise NotImplementedError("projattn_posembed_mode=%r: only 'ablation_not_use_rayconv' (every shipped "
+                                      "YAML) is built" % self.projattn_posembed_mode)
+        if reference_points.shape[-1] != 2:
+            raise ValueError("Last dim of reference_points must be 2, but get {} instead."
+                             .format(reference_points.shape[-1]))
+        if not torch.is_grad_enabled() and input_padding_mask is None and self.fused_supported(feat_lvls):
+            levels = ops.Levels(input_spatial_shapes, input_level_start_index)
+            feat = ops.pack_pyramid(src_views, levels, self.compute_dtype)
+            out = self.native_forward(query.float().contiguous(), reference_points.float().contiguous(), feat, levels,
+                                      1, n_views)
+            return out.view(n_views, Len_q, c).to(query.dtype)
+        sample_grid = torch.clamp(reference_points * 2.0 - 1.0, -1.1, 1.1)
+        feats = [F.grid_sample(src_views[l], sample_grid[:, :, l:l + 1, :], align_corners=False).squeeze(-1)
+                 .permute(0, 2, 1) for l in range(feat_lvls)]
+        input_flatten = torch.cat([s.flatten(2) for s in src_views], dim=-1).permute(0, 2, 1)
+        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == input_flatten.shape[1]
+        value = self.rayconv(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(n_views, -1, self.n_heads, self.d_model // self.n_heads)
+        xin = torch.stack(feats, dim=2) + query.unsqueeze(2)
+        sampling_offsets = self.sampling_offsets(xin).view(n_views, Len_q, self.n_heads, feat_lvls, self.n_points, 2)
+        attention_weights = self.attention_weights(xin).view(n_views, Len_q, self.n_heads, feat_lvls * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(n_views, Len_q, self.n_heads, feat_lvls,
+                                                                  self.n_points)
+        offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+        sampling_locations = reference_points[:, :, None, :, None, :] \
+            + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        output = DeformFunction.apply(value.contiguous(), input_spatial_shapes.contiguous(),
+                                      input_level_start_index.contiguous(), sampling_locations.contiguous(),
+                                      attention_weights.contiguous(), self.im2col_step)
+        return self.output_proj(output)
+
+
+# north_star alias
+MSDeformAttn = ProjAttn

@@ -153,3 +153,16 @@ def test_reference_fp32_dlt_noise():
                                   case.img_size, threshold=float(g["threshold"]), dtype=torch.float64)
     err = (out[1] - torch.from_numpy(g["refs"][0]).double()).norm(dim=-1)
     assert 1e-3 < float(err.max()) < 1.5     # ~0.85 mm: conditioning noise, not a bug
+
+
+@pytest.mark.parametrize("name", ["small_f32", "ragged_f32", "edge_f32"])
+def test_c_restatement_matches_reference_twin(name):
+    """oracle/msda_ref.c (plain C, cuh:248-309 restated) vs the reference's CPU twin."""
+    import subprocess
+    from oracle import msda_c
+    if not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "libmsda_ref.so")):
+        subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(GOLD), "..", "oracle")])
+    g = _load("msda")
+    c = msda_case(name)
+    y = msda_c.msda_forward(c["value"], c["shapes"], c["starts"], c["loc"], c["weight"])
+    assert _maxrel(y, g[name + "/out"]) < 2e-6
