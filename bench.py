@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- MVGFormer decoder hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = ONE decoder forward (DQDecoder.forward-equivalent: pyramid packing, all layers, all
+views, 2D refinement, triangulation, output scatter/stack; backbone and data loading excluded)
+over one synthetic sample already resident in HBM.  Workload = BASELINE.json configs[1]:
+Panoptic CMU0 geometry, 5 views, 1024 queries x 15 joints, 4 layers, feature maps
+(128,240)/(64,120)/(32,60) x 256 ch, bf16 storage + bf16 MFMA with fp32 accumulation
+(geometry fp32/fp64).  With N > 1 the person-queries are sharded over the ranks
+(BASELINE.json configs[2]) and the pose set is assembled with one RCCL all-gather per forward.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     : the sampling kernel (msda_fused), HIP-event timed per launch on its stream
+  cpu_baseline : the CPU oracle (oracle/decoder_ref.py, "port") timed on the host cores on a
+                 bounded sample (1 of the 4 layers, all views / queries), scaled to samples/s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def algorithmic_bytes_per_view_layer(S, C, Lq, M, L, P, elem):
+    """value read once + locations + weights + output."""
+    return S * C * elem + Lq * M * L * P * 2 * elem + Lq * M * L * P * elem + Lq * C * elem
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg2", help="cfg2 (headline) | cfg4 | cfg5 | cfg1 | mini5")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", type=int, default=1, help="replay the forward as a captured HIP graph")
+    ap.add_argument("--valid-fraction", type=float, default=None,
+                    help="fraction of queries passing the 0.1 threshold (default: all valid = worst case)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mvgformer_amd import _lib, ops
+    from mvgformer_amd import dist as mdist
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from mvgformer_amd.synthetic import build_case
+
+    arch, cus = _lib.device_info()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    elem = 2 if args.dtype == "bf16" else 4
+    thr = 0.1
+
+    case = build_case(args.config, seed=0, valid_fraction=args.valid_fraction)
+    NQ, J, V, Ly = case.NQ, 15, case.V, case.layers
+    cpu_case = None
+    if rank == 0 and args.cpu_baseline and world == 1:
+        import copy
+        cpu_case = copy.copy(case)      # keeps the host tensors; case_to_device() rebinds `case`'s attributes
+    dec = build_decoder_for_case(case, dev, dtype)
+    g = case_to_device(case, dev)
+    lo, hi = mdist.shard_bounds(NQ, world, rank)
+    tgt, qpos, ref, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, J, world, rank)
+    if world > 1:
+        mdist.install_any_valid_sync(dec, None)
+
+    # host-side, per-sample preparation that belongs to data loading (camera records)
+    ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, 1, dev)
+
+    def forward():
+        ctx.feat = None
+        out = dec(tgt, ref, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None, query_pos=qpos,
+                  threshold=thr, context=ctx)
+        if world > 1:
+            out = mdist.gather_outputs(out, NQ, J, None, gather_hidden=False)
+        return out
+
+    use_graph = bool(args.graph)
+    graph = None
+    with torch.no_grad():
+        for _ in range(3):
+            out = forward()
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = forward()
+                graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:   # capture not possible (e.g. collective in capture): run eagerly
+                if rank == 0:
+                    print("# graph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+        step = (lambda: graph.replay()) if graph is not None else forward
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
+        prof = {}
+        if rank == 0 and args.profile_steps > 0 and world == 1:
+            ops.PROFILE = {}
+            for _ in range(args.profile_steps):
+                forward()
+            torch.cuda.synchronize()
+            prof = ops.profile_summary()
+            ops.PROFILE = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    refs = out[1]
+    assert torch.isfinite(refs).all(), "non-finite poses"
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.steps / elapsed                          # samples / s (whole job: one sample per step)
+
+    # roofline of the dominant kernel: one msda_fused launch covers all V views of one layer
+    Lq_loc = (hi - lo) * J
+    S = int(sum(h * w for h, w in case.shapes))
+    bytes_launch = V * algorithmic_bytes_per_view_layer(S, 256, Lq_loc, 8, len(case.shapes), 8, elem)
+    roof = None
+    if "msda_fused" in prof:
+        n, ms = prof["msda_fused"]
+        ach = bytes_launch / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "msda_fused_kernel", "achieved": round(ach, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch}
+    kern = {k: {"launches": n, "avg_us": round(ms * 1e3, 2)} for k, (n, ms) in sorted(prof.items())}
+
+    cpu = None
+    if cpu_case is not None:
+        from mvgformer_amd.synthetic import to_torch_state
+        from oracle import decoder_ref as O
+        ncore = os.cpu_count() or 1
+        torch.set_num_threads(ncore)
+        prm = to_torch_state(cpu_case.weights)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.decoder_layer_forward(prm, "layers.0.", cpu_case.tgt.cpu(), cpu_case.query_pos.cpu(),
+                                    cpu_case.reference_points.cpu(), cpu_case.src_views, cpu_case.spatial_shapes.cpu(),
+                                    cpu_case.level_start_index.cpu(), cpu_case.meta, cpu_case.img_size, threshold=thr)
+        t_layer = time.perf_counter() - t0
+        cpu = {"value": round(1.0 / (t_layer * Ly), 5), "unit": "samples/s", "cores": ncore, "kind": "port",
+               "sample": "oracle/decoder_ref.py fp32, 1 of %d layers of the same workload (all %d views, all %d "
+                         "queries) in %.1f s, scaled x%d" % (Ly, V, NQ, t_layer, Ly)}
+
+    line = {
+        "metric": "decoder samples/sec (5-view, 1024 queries, 4 layers)" if args.config in ("cfg2", "cfg3")
+        else "decoder samples/sec (%s)" % args.config,
+        "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "%s: %d views, %d queries x %d joints, %d decoder layers, maps %s x 256ch, "
+                               "all queries valid" % (args.config, V, NQ, J, Ly, case.shapes)
+                   if args.valid_fraction is None else
+                   "%s: %d views, %d queries x %d joints, %d layers, ~%.0f%% queries valid"
+                   % (args.config, V, NQ, J, Ly, 100 * args.valid_fraction),
+                   "parallelism": "queries sharded x%d + all-gather" % world if world > 1 else "single GPU",
+                   "hip_graph": graph is not None, "device": arch, "cus": cus},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

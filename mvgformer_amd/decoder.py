@@ -67,17 +67,33 @@ def _get_activation_fn(activation):
 
 
 class DecoderContext:
-    """Per-forward, layer-independent state: packed pyramid, level table, packed cameras."""
+    """Per-forward, layer-independent state: level table + packed cameras (host side, built from
+    ``meta``) and the packed channels-last pyramid (device side, built from ``src_views``).
 
-    def __init__(self, src_views, spatial_shapes, level_start_index, meta, img_size, dtype, batch_size):
-        dev = src_views[0].device
-        self.levels = ops.Levels(spatial_shapes, level_start_index)
-        self.B = batch_size
-        self.V = src_views[0].shape[0] // batch_size
-        self.feat = ops.pack_pyramid(src_views, self.levels, dtype)
-        self.cams = ops.pack_cameras(meta, img_size, dev)
-        if self.cams.shape[0] != self.V * self.B:
-            raise RuntimeError("meta describes %d images, src_views hold %d" % (self.cams.shape[0], self.V * self.B))
+    ``prepare`` touches host memory (it reads the small camera tensors of ``meta``), ``pack`` only
+    enqueues kernels -- so a HIP-graph capture can call ``pack`` with a prepared context."""
+
+    def __init__(self, levels, cams, V, B, dtype):
+        self.levels, self.cams, self.V, self.B, self.dtype = levels, cams, V, B, dtype
+        self.feat = None
+
+    @classmethod
+    def prepare(cls, spatial_shapes, level_start_index, meta, img_size, dtype, batch_size, device):
+        levels = ops.Levels(spatial_shapes, level_start_index)
+        cams = ops.pack_cameras(meta, img_size, device)
+        V = cams.shape[0] // batch_size
+        return cls(levels, cams, V, batch_size, dtype)
+
+    def pack(self, src_views):
+        if src_views[0].shape[0] != self.V * self.B:
+            raise RuntimeError("meta describes %d images, src_views hold %d" % (self.V * self.B, src_views[0].shape[0]))
+        self.feat = ops.pack_pyramid(src_views, self.levels, self.dtype)
+        return self
+
+    @classmethod
+    def build(cls, src_views, spatial_shapes, level_start_index, meta, img_size, dtype, batch_size):
+        return cls.prepare(spatial_shapes, level_start_index, meta, img_size, dtype, batch_size,
+                           src_views[0].device).pack(src_views)
 
 
 class MvPDecoderLayer(nn.Module):
@@ -147,6 +163,9 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.compute_dtype = torch.float32
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
+        # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
+        # "no query valid anywhere -> force query (0,0)" rule (dq_decoder.py:620-623) global
+        self._any_valid_hook = None
 
     # ------------------------------------------------------------------------------ config
     def set_compute_dtype(self, dtype):
@@ -206,7 +225,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         dt = self.compute_dtype
         ctx = self._ctx
         if ctx is None:
-            ctx = DecoderContext(src_views, src_spatial_shapes, level_start_index, meta, self.img_size, dt, B)
+            ctx = DecoderContext.build(src_views, src_spatial_shapes, level_start_index, meta, self.img_size, dt, B)
         V = ctx.V
 
         # 1. projective attention features of every view (generate_features, dq_decoder.py:516-593)
@@ -242,6 +261,8 @@ class DQDecoderLayer(MvPDecoderLayer):
                 forced[b, torch.as_tensor(q, dtype=torch.long, device=tgt.device)] = 1
         prob, valid, any_valid = ops.class_head(tgt_update, self._w("Wc", (self.class_embed.weight,), f32),
                                                 self._w("bc", (self.class_embed.bias,), f32), threshold, B, NQ, J, forced)
+        if self._any_valid_hook is not None:
+            self._any_valid_hook(any_valid)
 
         # 4. 2D offsets from the per-view attention features (calculate_2d_offsets, dq_decoder.py:659-717)
         hcur = attn
@@ -302,13 +323,17 @@ class DQDecoder(MvPDecoder):
                 frame_id=None, indices=None, threshold=0.5, indices_all=None, context=None):
         """Returns (hs (layers,B,Lq,C), refs (layers,B,Lq,3), refs2d (layers,B,V,Lq,2),
         projs2d (layers,B,V,Lq,2), [class_prob (B,NQ,2)] * layers) when return_intermediate,
-        else (output, reference_points, ref_points_2d)."""
+        else (output, reference_points, ref_points_2d).  ``context`` (optional, beyond the reference
+        signature): a DecoderContext.prepare(...)d context, so the host-side camera packing is
+        hoisted out of a captured HIP graph."""
         output = tgt
         layer0 = self.layers[0]
         ctx = context
         if ctx is None:
-            ctx = DecoderContext(src_views, src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
-                                 layer0.compute_dtype, tgt.shape[0])
+            ctx = DecoderContext.build(src_views, src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
+                                       layer0.compute_dtype, tgt.shape[0])
+        elif ctx.feat is None:
+            ctx.pack(src_views)
         inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
         ref_points_2d = None
         try:

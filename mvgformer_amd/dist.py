@@ -1,0 +1,122 @@
+"""Query-sharded multi-GPU execution of the decoder.
+
+Every person-query is an independent unit of work in the shipped configuration
+(init_self_attention=False, feature_update_method='MLP'): nothing in ProjAttn, the MLP/FFN,
+the class head, the view-softmax, the undistortion or the DLT couples two queries.  So the
+NQ person-queries are split into contiguous blocks, one per rank (one process per GPU), each
+rank runs the whole decoder on its block with the feature pyramid / cameras / weights
+replicated, and ONE all-gather at the end of the forward assembles the pose set.  There is no
+collective inside the decoder (the reference has none either: SURVEY.md section 2.2).
+
+The messages are small (<= 1 MB per rank at 1024 queries without the hidden states), i.e.
+latency-bound: all outputs of a rank are packed into one flat buffer so the exchange is a
+single RCCL all_gather_into_tensor over xGMI, not one collective per tensor per layer.
+
+Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(NQ, world, rank):
+    """contiguous, balanced block [lo, hi) of person-queries for `rank` (first NQ % world ranks
+    get one more)."""
+    base, rem = divmod(NQ, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_queries(tgt, query_pos, reference_points, num_joints, world, rank):
+    """slice (B, NQ*J, ...) token tensors to this rank's block of person-queries."""
+    NQ = tgt.shape[1] // num_joints
+    lo, hi = shard_bounds(NQ, world, rank)
+    sl = slice(lo * num_joints, hi * num_joints)
+    cut = lambda t: None if t is None else t[:, sl].contiguous()
+    return cut(tgt), cut(query_pos), cut(reference_points), (lo, hi)
+
+
+def gather_outputs(outputs, NQ, num_joints, group=None, gather_hidden=False):
+    """all-gather the sharded decoder outputs.
+
+    outputs = (hs (Ly,B,Lq_loc,C), refs (Ly,B,Lq_loc,3), refs2d (Ly,B,V,Lq_loc,2),
+               projs2d (Ly,B,V,Lq_loc,2), [cls (B,NQ_loc,2)] * Ly)  -- DQDecoder.forward's tuple.
+    Returns the same tuple for all NQ queries (hs is None unless gather_hidden)."""
+    hs, refs, r2d, p2d, cls = outputs
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    J = num_joints
+    cls_t = torch.stack(list(cls))                                      # (Ly,B,NQ_loc,2)
+    Ly, B = refs.shape[:2]
+    V = r2d.shape[2]
+    C = hs.shape[-1]
+    nq_max = -(-NQ // world)
+    lo, hi = shard_bounds(NQ, world, rank)
+    nq_loc = hi - lo
+    assert refs.shape[2] == nq_loc * J, (refs.shape, nq_loc)
+
+    # per-person record: [refs J*3 | refs2d V*J*2 | projs2d V*J*2 | cls 2 | (hs J*C)] per (layer, batch)
+    parts = [refs.reshape(Ly, B, nq_loc, J * 3),
+             r2d.reshape(Ly, B, V, nq_loc, J * 2).permute(0, 1, 3, 2, 4).reshape(Ly, B, nq_loc, V * J * 2),
+             p2d.reshape(Ly, B, V, nq_loc, J * 2).permute(0, 1, 3, 2, 4).reshape(Ly, B, nq_loc, V * J * 2),
+             cls_t.reshape(Ly, B, nq_loc, 2)]
+    if gather_hidden:
+        parts.append(hs.reshape(Ly, B, nq_loc, J * C))
+    rec = torch.cat([p.float() for p in parts], -1)                     # (Ly,B,nq_loc,R)
+    R = rec.shape[-1]
+    send = rec.new_zeros((nq_max, Ly, B, R))
+    send[:nq_loc] = rec.permute(2, 0, 1, 3)
+    recv = rec.new_empty((world * nq_max, Ly, B, R))
+    dist.all_gather_into_tensor(recv, send, group=group)                # the one exchange step
+    keep = []
+    for r_ in range(world):
+        a, b = shard_bounds(NQ, world, r_)
+        keep.append(recv[r_ * nq_max: r_ * nq_max + (b - a)])
+    full = torch.cat(keep, 0).permute(1, 2, 0, 3)                       # (Ly,B,NQ,R)
+    o = 0
+    refs_f = full[..., o:o + J * 3].reshape(Ly, B, NQ * J, 3); o += J * 3
+    r2d_f = full[..., o:o + V * J * 2].reshape(Ly, B, NQ, V, J, 2).permute(0, 1, 3, 2, 4, 5).reshape(Ly, B, V, NQ * J, 2)
+    o += V * J * 2
+    p2d_f = full[..., o:o + V * J * 2].reshape(Ly, B, NQ, V, J, 2).permute(0, 1, 3, 2, 4, 5).reshape(Ly, B, V, NQ * J, 2)
+    o += V * J * 2
+    cls_f = full[..., o:o + 2]; o += 2
+    hs_f = full[..., o:o + J * C].reshape(Ly, B, NQ * J, C) if gather_hidden else None
+    return hs_f, refs_f.contiguous(), r2d_f.contiguous(), p2d_f.contiguous(), [cls_f[i].contiguous() for i in range(Ly)]
+
+
+def sharded_decoder_forward(decoder, tgt, reference_points, src_views, meta, spatial_shapes, level_start_index,
+                            query_pos, threshold, group=None, gather_hidden=False, context=None):
+    """Run DQDecoder.forward on this rank's block of queries and all-gather the pose set."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    J = decoder.layers[0].num_joints
+    NQ = tgt.shape[1] // J
+    t, p, r, _ = shard_queries(tgt, query_pos, reference_points, J, world, rank)
+    install_any_valid_sync(decoder, group)
+    try:
+        out = decoder(t, r, src_views, meta, spatial_shapes, level_start_index, None, query_pos=p,
+                      threshold=threshold, context=context)
+    finally:
+        install_any_valid_sync(decoder, None, remove=True)
+    return gather_outputs(out, NQ, J, group, gather_hidden)
+
+
+def install_any_valid_sync(decoder, group, remove=False):
+    """The reference forces query (0,0) through triangulation when NO query of the whole batch
+    passes the filter (dq_decoder.py:620-623).  With sharded queries that predicate is global: a
+    4-byte MAX all-reduce per layer makes it so, and only the rank that owns global query 0 may
+    apply it."""
+    if remove:
+        for layer in decoder.layers:
+            layer._any_valid_hook = None
+        return
+    rank = dist.get_rank(group)
+
+    def hook(any_valid):
+        dist.all_reduce(any_valid, op=dist.ReduceOp.MAX, group=group)
+        if rank != 0:
+            any_valid.fill_(1)
+
+    for layer in decoder.layers:
+        layer._any_valid_hook = hook

@@ -12,6 +12,35 @@ import torch
 
 from . import _lib as L
 
+# ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) -----
+PROFILE = None   # None (off) or dict name -> list[(start_event, end_event)]
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()      # recorded on torch's current stream == the stream the kernel is launched on
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+def profile_summary():
+    """name -> (launches, mean ms) after a torch.cuda.synchronize()."""
+    out = {}
+    for k, evs in (PROFILE or {}).items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[k] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out
+
 
 def _i64_host(t):
     """small int64 table (shapes / starts) as a host ctypes array (no device sync if it is
@@ -48,6 +77,8 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
     _, Lq, _, nl, P, _ = sampling_loc.shape
     lib = L.load()
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    if Lq == 0:
+        return out
     if value.dtype == torch.float32:
         if sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
             raise RuntimeError("sampling_loc / attn_weight must be float32")
@@ -113,7 +144,8 @@ def gather_ref(feat, r, x, levels, V, B):
     n_img, S, Cc = feat.shape
     Lq = r.shape[1]
     ain = torch.empty((n_img * Lq * levels.L, Cc), dtype=feat.dtype, device=feat.device)
-    L.check(L.load().mvg_gather_ref(L.ptr(feat), L.dtype_code(feat.dtype), L.ptr(r), L.ptr(x), levels.shapes_c,
+    with _timed("gather_ref"):
+      L.check(L.load().mvg_gather_ref(L.ptr(feat), L.dtype_code(feat.dtype), L.ptr(r), L.ptr(x), levels.shapes_c,
                                     levels.starts_c, L.ptr(ain), V, B, Lq, levels.L, S, Cc, L.stream_ptr()),
             "mvg_gather_ref")
     return ain
@@ -128,7 +160,8 @@ def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None):
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     if a.stride(1) != 1 or not w.is_contiguous() or out.stride(1) != 1:
         raise RuntimeError("mvg_linear: K-contiguous operands required")
-    L.check(L.load().mvg_linear(L.ptr(a), L.dtype_code(a.dtype), a.stride(0), L.ptr(w), L.dtype_code(w.dtype),
+    with _timed("linear_%dx%dx%d" % (M, N, K)):
+      L.check(L.load().mvg_linear(L.ptr(a), L.dtype_code(a.dtype), a.stride(0), L.ptr(w), L.dtype_code(w.dtype),
                                 L.ptr(bias), L.ptr(out), L.dtype_code(out.dtype), out.stride(0), L.ptr(rowmask),
                                 1 if relu else 0, M, N, K, L.stream_ptr()), "mvg_linear")
     return out
@@ -139,7 +172,8 @@ def msda_fused(value, oa, r, levels):
     n_img, S, Cc = value.shape
     Lq = r.shape[1]
     samp = torch.empty((n_img * Lq, Cc), dtype=value.dtype, device=value.device)
-    L.check(L.load().mvg_msda_fused(L.ptr(value), L.dtype_code(value.dtype), L.ptr(oa), L.ptr(r), levels.shapes_c,
+    with _timed("msda_fused"):
+      L.check(L.load().mvg_msda_fused(L.ptr(value), L.dtype_code(value.dtype), L.ptr(oa), L.ptr(r), levels.shapes_c,
                                     levels.starts_c, L.ptr(samp), n_img, Lq, levels.L, S, L.stream_ptr()),
             "mvg_msda_fused")
     return samp
@@ -185,7 +219,8 @@ def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J):
     new_ref = torch.empty((B, Lq, 3), dtype=torch.float32, device=dev)
     ref2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
     proj2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
-    L.check(L.load().mvg_triangulate(L.ptr(r), L.ptr(o), L.ptr(cams), L.ptr(valid), L.ptr(any_valid), L.ptr(new_ref),
+    with _timed("triangulate"):
+      L.check(L.load().mvg_triangulate(L.ptr(r), L.ptr(o), L.ptr(cams), L.ptr(valid), L.ptr(any_valid), L.ptr(new_ref),
                                      L.ptr(ref2d), L.ptr(proj2d), V, B, NQ, J, L.stream_ptr()), "mvg_triangulate")
     return new_ref, ref2d, proj2d
 

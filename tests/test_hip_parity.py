@@ -233,7 +233,9 @@ def test_triangulation_kernel_vs_reference_golden(O):
     rel_hip = ((X.double() - X64).norm(dim=-1) / X64.norm(dim=-1).clamp_min(1.0)).max()
     rel_vs_ref = ((X - want32).norm(dim=-1) / want32.norm(dim=-1).clamp_min(1.0)).max()
     # random (non-corresponding) 2D points: ill-posed -> relative bounds
-    assert float(rel_vs_ref) < 5e-3, float(rel_vs_ref)
+    print("DLT rel err: reference fp32 vs fp64 %.3e | HIP vs fp64 %.3e | HIP vs reference %.3e"
+          % (float(rel_ref), float(rel_hip), float(rel_vs_ref)))
+    assert float(rel_vs_ref) < 5e-3 + 2.0 * float(rel_ref), float(rel_vs_ref)
     assert float(rel_hip) <= max(2.0 * float(rel_ref), 1e-4), (float(rel_hip), float(rel_ref))
     assert float((proj2d.cpu().view(V, n, J, 2).permute(1, 0, 2, 3) - net.float()).abs().max()) < 1e-2
 
