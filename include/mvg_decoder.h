@@ -54,6 +54,9 @@ extern "C" {
  * usable device is present; MVG_E_NOGPU otherwise.  Host-only. */
 int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
 const char* mvg_version(void);
+/* Kernel-variant knobs for A/B measurements (host-only, process-wide).  Keys:
+ *   "fused_cpl_bf16" = 4 | 8 : channels per lane of the bf16 fused sampling kernel. */
+int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
  * value (N,S,M,D); spatial_shapes (L,2) int64 (H,W); level_start_index (L,) int64;

@@ -21,6 +21,7 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes (restype is always int unless noted); must list EVERY symbol of the header
 SIGNATURES = {
     "mvg_device_info": [C.c_char_p, _i, C.POINTER(_i)],
+    "mvg_set_tuning": [C.c_char_p, _i],
     "mvg_msda_forward_f32": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_forward_bf16": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_backward_f32": [_vp] * 9 + [_i] * 7 + [_vp],

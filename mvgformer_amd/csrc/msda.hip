@@ -13,6 +13,8 @@
 //   * workgroup -> (image, query) mapping is XCD-aware: the 8 XCDs of the chip each walk a
 //     contiguous range of query blocks, so queries that project next to each other (the
 //     15 joints of a person, neighbouring persons of the query grid) share one XCD's L2.
+#include <string.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------
@@ -133,82 +135,192 @@ static int launch_msda_fwd(const T* value, const int64_t* shapes, const int64_t*
 // The module is built with n_levels=1 but applied to L levels, and the outputs are VIEWED,
 // not transposed: flat offset index f_O = ((m*L+l)*P+p)*2+xy lives in level row
 // f_O/128, column f_O%128; flat logit index f_A = m*L*P + l*P + p in row f_A/64, column f_A%64.
-template <typename T, int L>
-__global__ __launch_bounds__(256) void msda_fused_kernel(const T* __restrict__ value, const float* __restrict__ oa,
+// Work decomposition: CPL channels per lane (4: 8 lanes per head, one (image,query) pair per
+// wavefront; 8: 4 lanes per head, two pairs per wavefront -- bf16 only, 16-byte loads).  The
+// sampling loop is software-pipelined by hand: the corner addresses / weights of NB samples are
+// computed first, their 4*NB vector loads are issued back to back (16 loads in flight per
+// wavefront instead of the 4-6 the compiler schedules on its own -- the kernel is latency-bound
+// on L2/MALL gathers otherwise), and only then are they blended into the accumulators.
+template <typename T, int CPL> struct RawVec;
+template <> struct RawVec<float, 4> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void fma(float (&acc)[4], const type& v, float w) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, v[c], acc[c]);
+  }
+};
+template <> struct RawVec<bf16_t, 4> {
+  typedef uint2 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ void fma(float (&acc)[4], const type& v, float w) {
+    acc[0] = fmaf(w, __uint_as_float(v.x << 16), acc[0]);
+    acc[1] = fmaf(w, __uint_as_float(v.x & 0xffff0000u), acc[1]);
+    acc[2] = fmaf(w, __uint_as_float(v.y << 16), acc[2]);
+    acc[3] = fmaf(w, __uint_as_float(v.y & 0xffff0000u), acc[3]);
+  }
+};
+template <> struct RawVec<bf16_t, 8> {
+  typedef uint4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void fma(float (&acc)[8], const type& v, float w) {
+    acc[0] = fmaf(w, __uint_as_float(v.x << 16), acc[0]);
+    acc[1] = fmaf(w, __uint_as_float(v.x & 0xffff0000u), acc[1]);
+    acc[2] = fmaf(w, __uint_as_float(v.y << 16), acc[2]);
+    acc[3] = fmaf(w, __uint_as_float(v.y & 0xffff0000u), acc[3]);
+    acc[4] = fmaf(w, __uint_as_float(v.z << 16), acc[4]);
+    acc[5] = fmaf(w, __uint_as_float(v.z & 0xffff0000u), acc[5]);
+    acc[6] = fmaf(w, __uint_as_float(v.w << 16), acc[6]);
+    acc[7] = fmaf(w, __uint_as_float(v.w & 0xffff0000u), acc[7]);
+  }
+};
+
+template <typename T, int CPL>
+__device__ __forceinline__ void store_acc(T* p, const float (&acc)[CPL]) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  } else if constexpr (CPL == 4) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+  } else {
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+}
+
+template <typename T, int L, int CPL>
+__global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(const T* __restrict__ value, const float* __restrict__ oa,
                                                          const float* __restrict__ r, LevelTable lv,
                                                          T* __restrict__ samp, int n_pairs, int Lq, int S) {
-  constexpr int D = 32, P = 8, C = 256, LP = L * P;   // M = 8 heads = 64 lanes / 8
+  constexpr int D = 32, P = 8, C = 256, LP = L * P;   // M = 8 heads
+  constexpr int LPH = D / CPL;                        // lanes per head (8 or 4)
+  constexpr int PPW = 64 / (8 * LPH);                 // (image,query) pairs per wavefront (1 or 2)
+  constexpr int NB = 4;                               // samples per gather batch (P % NB == 0)
+  typedef RawVec<T, CPL> RV;
   // XCD-aware block remap (bijective): XCD x = blockIdx % 8 walks a contiguous block range
   const int nb = gridDim.x;
   const int q8 = nb >> 3, r8 = nb & 7;
   const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
   const int lblock = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pair = lblock * 4 + wave;
-  if (pair >= n_pairs) return;
+  int pair = (lblock * 4 + wave) * PPW + lane / (8 * LPH);
+  const bool live = pair < n_pairs;
+  if (!live) pair = n_pairs - 1;                       // keep the wavefront converged; store is masked
   const int n = pair / Lq;
-  const int m = lane >> 3, sub = lane & 7;
+  const int m = (lane / LPH) & 7, sub = lane % LPH;
 
-  // ---- logits -> softmax weights (in registers, redundantly on the 8 lanes of a head)
-  float aw[LP];
+  // ---- pass 1: max and sum of the head's L*P logits (softmax denominator), redundantly on the
+  //      LPH lanes of a head; 16-byte loads that all lanes of a head share (one broadcast each)
   const float* oa_q = oa + (long)pair * L * 192;
+  float mx = -INFINITY;
+  {
+    f32x4 lg[LP / 4];
 #pragma unroll
-  for (int i = 0; i < LP / 4; ++i) {
-    const int fa = m * LP + 4 * i;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(oa_q + (fa >> 6) * 192 + 128 + (fa & 63));
-    aw[4 * i] = v[0]; aw[4 * i + 1] = v[1]; aw[4 * i + 2] = v[2]; aw[4 * i + 3] = v[3];
+    for (int i = 0; i < LP / 4; ++i) {
+      const int fa = m * LP + 4 * i;
+      lg[i] = *reinterpret_cast<const f32x4*>(oa_q + (fa >> 6) * 192 + 128 + (fa & 63));
+      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i)
+      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
+    // fold 1/sum into the exponent: w = exp(x - mx - log(sum))
+    mx += __logf(sum);
   }
-  float mx = aw[0];
-#pragma unroll
-  for (int i = 1; i < LP; ++i) mx = fmaxf(mx, aw[i]);
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < LP; ++i) {
-    aw[i] = __expf(aw[i] - mx);
-    sum += aw[i];
-  }
-  const float inv_sum = 1.f / sum;
 
-  const T* vbase = value + (long)n * S * C + m * D + sub * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const T* vbase = value + (long)n * S * C + m * D + sub * CPL;
+  float acc[CPL];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+
+  // ---- pass 2: a REAL loop over batches of NB samples (not unrolled: a fully unrolled body lets
+  //      the compiler pre-compute all 24 samples' corner weights / indices and spill); inside one
+  //      iteration the 4*NB gathers are issued back to back before the first blend.
+#pragma unroll 1
+  for (int it = 0; it < LP / NB; ++it) {
+    const int l = (it * NB) / P, b0 = (it * NB) % P;
     const int H = lv.H[l], W = lv.W[l];
     const float Wf = (float)W, Hf = (float)H;
     const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
     const float invW = 1.f / Wf, invH = 1.f / Hf;
     const T* lvl = vbase + (long)lv.start[l] * C;
+    const int fa = m * LP + it * NB;
+    const f32x4 lg = *reinterpret_cast<const f32x4*>(oa_q + (fa >> 6) * 192 + 128 + (fa & 63));
+    f32x4 o4[NB / 2];
 #pragma unroll
-    for (int pp = 0; pp < P / 2; ++pp) {
-      const int fo = ((m * L + l) * P + 2 * pp) * 2;  // 2 points = 4 floats, 16-B aligned
-      const f32x4 o4 = *reinterpret_cast<const f32x4*>(oa_q + (fo >> 7) * 192 + (fo & 127));
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float lx = refx + o4[2 * h] * invW;       // projattn.py:186-191
-        const float ly = refy + o4[2 * h + 1] * invH;
-        const float h_im = ly * Hf - 0.5f;
-        const float w_im = lx * Wf - 0.5f;
-        acc += bilinear4<T>(lvl, H, W, C, h_im, w_im, aw[l * P + 2 * pp + h] * inv_sum);
-      }
+    for (int i = 0; i < NB / 2; ++i) {
+      const int fo = ((m * L + l) * P + b0 + 2 * i) * 2;
+      o4[i] = *reinterpret_cast<const f32x4*>(oa_q + (fo >> 7) * 192 + (fo & 127));
     }
+    float cw[NB][4];
+    typename RV::type raw[NB][4];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const float lx = refx + o4[s >> 1][2 * (s & 1)] * invW;       // projattn.py:186-191
+      const float ly = refy + o4[s >> 1][2 * (s & 1) + 1] * invH;
+      const float h_im = ly * Hf - 0.5f;                             // cuh:295-296
+      const float w_im = lx * Wf - 0.5f;
+      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+      const int h_low = (int)hl_f, w_low = (int)wl_f;
+      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
+      const float a = inside ? __expf(lg[s] - mx) : 0.f;             // softmax weight (projattn.py:184)
+      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+      cw[s][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;               // cuh:66-88 zero padding
+      cw[s][1] = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
+      cw[s][2] = (hh_ok && wl_ok) ? lh * hw * a : 0.f;
+      cw[s][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
+      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+      const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
+      raw[s][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
+      raw[s][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
+      raw[s][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
+      raw[s][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all 4*NB loads are issued before the first blend
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s][k], cw[s][k]);
   }
-  Vec4<T>::store(samp + (long)pair * C + m * D + sub * 4, acc);
+  if (live) store_acc<T, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
 }
 
-template <typename T>
-static int launch_msda_fused(const T* value, const float* oa, const float* r, const LevelTable& lv, T* samp,
-                             int n_pairs, int Lq, int S, hipStream_t st) {
-  if (n_pairs <= 0) return 0;
-  const int grid = (n_pairs + 3) / 4;
+static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
+
+template <typename T, int CPL>
+static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r, const LevelTable& lv, T* samp,
+                                 int n_pairs, int Lq, int S, hipStream_t st) {
+  constexpr int PPW = CPL / 4;
+  const int grid = (n_pairs + 4 * PPW - 1) / (4 * PPW);
   switch (lv.L) {
-    case 1: hipLaunchKernelGGL((msda_fused_kernel<T, 1>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 2: hipLaunchKernelGGL((msda_fused_kernel<T, 2>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 3: hipLaunchKernelGGL((msda_fused_kernel<T, 3>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 4: hipLaunchKernelGGL((msda_fused_kernel<T, 4>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 1: hipLaunchKernelGGL((msda_fused_kernel<T, 1, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 2: hipLaunchKernelGGL((msda_fused_kernel<T, 2, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 3: hipLaunchKernelGGL((msda_fused_kernel<T, 3, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 4: hipLaunchKernelGGL((msda_fused_kernel<T, 4, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
     default: return MVG_E_BADARG;
   }
   MVG_LAUNCH_CHECK();
   return 0;
+}
+
+static int launch_msda_fused(const float* value, const float* oa, const float* r, const LevelTable& lv, float* samp,
+                             int n_pairs, int Lq, int S, hipStream_t st) {
+  if (n_pairs <= 0) return 0;
+  return launch_msda_fused_cpl<float, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+}
+static int launch_msda_fused(const bf16_t* value, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
+                             int n_pairs, int Lq, int S, hipStream_t st) {
+  if (n_pairs <= 0) return 0;
+  if (g_fused_cpl_bf16 == 4) return launch_msda_fused_cpl<bf16_t, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+  return launch_msda_fused_cpl<bf16_t, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -356,6 +468,12 @@ int mvg_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
   return 0;
 }
 
+int mvg_set_tuning(const char* key, int value) {
+  if (!key) return MVG_E_BADARG;
+  if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
+  return MVG_E_BADARG;
+}
+
 int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r, const int64_t* shapes_host,
                    const int64_t* starts_host, void* samp, int N_img, int Lq, int L, int S, void* stream) {
   if (!value || !oa || !r || !shapes_host || !starts_host || !samp) return MVG_E_BADARG;
@@ -366,9 +484,9 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
   const long pairs = (long)N_img * Lq;
   if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
   if (dtype == MVG_F32)
-    return launch_msda_fused<float>((const float*)value, oa, r, lv, (float*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
+    return launch_msda_fused((const float*)value, oa, r, lv, (float*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
   if (dtype == MVG_BF16)
-    return launch_msda_fused<bf16_t>((const bf16_t*)value, oa, r, lv, (bf16_t*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
+    return launch_msda_fused((const bf16_t*)value, oa, r, lv, (bf16_t*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
   return MVG_E_BADARG;
 }
 
