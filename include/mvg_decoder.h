@@ -118,6 +118,17 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,
                    int N_img, int Lq, int L, int S, void* stream);
 
+/* bf16 fast path of the two calls above with the "pixel-pair" value layout
+ *   vp[img][head 8][1+s][ch8 4][col 2][8 ch]  (bf16; (s,col0) = value(s), (s,col1) = value(s+1))
+ * in which the two horizontal bilinear corners of a sample are one aligned 128-byte line per head:
+ * mvg_value_proj_pairs = rayconv Linear (projattn.py:169) writing vp directly (vp must be zero-filled
+ * once by the caller: (n_img*8*(S+1)*64) bf16); mvg_msda_fused_pairs = mvg_msda_fused reading it. */
+int mvg_value_proj_pairs(const void* feat, int a_dtype, const void* W, int w_dtype, const float* bias,
+                         void* vp, int n_img, int S, int K, void* stream);
+int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl,
+                         const int64_t* shapes_host, const int64_t* starts_host, void* samp,
+                         int N_img, int Lq, int L, int S, void* stream);
+
 /* A.4 (dq_decoder.py:770): mean over views of attn (V,B*Lq,C) `dtype` -> (B*Lq,C) `dtype`. */
 int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream);
 

@@ -30,6 +30,8 @@ SIGNATURES = {
     "mvg_gather_ref": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvg_linear": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "mvg_msda_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvg_value_proj_pairs": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "mvg_msda_fused_pairs": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_mean_views": [_vp, _i, _vp, _i, _i, _i, _vp],
     "mvg_add_layernorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_class_head": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

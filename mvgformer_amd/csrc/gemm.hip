@@ -60,12 +60,21 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
   *reinterpret_cast<f32x4*>(lds + row * PITCH + col16 * 16) = v;
 }
 
+// Output placement of the epilogue.
+//   ROWMAJOR : out[row*ldc + col]
+//   PAIRS    : the sampling kernel's bf16 "pixel-pair" value layout (N = 256 = 8 heads x 32 ch,
+//              rows = pixels of S-pixel images):  vp[img][head][1+s][ch8][col][8]  with
+//              (s, col 0) = value(s) and (s, col 1) = value(s+1), so the two horizontal bilinear
+//              corners of any sample are ONE aligned 128-byte line per head.  Every pixel is
+//              therefore written twice (as the left corner of pair s and the right corner of s-1).
+enum { OUT_ROWMAJOR = 0, OUT_PAIRS = 1 };
+
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
-template <typename TA, bool BF16, typename TO>
+template <typename TA, bool BF16, typename TO, int MODE>
 __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, long lda, const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
-                                                     int K) {
+                                                     int K, int S_img) {
   using TW = typename std::conditional<BF16, bf16_t, float>::type;
   const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
@@ -121,17 +130,19 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
         a[i] = *reinterpret_cast<const f32x4*>(ldsA + (wm * 64 + i * 32 + rl) * PITCH + 32 * g + 16 * h);
         b[i] = *reinterpret_cast<const f32x4*>(ldsB + (wn * 64 + i * 32 + rl) * PITCH + 32 * g + 16 * h);
       }
+      // D' = W_tile * A_tile^T: the MFMA "row" index (registers) runs over output COLUMNS n, the
+      // lane index over output ROWS m, so a lane ends up with groups of 4 consecutive n.
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (BF16) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
-                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
           } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][t], a[i][t], acc[i][j], 0, 0, 0);
           }
         }
     }
@@ -142,63 +153,126 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue.  acc[i][j][e] = out[m0 + wm*64 + i*32 + rl][n0 + wn*64 + j*32 + (e&3) + 8*(e>>2) + 4*h].
+  // Two phases (i = 0, 1) of 64 rows x 128 columns: bias / ReLU / row mask in registers, the tile is
+  // transposed through LDS (16-byte writes of 4 consecutive columns), then stored with 16-byte
+  // vectors, 256 (bf16) or 512 (fp32) contiguous bytes per row.
+  constexpr int EP = (int)sizeof(TO) * BN + 16;     // staging pitch in bytes
+  static_assert(64 * EP <= (BM + BN) * PITCH, "staging tile must fit the main-loop LDS");
+  constexpr int CPV = 16 / (int)sizeof(TO);         // columns per 16-byte vector
+  constexpr int VPR = BN / CPV;                     // vectors per staged row
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + rl;
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
+  for (int i = 0; i < 2; ++i) {
+    const int grow = m0 + wm * 64 + i * 32 + rl;
+    const bool keep = rowmask ? (grow < M && rowmask[grow] != 0) : true;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < M) {
-          float v = acc[i][j][e] + bv;
-          if (relu) v = fmaxf(v, 0.f);
-          if (rowmask) v = rowmask[row] ? v : 0.f;
-          store1<TO>(out + (long)row * ldc + col, v);
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * 64 + j * 32 + 8 * g + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float x = acc[i][j][4 * g + t] + ((bias && n0 + nl + t < N) ? bias[n0 + nl + t] : 0.f);
+          if (relu) x = fmaxf(x, 0.f);
+          v[t] = keep ? x : 0.f;
+        }
+        char* dst = lds + (wm * 32 + rl) * EP + nl * (int)sizeof(TO);
+        if constexpr (sizeof(TO) == 4) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<uint2*>(dst) = pk;
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int c0 = 0; c0 < 64 * VPR; c0 += 256) {
+      const int c = c0 + tid;
+      const int srow = c / VPR, vcol = c % VPR;            // staged row (0..63), vector column
+      const int row = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
+      const int col = n0 + vcol * CPV;
+      if (row < M && col < N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + srow * EP + vcol * 16);
+        if constexpr (MODE == OUT_ROWMAJOR) {
+          *reinterpret_cast<f32x4*>(out + (long)row * ldc + col) = v;
+        } else {
+          const int img = row / S_img, s = row - img * S_img;
+          const int head = col >> 5, ch8 = (col & 31) >> 3;
+          TO* base = out + (((long)img * 8 + head) * (S_img + 1) + s) * 64 + ch8 * 16;
+          *reinterpret_cast<f32x4*>(base + 64) = v;      // pair 1+s, left corner  (col 0)
+          *reinterpret_cast<f32x4*>(base + 8) = v;       // pair s,   right corner (col 1)
         }
       }
     }
+    __syncthreads();
   }
 }
 
 template <typename TA, bool BF16, typename TO>
 int launch_linear(const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
-                  const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
+                  const uint8_t* rowmask, int relu, int M, int N, int K, int mode, int S_img, hipStream_t st) {
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias, (TO*)out, ldc,
-                     rowmask, relu, M, N, K);
+  if (mode == OUT_PAIRS) {
+    if constexpr (sizeof(TO) == 2) {
+      hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, OUT_PAIRS>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias,
+                         (TO*)out, ldc, rowmask, relu, M, N, K, S_img);
+    } else {
+      return MVG_E_BADARG;
+    }
+  } else {
+    hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, OUT_ROWMAJOR>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias,
+                       (TO*)out, ldc, rowmask, relu, M, N, K, S_img);
+  }
   MVG_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
 
-extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
-                          int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {
+static int linear_dispatch(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias,
+                           void* out, int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K,
+                           int mode, int S_img, void* stream) {
   if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return MVG_E_BADARG;
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool bf = (w_dtype == MVG_BF16);
   if (!bf && w_dtype != MVG_F32) return MVG_E_BADARG;
-  if (K % (bf ? 64 : 32) != 0) return MVG_E_BADARG;
-  const int a_el = (a_dtype == MVG_BF16) ? 2 : 4;
+  if (K % (bf ? 64 : 32) != 0 || N % 8 != 0) return MVG_E_BADARG;
+  const int a_el = (a_dtype == MVG_BF16) ? 2 : 4, o_el = (out_dtype == MVG_BF16) ? 2 : 4;
   if (((long)lda * a_el) % 16 != 0 || (reinterpret_cast<uintptr_t>(A) % 16) != 0 || (reinterpret_cast<uintptr_t>(W) % 16) != 0)
     return MVG_E_BADARG;
+  if (mode == OUT_ROWMAJOR && ((((long)ldc * o_el) % 16) != 0 || (reinterpret_cast<uintptr_t>(out) % 16) != 0)) return MVG_E_BADARG;
+  if (mode == OUT_PAIRS && (N != 256 || out_dtype != MVG_BF16 || S_img <= 0 || M % S_img != 0)) return MVG_E_BADARG;
   if (!bf) {
     if (a_dtype != MVG_F32) return MVG_E_BADARG;   // fp32 MFMA path takes fp32 activations
-    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
-    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
     return MVG_E_BADARG;
   }
   if (a_dtype == MVG_BF16) {
-    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
-    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
+    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
   } else if (a_dtype == MVG_F32) {
-    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
-    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
   }
   return MVG_E_BADARG;
+}
+
+extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
+                          int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {
+  return linear_dispatch(A, a_dtype, lda, W, w_dtype, bias, out, out_dtype, ldc, rowmask, relu, M, N, K, OUT_ROWMAJOR, 0,
+                         stream);
+}
+
+// value projection straight into the sampling kernel's bf16 pixel-pair layout (see OUT_PAIRS):
+// feat (n_img*S, K) @ W (256, K)^T + bias -> vp (n_img, 8, S+1, 4, 2, 8) bf16.  The caller provides vp
+// zero-initialised once (the right-corner slot of the last pixel of each head plane is never written).
+extern "C" int mvg_value_proj_pairs(const void* feat, int a_dtype, const void* W, int w_dtype, const float* bias,
+                                    void* vp, int n_img, int S, int K, void* stream) {
+  return linear_dispatch(feat, a_dtype, K, W, w_dtype, bias, vp, MVG_BF16, 0, nullptr, 0, n_img * S, 256, K, OUT_PAIRS, S,
+                         stream);
 }

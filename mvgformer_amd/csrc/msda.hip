@@ -194,14 +194,14 @@ __device__ __forceinline__ void store_acc(T* p, const float (&acc)[CPL]) {
   }
 }
 
-template <typename T, int L, int CPL>
-__global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(const T* __restrict__ value, const float* __restrict__ oa,
+template <typename T, int L, int CPL, int NB, bool PAIRS = false>
+__global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) void msda_fused_kernel(const T* __restrict__ value, const float* __restrict__ oa,
                                                          const float* __restrict__ r, LevelTable lv,
                                                          T* __restrict__ samp, int n_pairs, int Lq, int S) {
   constexpr int D = 32, P = 8, C = 256, LP = L * P;   // M = 8 heads
   constexpr int LPH = D / CPL;                        // lanes per head (8 or 4)
   constexpr int PPW = 64 / (8 * LPH);                 // (image,query) pairs per wavefront (1 or 2)
-  constexpr int NB = 4;                               // samples per gather batch (P % NB == 0)
+  // NB = samples per gather batch (P % NB == 0): 4*NB vector loads in flight per lane
   typedef RawVec<T, CPL> RV;
   // XCD-aware block remap (bijective): XCD x = blockIdx % 8 walks a contiguous block range
   const int nb = gridDim.x;
@@ -235,7 +235,11 @@ __global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(con
     mx += __logf(sum);
   }
 
-  const T* vbase = value + (long)n * S * C + m * D + sub * CPL;
+  // PAIRS: value is the bf16 pixel-pair layout vp[img][head][1+s][ch8][col][8] written by
+  // mvg_value_proj_pairs: both horizontal corners of a sample are one aligned 128-B line per head
+  // (half the L2 requests of the pixel-major layout, where each corner is its own 64-B segment).
+  const T* vbase = PAIRS ? value + ((long)n * 8 + m) * (S + 1) * 64 + sub * 16
+                         : value + (long)n * S * C + m * D + sub * CPL;
   float acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
@@ -250,9 +254,12 @@ __global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(con
     const float Wf = (float)W, Hf = (float)H;
     const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
     const float invW = 1.f / Wf, invH = 1.f / Hf;
-    const T* lvl = vbase + (long)lv.start[l] * C;
+    const T* lvl = PAIRS ? vbase + (long)(1 + lv.start[l]) * 64 : vbase + (long)lv.start[l] * C;
     const int fa = m * LP + it * NB;
-    const f32x4 lg = *reinterpret_cast<const f32x4*>(oa_q + (fa >> 6) * 192 + 128 + (fa & 63));
+    f32x4 lg[NB / 4];
+#pragma unroll
+    for (int i = 0; i < NB / 4; ++i)
+      lg[i] = *reinterpret_cast<const f32x4*>(oa_q + ((fa + 4 * i) >> 6) * 192 + 128 + ((fa + 4 * i) & 63));
     f32x4 o4[NB / 2];
 #pragma unroll
     for (int i = 0; i < NB / 2; ++i) {
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(con
       const int h_low = (int)hl_f, w_low = (int)wl_f;
       const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
       const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
-      const float a = inside ? __expf(lg[s] - mx) : 0.f;             // softmax weight (projattn.py:184)
+      const float a = inside ? __expf(lg[s >> 2][s & 3] - mx) : 0.f;   // softmax weight (projattn.py:184)
       const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
       cw[s][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;               // cuh:66-88 zero padding
       cw[s][1] = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
@@ -279,10 +286,18 @@ __global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(con
       cw[s][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
       const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
       const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
-      raw[s][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
-      raw[s][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
-      raw[s][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
-      raw[s][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
+      if constexpr (PAIRS) {
+        const int wp = min(max(w_low, -1), W - 1);                   // pair index: left corner column
+        raw[s][0] = RV::load(lvl + (hl_c * W + wp) * 64);
+        raw[s][1] = RV::load(lvl + (hl_c * W + wp) * 64 + 8);
+        raw[s][2] = RV::load(lvl + (hh_c * W + wp) * 64);
+        raw[s][3] = RV::load(lvl + (hh_c * W + wp) * 64 + 8);
+      } else {
+        raw[s][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
+        raw[s][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
+        raw[s][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
+        raw[s][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);   // all 4*NB loads are issued before the first blend
 #pragma unroll
@@ -294,17 +309,33 @@ __global__ __launch_bounds__(256, (CPL == 8 ? 3 : 4)) void msda_fused_kernel(con
 }
 
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
+static int g_fused_nb = 4;         // tuning knob: samples per gather batch (4 or 8)
 
-template <typename T, int CPL>
+template <typename T, int CPL, int NB>
 static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r, const LevelTable& lv, T* samp,
                                  int n_pairs, int Lq, int S, hipStream_t st) {
   constexpr int PPW = CPL / 4;
   const int grid = (n_pairs + 4 * PPW - 1) / (4 * PPW);
   switch (lv.L) {
-    case 1: hipLaunchKernelGGL((msda_fused_kernel<T, 1, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 2: hipLaunchKernelGGL((msda_fused_kernel<T, 2, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 3: hipLaunchKernelGGL((msda_fused_kernel<T, 3, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 4: hipLaunchKernelGGL((msda_fused_kernel<T, 4, CPL>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 1: hipLaunchKernelGGL((msda_fused_kernel<T, 1, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 2: hipLaunchKernelGGL((msda_fused_kernel<T, 2, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 3: hipLaunchKernelGGL((msda_fused_kernel<T, 3, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 4: hipLaunchKernelGGL((msda_fused_kernel<T, 4, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
+    default: return MVG_E_BADARG;
+  }
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_msda_fused_pairs(const bf16_t* vp, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
+                                   int n_pairs, int Lq, int S, hipStream_t st) {
+  if (n_pairs <= 0) return 0;
+  const int grid = (n_pairs + 7) / 8;
+  switch (lv.L) {
+    case 1: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 1, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 2: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 2, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 3: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 3, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+    case 4: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 4, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
     default: return MVG_E_BADARG;
   }
   MVG_LAUNCH_CHECK();
@@ -314,13 +345,18 @@ static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r
 static int launch_msda_fused(const float* value, const float* oa, const float* r, const LevelTable& lv, float* samp,
                              int n_pairs, int Lq, int S, hipStream_t st) {
   if (n_pairs <= 0) return 0;
-  return launch_msda_fused_cpl<float, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+  if (g_fused_nb == 8) return launch_msda_fused_cpl<float, 4, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+  return launch_msda_fused_cpl<float, 4, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
 }
 static int launch_msda_fused(const bf16_t* value, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
                              int n_pairs, int Lq, int S, hipStream_t st) {
   if (n_pairs <= 0) return 0;
-  if (g_fused_cpl_bf16 == 4) return launch_msda_fused_cpl<bf16_t, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
-  return launch_msda_fused_cpl<bf16_t, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+  if (g_fused_cpl_bf16 == 4) {
+    if (g_fused_nb == 8) return launch_msda_fused_cpl<bf16_t, 4, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+    return launch_msda_fused_cpl<bf16_t, 4, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+  }
+  if (g_fused_nb == 8) return launch_msda_fused_cpl<bf16_t, 8, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
+  return launch_msda_fused_cpl<bf16_t, 8, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -468,9 +504,22 @@ int mvg_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
   return 0;
 }
 
+int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl, const int64_t* shapes_host,
+                         const int64_t* starts_host, void* samp, int N_img, int Lq, int L, int S, void* stream) {
+  if (!vp || !oa || !ref_lvl || !shapes_host || !starts_host || !samp) return MVG_E_BADARG;
+  LevelTable lv;
+  int e = mvg_fill_levels(&lv, shapes_host, starts_host, L);
+  if (e) return e;
+  if (L > 4) return MVG_E_BADARG;
+  const long pairs = (long)N_img * Lq;
+  if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
+  return launch_msda_fused_pairs((const bf16_t*)vp, oa, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
+}
+
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
+  if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
   return MVG_E_BADARG;
 }
 

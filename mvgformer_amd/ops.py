@@ -179,6 +179,26 @@ def msda_fused(value, oa, r, levels):
     return samp
 
 
+def value_proj_pairs(feat, w, bias, vp):
+    """rayconv Linear of the packed pyramid feat (n_img,S,K) written straight into the bf16 pixel-pair
+    layout vp (n_img, 8, S+1, 64) (zero-initialised once by the caller)."""
+    n_img, S, K = feat.shape
+    with _timed("linear_%dx%dx%d" % (n_img * S, 256, K)):
+      L.check(L.load().mvg_value_proj_pairs(L.ptr(feat), L.dtype_code(feat.dtype), L.ptr(w), L.dtype_code(w.dtype),
+                                            L.ptr(bias), L.ptr(vp), n_img, S, K, L.stream_ptr()), "mvg_value_proj_pairs")
+    return vp
+
+
+def msda_fused_pairs(vp, oa, r, levels):
+    n_img = vp.shape[0]
+    Lq = r.shape[1]
+    samp = torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
+    with _timed("msda_fused"):
+      L.check(L.load().mvg_msda_fused_pairs(L.ptr(vp), L.ptr(oa), L.ptr(r), levels.shapes_c, levels.starts_c, L.ptr(samp),
+                                            n_img, Lq, levels.L, levels.S, L.stream_ptr()), "mvg_msda_fused_pairs")
+    return samp
+
+
 def mean_views(attn, V):
     rows = attn.shape[0] // V
     out = torch.empty((rows, attn.shape[1]), dtype=attn.dtype, device=attn.device)

@@ -73,7 +73,9 @@ class ProjAttn(nn.Module):
         self._reset_parameters()
         self.projattn_posembed_mode = projattn_posembed_mode
         self.compute_dtype = torch.float32
+        self.use_pair_layout = True     # bf16 inference: pixel-pair value layout (half the L2 gather requests)
         self._wc = WeightCache()
+        self._vp = None
 
     def _reset_parameters(self):
         constant_(self.sampling_offsets.weight.data, 0.)
@@ -108,6 +110,14 @@ class ProjAttn(nn.Module):
                 wc.get("Wp", (self.output_proj.weight,), dtype),
                 wc.get("bp", (self.output_proj.bias,), torch.float32))
 
+    def _pair_buffer(self, n_img, S, device):
+        """zero-initialised ONCE (the never-written right-corner slot of each plane's last pixel must
+        stay finite); shared by every call with the same geometry."""
+        shape = (n_img, 8, S + 1, 64)
+        if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
+            self._vp = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+        return self._vp
+
     def native_forward(self, x, r, feat, levels, V, B, rowmask=None):
         """Inference path on packed inputs.  x (B,Lq,C) f32 = tgt+query_pos; r (V*B,Lq,L,2) the
         per-level reference points; feat (V*B,S,C) channels-last pyramid in the compute dtype.
@@ -116,9 +126,14 @@ class ProjAttn(nn.Module):
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
-        value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
-        samp = ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
+        if dt == torch.bfloat16 and self.use_pair_layout:
+            vp = self._pair_buffer(n_img, S, feat.device)
+            ops.value_proj_pairs(feat, Wv, bv, vp)                           # projattn.py:169, pixel-pair layout
+            samp = ops.msda_fused_pairs(vp, oa, r, levels)                   # projattn.py:184-200
+        else:
+            value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
+            samp = ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
         return ops.linear(samp, Wp, bp, out_dtype=dt, rowmask=rowmask)       # projattn.py:203 (+ dq_decoder.py:585)
 
     # ------------------------------------------------------------------------------- forward

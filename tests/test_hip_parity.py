@@ -357,3 +357,28 @@ def test_decoder_full_size_properties():
         assert torch.equal(torch.cat([a[1], b[1]], 1), full[1])
         assert torch.equal(torch.cat([a[2], b[2]], 2), full[2])
     assert torch.isfinite(full[0]).all() and torch.isfinite(full[1]).all()
+
+
+def test_pixel_pair_layout_is_bit_identical_to_pixel_major():
+    """bf16 fast path: value projection written in the pixel-pair layout + pair-reading fused kernel
+    == row-major value + pixel-major fused kernel, bit for bit (same corners, same order)."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_half")
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    pa = dec.layers[0].proj_attn
+    with torch.no_grad():
+        ctx = DecoderContext.build(gc.src_views, gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size,
+                                   torch.bfloat16, 1)
+        r, ref_lvl, inside = ops.project(gc.reference_points, ctx.cams, ctx.levels, ctx.V, 1)
+        # push some points out of the maps to exercise the w_low = -1 / W-1 pair slots
+        ref_lvl[:, 0::7] = ref_lvl[:, 0::7] * 1.6 - 0.3
+        x = (gc.tgt + gc.query_pos).contiguous()
+        pa.use_pair_layout = False
+        a = pa.native_forward(x, ref_lvl, ctx.feat, ctx.levels, ctx.V, 1)
+        pa.use_pair_layout = True
+        b = pa.native_forward(x, ref_lvl, ctx.feat, ctx.levels, ctx.V, 1)
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a, b)

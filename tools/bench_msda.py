@@ -1,0 +1,75 @@
+"""Micro-benchmark of msda_fused on the cfg-2 layer-0 inputs (real offsets/logits from the
+synthetic weights), A/B over the tuning knobs.  GPU only.  python tools/bench_msda.py [dtype]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from mvgformer_amd import _lib, ops  # noqa: E402
+from mvgformer_amd.decoder import DecoderContext  # noqa: E402
+from mvgformer_amd.factory import build_decoder_for_case, case_to_device  # noqa: E402
+from mvgformer_amd.synthetic import build_case  # noqa: E402
+
+dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+case = build_case("cfg2", seed=0, layers=1)
+dec = build_decoder_for_case(case, "cuda", dtype)
+g = case_to_device(case, "cuda")
+layer = dec.layers[0]
+pa = layer.proj_attn
+lib = _lib.load()
+with torch.no_grad():
+    ctx = DecoderContext.build(g.src_views, g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, 1)
+    r, ref_lvl, inside = ops.project(g.reference_points, ctx.cams, ctx.levels, ctx.V, 1)
+    x = (g.tgt + g.query_pos).contiguous()
+    Wv, bv, Woa, boa, Wp, bp = pa.weights(dtype)
+    ain = ops.gather_ref(ctx.feat, ref_lvl, x, ctx.levels, ctx.V, 1)
+    value = ops.linear(ctx.feat.view(-1, 256), Wv, bv, out_dtype=dtype).view(ctx.V, -1, 256)
+    oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)
+    elem = 2 if dtype == torch.bfloat16 else 4
+    Lq, S = 15360, ctx.levels.S
+    bytes_launch = ctx.V * (S * 256 * elem + Lq * 8 * 3 * 8 * 3 * elem + Lq * 256 * elem)
+
+    def run(tag, n=20):
+        for _ in range(3):
+            ops.msda_fused(value, oa, ref_lvl, ctx.levels)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            out = ops.msda_fused(value, oa, ref_lvl, ctx.levels)
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) / n * 1e3
+        print("%-28s %8.1f us  %7.1f GB/s algorithmic" % (tag, us, bytes_launch / us / 1e3))
+        return out
+
+    if dtype == torch.bfloat16:
+        vp = pa._pair_buffer(ctx.V, S, value.device)
+        ops.value_proj_pairs(ctx.feat, Wv, bv, vp)
+        for _ in range(3):
+            ops.msda_fused_pairs(vp, oa, ref_lvl, ctx.levels)
+        torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(20):
+            outp = ops.msda_fused_pairs(vp, oa, ref_lvl, ctx.levels)
+        e_.record()
+        torch.cuda.synchronize()
+        us = s_.elapsed_time(e_) / 20 * 1e3
+        print("%-28s %8.1f us  %7.1f GB/s algorithmic" % ("PAIRS cpl=8 nb=4", us, bytes_launch / us / 1e3))
+        lib.mvg_set_tuning(b"fused_cpl_bf16", 8); lib.mvg_set_tuning(b"fused_nb", 4)
+        ref = ops.msda_fused(value, oa, ref_lvl, ctx.levels)
+        print("    pairs == pixel-major:", bool(torch.equal(outp, ref)))
+    base = None
+    knobs = [("fused_cpl_bf16", 8), ("fused_cpl_bf16", 4)] if dtype == torch.bfloat16 else [("fused_cpl_bf16", 8)]
+    for ck, cv in knobs:
+        for nb in (4, 8):
+            lib.mvg_set_tuning(ck.encode(), cv)
+            lib.mvg_set_tuning(b"fused_nb", nb)
+            out = run("cpl=%d nb=%d" % (cv, nb))
+            if base is None:
+                base = out.float()
+            else:
+                print("    max |diff| vs first variant: %.3e" % float((out.float() - base).abs().max()))
