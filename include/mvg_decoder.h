@@ -54,8 +54,9 @@ extern "C" {
  * usable device is present; MVG_E_NOGPU otherwise.  Host-only. */
 int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
 const char* mvg_version(void);
-/* Kernel-variant knobs for A/B measurements (host-only, process-wide).  Keys:
- *   "fused_cpl_bf16" = 4 | 8 : channels per lane of the bf16 fused sampling kernel. */
+/* Kernel-variant knobs for A/B measurements (host-only, process-wide; env MVG_TUNE="k=v,..").  Keys:
+ *   "fused_cpl_bf16" = 4 | 8, "fused_nb" = 4 | 8, "fused_headx" = 0 | 1 : fused sampling kernel variants;
+ *   "chain_rm" = 64 | 128, "chain_a_waves" / "chain_waves" = 4 | 8     : fused Linear-chain geometry. */
 int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
@@ -148,6 +149,28 @@ int mvg_class_head(const float* tgt, const float* Wc, const float* bc, float thr
 /* last pose_embed layer (N=3): o (rows,3) f32 = h (rows,C) @ W3 (3,C)^T + b3. */
 int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, float* o,
                 int rows, int C, void* stream);
+
+/* Fused bf16 chain per (image, query) row (dq_decoder.py:585-588,659-690):
+ *   attn = inside * (samp @ Wp^T + bp)                       (stored: input of the view mean)
+ *   o    = W2 relu(W1 relu(W0 attn + b0) + b1) + b2          (dx, dy, confidence logit)
+ * samp/attn (rows,256) bf16; Wp,W0,W1 (256,256) bf16; W2 (3,256) f32; biases f32; o (rows,3) f32.
+ * Replaces mvg_linear x3 + mvg_rowdot3 of the unfused path; activations stay in LDS. */
+int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
+                        const void* W0, const float* b0, const void* W1, const float* b1,
+                        const float* W2, const float* b2, void* attn, float* o, int rows, void* stream);
+
+/* Fused bf16 chain per joint token (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-908):
+ *   t1 = LN2(tgt + Wu mean_v(attn_v) + bu);  tgt' = LN3(t1 + W2 relu(W1 t1 + b1) + b2) (has_ffn) else t1;
+ *   prob = mean_j sigmoid(Wc tgt' + bc);  valid = prob[...,1] > threshold (or forced_valid).
+ * attn (V, B*NQ*J, 256) bf16; tgt/tgt_out (B*NQ*J, 256) f32; Wu (256,256), W1 (1024,256), W2 (256,1024) bf16
+ * in the fragment order of csrc/chain.hip (mvgformer_amd.ops.swizzle_weight); LN params / biases f32;
+ * any_valid must be zeroed by the caller.  Replaces mean_views + 3 linears + 2 add_layernorm + class_head. */
+int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,
+                               const float* g2, const float* be2, const void* W1, const float* b1,
+                               const void* W2, const float* b2, const float* g3, const float* be3,
+                               const float* Wc, const float* bc, float threshold,
+                               const uint8_t* forced_valid, float* tgt_out, float* prob, uint8_t* valid,
+                               int* any_valid, int B, int NQ, int J, int has_ffn, void* stream);
 
 /* A.6-A.8 (dq_decoder.py:659-717,399-461,119-246,1013-1029; multiview.py:170-269):
  * 2D refinement, view-softmax confidence, un-crop, 5-iteration undistortion, DLT rows,

@@ -32,6 +32,8 @@ SIGNATURES = {
     "mvg_msda_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_value_proj_pairs": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "mvg_msda_fused_pairs": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvg_chain_attn_pose": [_vp] * 12 + [_i, _vp],
+    "mvg_chain_update_ffn_class": [_vp, _i] + [_vp] * 13 + [_f] + [_vp] * 5 + [_i] * 4 + [_vp],
     "mvg_mean_views": [_vp, _i, _vp, _i, _i, _i, _vp],
     "mvg_add_layernorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_class_head": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -63,6 +65,10 @@ def load():
     lib.mvg_version.restype = C.c_char_p
     lib.mvg_version.argtypes = []
     _lib = lib
+    # A/B knobs for measurements: MVG_TUNE="chain_rm=128,fused_nb=4"
+    for item in filter(None, os.environ.get("MVG_TUNE", "").split(",")):
+        k, v = item.split("=")
+        check(lib.mvg_set_tuning(k.strip().encode(), int(v)), "mvg_set_tuning(%s)" % item)
     return lib
 
 

@@ -1,0 +1,453 @@
+// Fused per-token Linear chains of the decoder layer (bf16 MFMA, fp32 accumulate), gfx950.
+//
+// With K = 256 the dense projections of this model sit at ~128 FLOP/byte in bf16 -- below the
+// MI355X ridge (2.5 PF / 8 TB/s = 312 FLOP/B): as separate GEMM launches they are bound by
+// writing and re-reading (rows x 256) activations.  Here a workgroup keeps a tile of rows
+// resident in LDS and walks it through a whole chain of Linears; only the weights (128 KB per
+// 256x256 layer, L2-resident) are streamed.
+//
+// Weight operands of the chains are in the fragment order documented at stage_gemm (host helper:
+// mvgformer_amd.ops.swizzle_weight).
+//
+//   chain A (per (image, query) row; dq_decoder.py:585-588 + 659-690):
+//       attn = inside * (samp @ Wp^T + bp)            -> stored (needed for the view mean)
+//       o    = W2 relu(W1 relu(W0 attn + b0) + b1) + b2   (dx, dy, confidence logit)
+//   chain B (per joint token; dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-893):
+//       t1   = LN2(tgt + Wu mean_v(attn_v) + bu)
+//       tgt' = LN3(t1 + W2f relu(W1f t1 + b1f) + b2f)
+//       prob = mean_j sigmoid(Wc tgt' + bc), valid = prob[1] > thr
+//
+// Stage GEMM: 4 wavefronts, wave w owns output columns [64w, 64w+64) for all RM rows; the
+// activation tile (RM x 256 bf16, 528-byte pitch -> conflict-free ds_read_b128) is the MFMA
+// "B" operand, the weight fragment the "A" operand, so a lane ends with 4 consecutive output
+// columns of one row and writes the next stage's input back to LDS with 8-byte stores.
+#include "common.h"
+
+namespace {
+
+constexpr int ACT_PITCH = 528;   // bytes per activation row in LDS (256 bf16 + 16 pad)
+
+// Stage GEMM  acc[m][n] = sum_k act[m][k] * W[n][k]  for one 256-column block of W.
+// Weights are NOT staged through LDS: they are pre-swizzled on the host into MFMA-fragment order
+//   Wf[wn 4][ks K/16][j 2][lane 64][8 bf16],  lane (rl = lane&31, h = lane>>5) holds
+//   W[n = wn*64 + j*32 + rl][k = ks*16 + h*8 .. +8],
+// so every fragment load of a wavefront is one fully coalesced 1-KB global_load_dwordx4 from the
+// L2-resident weight (128 KB per 256x256 layer), issued RING k-steps ahead of its MFMAs.  The
+// waves of a workgroup never synchronise inside a stage (the activation tile is read-only).
+// `rot` rotates the k-step order per workgroup: all workgroups walk the SAME 128-KB weight, and in
+// lock-step they would all hit the same L2 channel at the same time (measured: 1.3 us average
+// load latency, MFMA utilisation 13 %); with a per-workgroup rotation the requests spread over the
+// whole weight at any instant.  (fp32 accumulation order changes with rot: results agree with the
+// unfused kernels to fp32 rounding, not bit for bit.)
+template <int MT, int KSTEPS, int RING = 4>
+__device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const bf16_t* __restrict__ Wf,
+                                           f32x16 (&acc)[MT][2], int tid, bool zero, int rot,
+                                           int wn_stride = KSTEPS * 1024) {
+  static_assert((KSTEPS & (KSTEPS - 1)) == 0, "KSTEPS must be a power of two");
+  // 4 column slices (wn) x NRB row blocks of MT*32 rows: waves 0-3 take rows [0, MT*32), waves 4-7 the next block
+  const int lane = tid & 63, wn = (tid >> 6) & 3, row0 = (tid >> 8) * MT * 32, rl = lane & 31, h = lane >> 5;
+  if (zero) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mt][j][e] = 0.f;
+  }
+  const bf16_t* wp = Wf + (long)wn * wn_stride + lane * 8;   // wn_stride: elements between the wave slices
+  f32x4 ring[RING][2];
+#pragma unroll
+  for (int p = 0; p < RING; ++p) {
+    const int kq = (p + rot) & (KSTEPS - 1);
+    ring[p][0] = *reinterpret_cast<const f32x4*>(wp + kq * 1024);
+    ring[p][1] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + 512);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int kc = (ks + rot) & (KSTEPS - 1);
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      a[mt] = *reinterpret_cast<const f32x4*>(act + (row0 + mt * 32 + rl) * ACT_PITCH + kc * 32 + 16 * h);
+    const f32x4 b0 = ring[ks % RING][0], b1 = ring[ks % RING][1];
+    if (ks + RING < KSTEPS) {
+      const int kq = (ks + RING + rot) & (KSTEPS - 1);
+      ring[ks % RING][0] = *reinterpret_cast<const f32x4*>(wp + kq * 1024);
+      ring[ks % RING][1] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + 512);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, a[mt]),
+                                                          acc[mt][0], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, a[mt]),
+                                                          acc[mt][1], 0, 0, 0);
+    }
+    // pin the k-step: without this hipcc sinks the ring refills down to their uses (issue -> vmcnt(0)
+    // -> MFMA in the same step, i.e. no prefetch distance at all; measured MFMA utilisation 13 %)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// acc (+bias, relu, row keep-mask) -> bf16 activation tile in LDS, IN PLACE: the caller puts a
+// __syncthreads() before (every wave finished reading `act`) and after (next stage may read).
+template <int MT>
+__device__ __forceinline__ void write_act(char* __restrict__ act, const f32x16 (&acc)[MT][2],
+                                          const float* __restrict__ bias, bool relu, const bool (&keep)[MT], int tid) {
+  const int lane = tid & 63, wn = (tid >> 6) & 3, row0 = (tid >> 8) * MT * 32, rl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = wn * 64 + j * 32 + 8 * g + 4 * h;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float x = acc[mt][j][4 * g + t] + bv[t];
+          if (relu) x = fmaxf(x, 0.f);
+          v[t] = keep[mt] ? x : 0.f;
+        }
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(act + (row0 + mt * 32 + rl) * ACT_PITCH + n * 2) = pk;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// chain A
+template <int RM, int NT>   // NT = 256 (4 waves) or 512 (8 waves: two row blocks)
+__global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict__ samp, const uint8_t* __restrict__ inside,
+                                                      const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
+                                                      const bf16_t* __restrict__ W0, const float* __restrict__ b0,
+                                                      const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                      const float* __restrict__ W2, const float* __restrict__ b2,
+                                                      bf16_t* __restrict__ attn, float* __restrict__ o, int R) {
+  constexpr int MT = RM / 32 / (NT / 256);                  // row tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;
+  const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
+  const int r0 = blockIdx.x * RM, row0 = (tid >> 8) * MT * 32;
+  const int rot = (blockIdx.x * 7 + ((tid >> 6) & 3) * 3) & 15;   // de-synchronise the weight walk (see stage_gemm)
+
+  // samp tile -> LDS (16-byte vectors, rows past R are zero); all loads in flight before the first write
+  {
+    f32x4 x[RM * 32 / NT];
+#pragma unroll
+    for (int i = 0; i < RM * 32 / NT; ++i) {
+      const int c = i * NT + tid, row = c >> 5, v16 = c & 31;
+      // clamped address + select instead of a branch: a guarded load makes hipcc wait vmcnt(0) per element
+      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)min(r0 + row, R - 1) * 256 + v16 * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RM * 32 / NT; ++i) {
+      const int c = i * NT + tid, row = c >> 5, v16 = c & 31;
+      *reinterpret_cast<f32x4*>(act + row * ACT_PITCH + v16 * 16) = (r0 + row < R) ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x16 acc[MT][2];
+  bool keep[MT], all[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = r0 + row0 + mt * 32 + rl;
+    keep[mt] = (inside[min(row, R - 1)] != 0) && (row < R);      // dq_decoder.py:585-586
+    all[mt] = true;
+  }
+  __syncthreads();
+  // attn = inside * output_proj(samp)
+  stage_gemm<MT, 16>(act, Wp, acc, tid, true, rot);
+  __syncthreads();
+  write_act<MT>(act, acc, bp, false, keep, tid);
+  __syncthreads();
+#pragma unroll
+  for (int c0 = 0; c0 < RM * 32; c0 += NT) {
+    const int c = c0 + tid, row = c >> 5, v16 = c & 31;
+    if (r0 + row < R)
+      *reinterpret_cast<f32x4*>(attn + (long)(r0 + row) * 256 + v16 * 8) =
+          *reinterpret_cast<const f32x4*>(act + row * ACT_PITCH + v16 * 16);
+  }
+  // pose_embed MLP layers 0, 1 (ReLU)
+  stage_gemm<MT, 16>(act, W0, acc, tid, true, rot + 5);
+  __syncthreads();
+  write_act<MT>(act, acc, b0, true, all, tid);
+  __syncthreads();
+  stage_gemm<MT, 16>(act, W1, acc, tid, true, rot + 10);
+  __syncthreads();
+  write_act<MT>(act, acc, b1, true, all, tid);
+  __syncthreads();
+  // last layer (3 outputs): 4 threads per row (RM = 64) / 8 threads per row (RM = 32)
+  constexpr int TPR = NT / RM, CPT = 256 / TPR;
+  const int row = tid / TPR, part = tid % TPR;
+  float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < CPT; c += 8) {
+    const uint4 hv = *reinterpret_cast<const uint4*>(act + row * ACT_PITCH + (part * CPT + c) * 2);
+    const unsigned w4[4] = {hv.x, hv.y, hv.z, hv.w};
+    float hf[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      hf[2 * t] = __uint_as_float(w4[t] << 16);
+      hf[2 * t + 1] = __uint_as_float(w4[t] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(W2 + k * 256 + part * CPT + c);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(W2 + k * 256 + part * CPT + c + 4);
+      s[k] += hf[0] * wa[0] + hf[1] * wa[1] + hf[2] * wa[2] + hf[3] * wa[3] + hf[4] * wb[0] + hf[5] * wb[1] +
+              hf[6] * wb[2] + hf[7] * wb[3];
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < TPR; off <<= 1)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] += __shfl_xor(s[k], off, 64);
+  if (part == 0 && r0 + row < R) {
+    o[(long)(r0 + row) * 3 + 0] = s[0] + b2[0];
+    o[(long)(r0 + row) * 3 + 1] = s[1] + b2[1];
+    o[(long)(r0 + row) * 3 + 2] = s[2] + b2[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// chain B: one workgroup = QPT person-queries x 15 joints (60 token rows in a 64-row tile).
+//   mean over views -> feature_update_mlp -> +tgt -> LN2 -> FFN (4 hidden chunks of 256) -> +t1 -> LN3
+//   -> class head (sigmoid, mean over the 15 joints, threshold).
+constexpr int XP = 1040;         // bytes per fp32 row in LDS (256 fp32 + 16 pad)
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// acc (+bias) -> fp32 LDS tile xb[row][n] (add = accumulate onto what is there)
+template <int MT>
+__device__ __forceinline__ void acc_to_x(char* __restrict__ xb, const f32x16 (&acc)[MT][2], const float* __restrict__ bias,
+                                         bool add, int tid) {
+  const int lane = tid & 63, wn = (tid >> 6) & 3, row0 = (tid >> 8) * MT * 32, rl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = wn * 64 + j * 32 + 8 * g + 4 * h;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4* dst = reinterpret_cast<f32x4*>(xb + (row0 + mt * 32 + rl) * XP + n * 4);
+        f32x4 v = {acc[mt][j][4 * g] + bv[0], acc[mt][j][4 * g + 1] + bv[1], acc[mt][j][4 * g + 2] + bv[2],
+                   acc[mt][j][4 * g + 3] + bv[3]};
+        if (add) v += *dst;
+        *dst = v;
+      }
+    }
+}
+
+template <int BRING, int NT>
+__global__ __launch_bounds__(NT) void chain_b_kernel(
+    const bf16_t* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu,
+    const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
+    const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+    const float* __restrict__ b2, const float* __restrict__ g3, const float* __restrict__ be3,
+    const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
+    float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
+    int rows, int J, int nq_total, int has_ffn) {
+  constexpr int RM = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;                       // RM x 256 bf16 : GEMM operand (mean, then t1)
+  char* hbuf = smem + RM * ACT_PITCH;     // RM x 256 bf16 : FFN hidden chunk
+  char* xb = hbuf + RM * ACT_PITCH;       // RM x 256 fp32 : pre-LN sums / t1 / tgt'
+  float* pr = reinterpret_cast<float*>(xb + RM * XP);   // RM x 2 per-row class probabilities
+  constexpr int MT = 2 / (NT / 256), NW = NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qpt = RM / J;                                // queries per tile (4 for J = 15)
+  const int rpt = qpt * J;                               // real rows per tile (60)
+  const int q0 = blockIdx.x * qpt, r0 = q0 * J;
+  const int nrow = min(rpt, rows - r0);
+  const int rot = (blockIdx.x * 7 + (wave & 3) * 3) & 15;
+
+  // ---- mean over views (dq_decoder.py:770) -> act (bf16)
+  {
+    const float inv = 1.f / (float)V;
+#pragma unroll 1
+    for (int i = 0; i < RM * 32 / NT; ++i) {
+      const int c = i * NT + tid, row = c >> 5, v16 = c & 31;
+      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const long off = (long)(r0 + min(row, nrow - 1)) * 256 + v16 * 8;
+      // views in groups of 8 with all loads of a group in flight (clamped index + zero weight instead
+      // of a guard: a guarded load makes hipcc wait vmcnt(0) per element)
+      for (int v0 = 0; v0 < V; v0 += 8) {
+        uint4 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          x[k] = *reinterpret_cast<const uint4*>(attn + (long)min(v0 + k, V - 1) * rows * 256 + off);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float wv = (v0 + k < V) ? 1.f : 0.f;
+          const unsigned w4[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            s[2 * t] = fmaf(wv, __uint_as_float(w4[t] << 16), s[2 * t]);
+            s[2 * t + 1] = fmaf(wv, __uint_as_float(w4[t] & 0xffff0000u), s[2 * t + 1]);
+          }
+        }
+      }
+      uint4 o;
+      unsigned* op = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a = row < nrow ? s[2 * t] * inv : 0.f, b = row < nrow ? s[2 * t + 1] * inv : 0.f;
+        op[t] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+      }
+      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
+  f32x16 acc[MT][2];
+  stage_gemm<MT, 16, BRING>(act, Wu, acc, tid, true, rot);
+  acc_to_x<MT>(xb, acc, bu, false, tid);
+  __syncthreads();
+  for (int row = wave; row < RM; row += NW) {           // one wavefront per row, 4 channels per lane
+    f32x4 v = *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
+    if (row < nrow) v += *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + row) * 256 + lane * 4);
+    const float mean = wsum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+    const f32x4 d = v - mean;
+    const float rstd = 1.f / sqrtf(wsum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f) + 1e-5f);
+    const f32x4 y = d * rstd * *reinterpret_cast<const f32x4*>(g2 + lane * 4) + *reinterpret_cast<const f32x4*>(be2 + lane * 4);
+    *reinterpret_cast<f32x4*>(xb + row * XP + lane * 16) = y;                       // t1 (fp32, residual)
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16(y[0]) | ((unsigned)f32_to_bf16(y[1]) << 16);
+    pk.y = (unsigned)f32_to_bf16(y[2]) | ((unsigned)f32_to_bf16(y[3]) << 16);
+    *reinterpret_cast<uint2*>(act + row * ACT_PITCH + lane * 8) = pk;               // t1 (bf16, GEMM operand)
+  }
+  __syncthreads();
+
+  if (has_ffn) {
+    // ---- FFN (mvp_decoder.py:94-98): Y = sum_c relu(t1 W1_c^T + b1_c) W2[:, c]^T, hidden chunks of 256
+    f32x16 accy[MT][2];
+    bool all[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) all[mt] = true;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      stage_gemm<MT, 16, BRING>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c);
+      write_act<MT>(hbuf, acc, b1 + c * 256, true, all, tid);                         // private buffer: no hazard with act
+      __syncthreads();
+      stage_gemm<MT, 16, BRING>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024);
+      __syncthreads();                                                               // hbuf free for the next chunk
+    }
+    acc_to_x<MT>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
+    __syncthreads();
+  }
+
+  // ---- tgt' = LN3(x) (or t1 when the FFN is off) ; class head per row (dq_decoder.py:889-893)
+  for (int row = wave; row < RM; row += NW) {
+    f32x4 y = *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
+    if (has_ffn) {
+      const float mean = wsum(y[0] + y[1] + y[2] + y[3]) * (1.f / 256.f);
+      const f32x4 d = y - mean;
+      const float rstd = 1.f / sqrtf(wsum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f) + 1e-5f);
+      y = d * rstd * *reinterpret_cast<const f32x4*>(g3 + lane * 4) + *reinterpret_cast<const f32x4*>(be3 + lane * 4);
+    }
+    if (row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + lane * 4) = y;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + lane * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + lane * 4);
+    const float a0 = wsum(y[0] * w0[0] + y[1] * w0[1] + y[2] * w0[2] + y[3] * w0[3]) + bc[0];
+    const float a1 = wsum(y[0] * w1[0] + y[1] * w1[1] + y[2] * w1[2] + y[3] * w1[3]) + bc[1];
+    if (lane == 0) {
+      pr[2 * row] = 1.f / (1.f + expf(-a0));
+      pr[2 * row + 1] = 1.f / (1.f + expf(-a1));
+    }
+  }
+  __syncthreads();
+  if (tid < qpt && q0 + tid < nq_total) {
+    float p0 = 0.f, p1 = 0.f;
+    for (int j = 0; j < J; ++j) {
+      p0 += pr[2 * (tid * J + j)];
+      p1 += pr[2 * (tid * J + j) + 1];
+    }
+    p0 /= (float)J;
+    p1 /= (float)J;
+    const int qi = q0 + tid;
+    prob[2 * (long)qi] = p0;
+    prob[2 * (long)qi + 1] = p1;
+    const bool ok = forced ? (forced[qi] != 0) : (p1 > threshold);                   // dq_decoder.py:605
+    valid[qi] = ok ? 1 : 0;
+    if (ok) atomicOr(any_valid, 1);
+  }
+}
+
+}  // namespace
+
+int g_chain_waves = 8;    // tuning knob "chain_waves": wavefronts per workgroup of chain B (4 | 8); measured 86 -> 69 us
+int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 measured slower: 93 vs 79 us)
+int g_chain_rm = 64;   // tuning knob "chain_rm": rows per workgroup of the fused chains (64 | 128)
+
+template <int RM, int NT>
+static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
+                          const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
+                          float* o, int rows, hipStream_t st) {
+  const size_t lds = RM * ACT_PITCH;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((chain_a_kernel<RM, NT>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
+                     (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, rows);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
+                                   const void* W0, const float* b0, const void* W1, const float* b1, const float* W2,
+                                   const float* b2, void* attn, float* o, int rows, void* stream) {
+  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_chain_rm == 128 && g_chain_a_waves == 8) return launch_chain_a<128, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
+  if (g_chain_rm == 128) return launch_chain_a<128, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
+  if (g_chain_a_waves == 8) return launch_chain_a<64, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
+  return launch_chain_a<64, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
+}
+
+extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,
+                                          const float* g2, const float* be2, const void* W1, const float* b1,
+                                          const void* W2, const float* b2, const float* g3, const float* be3,
+                                          const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
+                                          float* tgt_out, float* prob, uint8_t* valid, int* any_valid, int B, int NQ,
+                                          int J, int has_ffn, void* stream) {
+  if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
+  if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
+  if (V <= 0 || J <= 0 || J > 64 || B < 0 || NQ < 0) return MVG_E_BADARG;
+  const int nq_total = B * NQ, rows = nq_total * J;
+  if (rows == 0) return 0;
+  const int qpt = 64 / J;
+  const size_t lds = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const dim3 grid((nq_total + qpt - 1) / qpt);
+#define MVG_CB(R, NTH)                                                                                                  \
+  hipLaunchKernelGGL((chain_b_kernel<R, NTH>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
+                     (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc,     \
+                     threshold, forced_valid, tgt_out, prob, valid, any_valid, rows, J, nq_total, has_ffn)
+  if (g_chain_waves == 8) MVG_CB(4, 512);
+  else MVG_CB(4, 256);
+#undef MVG_CB
+  MVG_LAUNCH_CHECK();
+  return 0;
+}

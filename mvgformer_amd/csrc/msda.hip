@@ -194,7 +194,12 @@ __device__ __forceinline__ void store_acc(T* p, const float (&acc)[CPL]) {
   }
 }
 
-template <typename T, int L, int CPL, int NB, bool PAIRS = false>
+// HEADX: head-per-XCD work mapping.  Block b works on head (b & 7) -- with the round-robin dispatch
+// of gfx950 (block b -> XCD b % 8) every XCD then touches only ONE head plane of `value`
+// (2.6-5.2 MB per view instead of all 8 heads = 21-41 MB), which its 4-MB L2 can actually hold,
+// so gathers that miss the 32-KB L1 hit in L2 instead of going out to the Infinity Cache / HBM.
+// A wavefront is then 16 (image,query) pairs x 1 head x 4 lanes (CPL = 8).
+template <typename T, int L, int CPL, int NB, bool PAIRS = false, bool HEADX = false>
 __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) void msda_fused_kernel(const T* __restrict__ value, const float* __restrict__ oa,
                                                          const float* __restrict__ r, LevelTable lv,
                                                          T* __restrict__ samp, int n_pairs, int Lq, int S) {
@@ -209,11 +214,20 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
   const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
   const int lblock = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int pair = (lblock * 4 + wave) * PPW + lane / (8 * LPH);
+  int pair, m, sub;
+  if constexpr (HEADX) {
+    static_assert(!HEADX || CPL == 8, "head-per-XCD mapping is written for 4 lanes per head");
+    m = blockIdx.x & 7;
+    pair = (blockIdx.x >> 3) * 64 + wave * 16 + (lane >> 2);
+    sub = lane & 3;
+  } else {
+    pair = (lblock * 4 + wave) * PPW + lane / (8 * LPH);
+    m = (lane / LPH) & 7;
+    sub = lane % LPH;
+  }
   const bool live = pair < n_pairs;
   if (!live) pair = n_pairs - 1;                       // keep the wavefront converged; store is masked
   const int n = pair / Lq;
-  const int m = (lane / LPH) & 7, sub = lane % LPH;
 
   // ---- pass 1: max and sum of the head's L*P logits (softmax denominator), redundantly on the
   //      LPH lanes of a head; 16-byte loads that all lanes of a head share (one broadcast each)
@@ -327,9 +341,23 @@ static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r
   return 0;
 }
 
+static int g_fused_headx = 1;      // tuning knob "fused_headx": head-per-XCD mapping of the pair-layout kernel
+
 static int launch_msda_fused_pairs(const bf16_t* vp, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
                                    int n_pairs, int Lq, int S, hipStream_t st) {
   if (n_pairs <= 0) return 0;
+  if (g_fused_headx) {
+    const int gridx = 8 * ((n_pairs + 63) / 64);
+    switch (lv.L) {
+      case 1: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 1, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+      case 2: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 2, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+      case 3: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 3, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+      case 4: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 4, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
+      default: return MVG_E_BADARG;
+    }
+    MVG_LAUNCH_CHECK();
+    return 0;
+  }
   const int grid = (n_pairs + 7) / 8;
   switch (lv.L) {
     case 1: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 1, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
@@ -516,10 +544,18 @@ int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl, 
   return launch_msda_fused_pairs((const bf16_t*)vp, oa, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
 }
 
+extern int g_chain_rm;
+extern int g_chain_waves;
+extern int g_chain_a_waves;
+
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;
+  if (!strcmp(key, "chain_a_waves") && (value == 4 || value == 8)) { g_chain_a_waves = value; return 0; }
+  if (!strcmp(key, "chain_waves") && (value == 4 || value == 8)) { g_chain_waves = value; return 0; }
+  if (!strcmp(key, "chain_rm") && (value == 64 || value == 128)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
+  if (!strcmp(key, "fused_headx") && (value == 0 || value == 1)) { g_fused_headx = value; return 0; }
   return MVG_E_BADARG;
 }
 

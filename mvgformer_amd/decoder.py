@@ -161,6 +161,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.filter_query = filter_query
         self.d_model = d_model
         self.compute_dtype = torch.float32
+        self.use_fused_chains = True    # bf16 inference: LDS-resident Linear chains (csrc/chain.hip)
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
@@ -232,26 +233,26 @@ class DQDecoderLayer(MvPDecoderLayer):
         X = reference_points.detach().reshape(B, Lq, 3).float().contiguous()
         r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
         x = self.with_pos_embed(tgt.float(), None if query_pos is None else query_pos.float()).contiguous()
-        attn = self.proj_attn.native_forward(x, ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
-
-        # 2. update the query features (update_feature 'MLP', dq_decoder.py:763-778 + forward_ffn)
         f32 = torch.float32
-        mean = ops.mean_views(attn, V)
-        u = ops.linear(mean, self._w("Wu", (self.feature_update_mlp.weight,), dt),
-                       self._w("bu", (self.feature_update_mlp.bias,), f32), out_dtype=dt)
-        t1 = ops.add_layernorm(tgt.float().reshape(B * Lq, C).contiguous(), u,
-                               self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32))
-        if self.open_forward_ffn:
-            h = ops.linear(t1, self._w("W1", (self.linear1.weight,), dt), self._w("b1", (self.linear1.bias,), f32),
-                           out_dtype=dt, relu=True)
-            f = ops.linear(h, self._w("W2", (self.linear2.weight,), dt), self._w("bb2", (self.linear2.bias,), f32),
-                           out_dtype=dt)
-            tgt_update = ops.add_layernorm(t1, f, self._w("g3", (self.norm3.weight,), f32),
-                                           self._w("b3", (self.norm3.bias,), f32))
+        pose_layers = self.pose_embed.MLP.layers
+        fuse_a = (dt == torch.bfloat16 and self.use_fused_chains and len(pose_layers) == 3 and
+                  pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256)
+        o = None
+        if fuse_a:
+            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B)
+            sw = lambda w: ops.swizzle_weight(w.to(dt))
+            attn, o = ops.chain_attn_pose(
+                samp, inside.view(-1),
+                self._w("Wp_sw", (self.proj_attn.output_proj.weight,), dt, sw),
+                self._w("bp", (self.proj_attn.output_proj.bias,), f32),
+                self._w("Wpe0_sw", (pose_layers[0].weight,), dt, sw), self._w("bpe0", (pose_layers[0].bias,), f32),
+                self._w("Wpe1_sw", (pose_layers[1].weight,), dt, sw), self._w("bpe1", (pose_layers[1].bias,), f32),
+                self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
         else:
-            tgt_update = t1
+            attn = self.proj_attn.native_forward(x, ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
 
-        # 3. class head + filter (dq_decoder.py:889-908)
+        # 2.+3. update the query features (update_feature 'MLP', dq_decoder.py:763-778 + forward_ffn),
+        #       class head + filter (dq_decoder.py:889-908)
         forced = None
         if not self.filter_query or self.query_filter_method == "all":
             forced = torch.ones((B, NQ), dtype=torch.uint8, device=tgt.device)
@@ -259,18 +260,51 @@ class DQDecoderLayer(MvPDecoderLayer):
             forced = torch.zeros((B, NQ), dtype=torch.uint8, device=tgt.device)
             for b, q in enumerate(indices):
                 forced[b, torch.as_tensor(q, dtype=torch.long, device=tgt.device)] = 1
-        prob, valid, any_valid = ops.class_head(tgt_update, self._w("Wc", (self.class_embed.weight,), f32),
-                                                self._w("bc", (self.class_embed.bias,), f32), threshold, B, NQ, J, forced)
+        tgt32 = tgt.float().reshape(B * Lq, C).contiguous()
+        fuse_b = (dt == torch.bfloat16 and self.use_fused_chains and C == 256 and J <= 64 and
+                  (not self.open_forward_ffn or self.linear1.out_features == 1024))
+        if fuse_b:
+            sw = lambda w: ops.swizzle_weight(w.to(dt))
+            ffn = self.open_forward_ffn
+            tgt_update, prob, valid, any_valid = ops.chain_update_ffn_class(
+                attn, V, tgt32,
+                self._w("Wu_sw", (self.feature_update_mlp.weight,), dt, sw), self._w("bu", (self.feature_update_mlp.bias,), f32),
+                self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
+                self._w("W1_sw", (self.linear1.weight,), dt, sw) if ffn else None,
+                self._w("b1", (self.linear1.bias,), f32) if ffn else None,
+                self._w("W2_sw", (self.linear2.weight,), dt, sw) if ffn else None,
+                self._w("bb2", (self.linear2.bias,), f32) if ffn else None,
+                self._w("g3", (self.norm3.weight,), f32) if ffn else None,
+                self._w("b3", (self.norm3.bias,), f32) if ffn else None,
+                self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32),
+                threshold, B, NQ, J, forced, ffn)
+        else:
+            mean = ops.mean_views(attn, V)
+            u = ops.linear(mean, self._w("Wu", (self.feature_update_mlp.weight,), dt),
+                           self._w("bu", (self.feature_update_mlp.bias,), f32), out_dtype=dt)
+            t1 = ops.add_layernorm(tgt32, u, self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32))
+            if self.open_forward_ffn:
+                h = ops.linear(t1, self._w("W1", (self.linear1.weight,), dt), self._w("b1", (self.linear1.bias,), f32),
+                               out_dtype=dt, relu=True)
+                f = ops.linear(h, self._w("W2", (self.linear2.weight,), dt), self._w("bb2", (self.linear2.bias,), f32),
+                               out_dtype=dt)
+                tgt_update = ops.add_layernorm(t1, f, self._w("g3", (self.norm3.weight,), f32),
+                                               self._w("b3", (self.norm3.bias,), f32))
+            else:
+                tgt_update = t1
+            prob, valid, any_valid = ops.class_head(tgt_update, self._w("Wc", (self.class_embed.weight,), f32),
+                                                    self._w("bc", (self.class_embed.bias,), f32), threshold, B, NQ, J, forced)
         if self._any_valid_hook is not None:
             self._any_valid_hook(any_valid)
 
         # 4. 2D offsets from the per-view attention features (calculate_2d_offsets, dq_decoder.py:659-717)
-        hcur = attn
-        layers = self.pose_embed.MLP.layers
-        for i, lin in enumerate(layers[:-1]):
-            hcur = ops.linear(hcur, self._w("Wpe%d" % i, (lin.weight,), dt), self._w("bpe%d" % i, (lin.bias,), f32),
-                              out_dtype=dt, relu=True)
-        o = ops.rowdot3(hcur, self._w("Wpe_last", (layers[-1].weight,), f32), self._w("bpe_last", (layers[-1].bias,), f32))
+        if o is None:
+            hcur = attn
+            for i, lin in enumerate(pose_layers[:-1]):
+                hcur = ops.linear(hcur, self._w("Wpe%d" % i, (lin.weight,), dt), self._w("bpe%d" % i, (lin.bias,), f32),
+                                  out_dtype=dt, relu=True)
+            o = ops.rowdot3(hcur, self._w("Wpe_last", (pose_layers[-1].weight,), f32),
+                            self._w("bpe_last", (pose_layers[-1].bias,), f32))
 
         # 5. triangulation + scatter (learnable_triangulate, dq_decoder.py:399-461,1013-1029)
         new_ref, ref2d, proj2d = ops.triangulate(r, o, ctx.cams, valid, any_valid, V, B, NQ, J)

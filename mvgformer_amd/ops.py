@@ -199,6 +199,53 @@ def msda_fused_pairs(vp, oa, r, levels):
     return samp
 
 
+def swizzle_weight(w):
+    """nn.Linear weight (N, K) bf16 with N % 256 == 0 -> MFMA-fragment order of csrc/chain.hip:
+    Wf[nb N/256][wn 4][ks K/16][j 2][lane 64][8], lane = h*32 + rl holds
+    W[nb*256 + wn*64 + j*32 + rl][ks*16 + h*8 : +8]."""
+    N, K = w.shape
+    assert N % 256 == 0 and K % 16 == 0, (N, K)
+    t = w.reshape(N // 256, 4, 2, 32, K // 16, 2, 8)          # nb, wn, j, rl, ks, h, e
+    return t.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)
+
+
+def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2):
+    """fused output_proj (* in-image mask) + 3-layer pose MLP; Wp/W0/W1 in swizzle_weight order.
+    Returns (attn bf16 (rows,256), o f32 (rows,3))."""
+    rows = samp.shape[0]
+    attn = torch.empty((rows, 256), dtype=torch.bfloat16, device=samp.device)
+    o = torch.empty((rows, 3), dtype=torch.float32, device=samp.device)
+    with _timed("chain_attn_pose"):
+      L.check(L.load().mvg_chain_attn_pose(L.ptr(samp), L.ptr(inside), L.ptr(Wp), L.ptr(bp), L.ptr(W0), L.ptr(b0), L.ptr(W1),
+                                           L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o), rows, L.stream_ptr()),
+              "mvg_chain_attn_pose")
+    return attn, o
+
+
+def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
+                           forced_valid=None, has_ffn=True):
+    """fused view-mean + update MLP + LN2 + FFN + LN3 + class head (weights in swizzle_weight order).
+    Returns (tgt_update f32 (B*NQ*J,256), prob (B,NQ,2), valid (B,NQ) u8, any_valid int32[1])."""
+    dev = attn.device
+    rows = B * NQ * J
+    tgt_out = torch.empty((rows, 256), dtype=torch.float32, device=dev)
+    prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
+    any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with _timed("chain_update_ffn_class"):
+      L.check(L.load().mvg_chain_update_ffn_class(
+          L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
+          L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out), L.ptr(prob),
+          L.ptr(valid), L.ptr(any_valid), B, NQ, J, 1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class")
+    return tgt_out, prob, valid, any_valid
+
+
+def swizzle_weight_k(w):
+    """(256, K) weight with K = n*256 consumed in K-chunks of 256 (FFN linear2): fragment order
+    Wf[wn 4][ks K/16][j 2][lane 64][8] -- chunk c starts at ks = 16*c, wave stride (K/16)*1024."""
+    return swizzle_weight(w)
+
+
 def mean_views(attn, V):
     rows = attn.shape[0] // V
     out = torch.empty((rows, attn.shape[1]), dtype=attn.dtype, device=attn.device)

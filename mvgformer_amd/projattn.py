@@ -122,6 +122,12 @@ class ProjAttn(nn.Module):
         """Inference path on packed inputs.  x (B,Lq,C) f32 = tgt+query_pos; r (V*B,Lq,L,2) the
         per-level reference points; feat (V*B,S,C) channels-last pyramid in the compute dtype.
         Returns (V*B*Lq, C)."""
+        samp = self.native_sample(x, r, feat, levels, V, B)
+        _, _, _, _, Wp, bp = self.weights(feat.dtype)
+        return ops.linear(samp, Wp, bp, out_dtype=feat.dtype, rowmask=rowmask)   # projattn.py:203 (+ dq_decoder.py:585)
+
+    def native_sample(self, x, r, feat, levels, V, B):
+        """everything of native_forward up to (not including) output_proj: (V*B*Lq, C) sampled values."""
         dt = feat.dtype
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
@@ -134,7 +140,7 @@ class ProjAttn(nn.Module):
         else:
             value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
             samp = ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
-        return ops.linear(samp, Wp, bp, out_dtype=dt, rowmask=rowmask)       # projattn.py:203 (+ dq_decoder.py:585)
+        return samp
 
     # ------------------------------------------------------------------------------- forward
     def forward(self, query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,

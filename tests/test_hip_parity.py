@@ -382,3 +382,25 @@ def test_pixel_pair_layout_is_bit_identical_to_pixel_major():
         b = pa.native_forward(x, ref_lvl, ctx.feat, ctx.levels, ctx.V, 1)
     assert torch.isfinite(a.float()).all()
     assert torch.equal(a, b)
+
+
+def test_fused_chains_match_unfused_path():
+    """LDS-resident chains (output_proj * mask -> pose MLP; view mean -> update -> LN -> FFN -> LN -> class
+    head) vs the separate MFMA linears / LayerNorm / class-head kernels."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_half")
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    layer = dec.layers[0]
+    outs = []
+    for fused in (False, True):
+        layer.use_fused_chains = fused
+        with torch.no_grad():
+            outs.append(layer(gc.tgt, gc.query_pos, gc.reference_points[:, :, None], gc.src_views, gc.spatial_shapes,
+                              gc.level_start_index, gc.meta, threshold=0.1))
+    a, b = outs
+    # same bf16 operands, fp32 accumulation in another k order -> agreement to fp32/bf16 rounding
+    assert float((a[4] - b[4]).abs().max()) < 1e-3 and float((a[0] - b[0]).abs().max()) < 3e-2
+    assert torch.equal(a[3], b[3])                                           # projections untouched
+    assert float((a[2] - b[2]).abs().max()) < 5e-2                           # px
+    assert float((a[1] - b[1]).norm(dim=-1).max()) < 1.0                     # mm
