@@ -130,6 +130,18 @@ int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl,
                          const int64_t* shapes_host, const int64_t* starts_host, void* samp,
                          int N_img, int Lq, int L, int S, void* stream);
 
+/* Weight-stationary forms (persistent workgroups, the weight lives in registers; csrc/wreg_gemm.hip):
+ * mvg_value_proj_pairs_ws = mvg_value_proj_pairs for bf16 feat, Wf in the fragment order of
+ * mvgformer_amd.ops.swizzle_weight; mvg_oa_gather_gemm = mvg_gather_ref + the offsets/logits Linear in one
+ * kernel: oa (V*B*Lq*L, N) f32 = bilinear(feat, ref_lvl) @ W^T + xw[(b,q)], where
+ * xw (B*Lq, N) f32 = (tgt+query_pos) @ W^T + bias is computed once per layer (N = 192, weight zero-padded
+ * to 256 rows before swizzling). */
+int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
+                            void* stream);
+int mvg_oa_gather_gemm(const void* feat, const float* ref_lvl, const float* xw, const void* Wf,
+                       const int64_t* shapes_host, const int64_t* starts_host, float* oa,
+                       int V, int B, int Lq, int L, int S, int N, void* stream);
+
 /* A.4 (dq_decoder.py:770): mean over views of attn (V,B*Lq,C) `dtype` -> (B*Lq,C) `dtype`. */
 int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream);
 

@@ -189,6 +189,26 @@ def value_proj_pairs(feat, w, bias, vp):
     return vp
 
 
+def value_proj_pairs_ws(feat, w_frag, bias, vp):
+    """weight-stationary value projection (bf16 feat, swizzled weight) into the pixel-pair layout."""
+    n_img, S, K = feat.shape
+    with _timed("value_proj_ws"):
+      L.check(L.load().mvg_value_proj_pairs_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(bias), L.ptr(vp), n_img, S, L.stream_ptr()),
+              "mvg_value_proj_pairs_ws")
+    return vp
+
+
+def oa_gather_gemm(feat, r, xw, w_frag, levels, V, B, N=192):
+    """fused ref-point bilinear gather + offsets/logits Linear; r (n_img,Lq,L,2), xw (B*Lq,N) f32."""
+    n_img, S, _ = feat.shape
+    Lq = r.shape[1]
+    oa = torch.empty((n_img * Lq * levels.L, N), dtype=torch.float32, device=feat.device)
+    with _timed("oa_gather_gemm"):
+      L.check(L.load().mvg_oa_gather_gemm(L.ptr(feat), L.ptr(r), L.ptr(xw), L.ptr(w_frag), levels.shapes_c, levels.starts_c,
+                                          L.ptr(oa), V, B, Lq, levels.L, S, N, L.stream_ptr()), "mvg_oa_gather_gemm")
+    return oa
+
+
 def msda_fused_pairs(vp, oa, r, levels):
     n_img = vp.shape[0]
     Lq = r.shape[1]

@@ -74,6 +74,7 @@ class ProjAttn(nn.Module):
         self.projattn_posembed_mode = projattn_posembed_mode
         self.compute_dtype = torch.float32
         self.use_pair_layout = True     # bf16 inference: pixel-pair value layout (half the L2 gather requests)
+        self.use_weight_stationary = True   # bf16 inference: persistent weight-in-register GEMMs (csrc/wreg_gemm.hip)
         self._wc = WeightCache()
         self._vp = None
 
@@ -131,11 +132,24 @@ class ProjAttn(nn.Module):
         dt = feat.dtype
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
-        ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
-        oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
+        ws = dt == torch.bfloat16 and self.use_weight_stationary
+        if ws:
+            # (ref feats + query) @ W = ref feats @ W + [query @ W + b]: the query term is computed once per layer
+            pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
+                                                  .to(dt))
+            Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
+            xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
+            oa = ops.oa_gather_gemm(feat, r, xw, Woa_f, levels, V, B, Woa.shape[0])   # projattn.py:148-153,180-181
+        else:
+            ain = ops.gather_ref(feat, r, x, levels, V, B)                   # projattn.py:148-153,180 (+query)
+            oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)          # projattn.py:180-181
         if dt == torch.bfloat16 and self.use_pair_layout:
             vp = self._pair_buffer(n_img, S, feat.device)
-            ops.value_proj_pairs(feat, Wv, bv, vp)                           # projattn.py:169, pixel-pair layout
+            if ws:
+                Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
+                ops.value_proj_pairs_ws(feat, Wv_f, bv, vp)                  # projattn.py:169, weight-stationary
+            else:
+                ops.value_proj_pairs(feat, Wv, bv, vp)                       # projattn.py:169, pixel-pair layout
             samp = ops.msda_fused_pairs(vp, oa, r, levels)                   # projattn.py:184-200
         else:
             value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
