@@ -21,7 +21,6 @@
 
 namespace {
 
-constexpr int RM = 64;            // rows per tile
 constexpr int ACT_PITCH = 528;    // bytes per bf16 activation row in LDS (256 bf16 + 16 pad)
 
 struct WregParams {
@@ -56,6 +55,10 @@ __device__ __forceinline__ uint4 blend_bf16x8(const uint4& c00, const uint4& c10
 
 template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
+  // rows per tile: 64 for the gather form; 32 for the plain form, whose next tile is prefetched into
+  // registers (128 weight + 32 accumulator + 16 prefetch VGPRs fit the 256-register budget of 2 waves/SIMD)
+  constexpr int RM = GATHER ? 64 : 32;
+  constexpr int MT = RM / 32, NCH = RM * 32 / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                       // RM x 256 bf16 A tile
   char* stage = smem + RM * ACT_PITCH;    // epilogue staging (pairs: RM x 528 B; gather: 32 x (N*4+16) B)
@@ -74,25 +77,28 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   }
 
   const int ntiles = (p.M + RM - 1) / RM;
+  uint4 xpre[GATHER ? 1 : NCH];            // plain mode: next A tile, in flight across the MFMAs / epilogue
+  auto prefetch = [&](int tile) {
+    if constexpr (!GATHER) {
+      const int rr = min(tile, ntiles - 1) * RM;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
+        xpre[i] = *reinterpret_cast<const uint4*>(p.A + (long)min(rr + row, p.M - 1) * 256 + v16 * 8);
+      }
+    }
+  };
+  prefetch(blockIdx.x);
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * RM;
     // ---------------- A tile -> LDS
     if constexpr (!GATHER) {
+      // the tile was prefetched into registers during the previous iteration (or before the loop)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        uint4 x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = (half * 4 + i) * 256 + tid, row = c >> 5, v16 = c & 31;
-          x[i] = *reinterpret_cast<const uint4*>(p.A + (long)min(r0 + row, p.M - 1) * 256 + v16 * 8);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = (half * 4 + i) * 256 + tid, row = c >> 5, v16 = c & 31;
-          *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = x[i];
-        }
+      for (int i = 0; i < NCH; ++i) {
+        const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
+        *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = xpre[i];
       }
     } else {
       // thread -> (row = i*8 + tid/32, 16-byte chunk = tid%32); the 4 corner pointers / weights of a row are
@@ -127,11 +133,13 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
       }
     }
     __syncthreads();
+    prefetch(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- MFMA: acc[mt][j] = A_tile(64 x 256) . W_slice(64 cols)^T, weights from registers
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -139,12 +147,12 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
     if (wave_has_cols) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        f32x4 a[2];
+        f32x4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           a[mt] = *reinterpret_cast<const f32x4*>(act + (mt * 32 + rl) * ACT_PITCH + ks * 32 + 16 * h);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks][j]),
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
           const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;
           const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + nn);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
+          for (int mt = 0; mt < MT; ++mt) {
             uint2 pk;
             pk.x = (unsigned)f32_to_bf16(acc[mt][j][4 * g] + bv[0]) | ((unsigned)f32_to_bf16(acc[mt][j][4 * g + 1] + bv[1]) << 16);
             pk.y = (unsigned)f32_to_bf16(acc[mt][j][4 * g + 2] + bv[2]) | ((unsigned)f32_to_bf16(acc[mt][j][4 * g + 3] + bv[3]) << 16);
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
       __syncthreads();
       bf16_t* vp = reinterpret_cast<bf16_t*>(p.out);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
         const int grow = r0 + row;
         if (grow < p.M) {
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
       const int vpr = p.N / 4;                 // 16-byte vectors per output row
       float* oa = reinterpret_cast<float*>(p.out);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         if (wave_has_cols) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
@@ -230,7 +238,8 @@ int launch_wreg(const WregParams& p, size_t lds, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  const int ntiles = (p.M + RM - 1) / RM;
+  const int RMh = GATHER ? 64 : 32;
+  const int ntiles = (p.M + RMh - 1) / RMh;
   const int grid = ntiles < 512 ? ntiles : 512;      // persistent: 2 workgroups per CU
   hipLaunchKernelGGL((wreg_gemm_kernel<GATHER>), dim3(grid), dim3(256), lds, st, p);
   MVG_LAUNCH_CHECK();
@@ -245,7 +254,7 @@ extern "C" int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const f
   WregParams p = {};
   p.A = (const bf16_t*)feat; p.Wf = (const bf16_t*)Wf; p.bias = bias; p.out = vp;
   p.M = n_img * S; p.N = 256; p.S_img = S;
-  return launch_wreg<false>(p, 2 * RM * ACT_PITCH, (hipStream_t)stream);
+  return launch_wreg<false>(p, 2 * 32 * ACT_PITCH, (hipStream_t)stream);
 }
 
 extern "C" int mvg_oa_gather_gemm(const void* feat, const float* ref_lvl, const float* xw, const void* Wf,
@@ -261,5 +270,5 @@ extern "C" int mvg_oa_gather_gemm(const void* feat, const float* ref_lvl, const 
   if (rows > 0x7fffffffL) return MVG_E_BADARG;
   if (rows == 0) return 0;
   p.M = (int)rows; p.N = N; p.S_img = S; p.ref_lvl = ref_lvl; p.xw = xw; p.Lq = Lq; p.B = B;
-  return launch_wreg<true>(p, RM * ACT_PITCH + 32 * (N * 4 + 16), (hipStream_t)stream);
+  return launch_wreg<true>(p, 64 * ACT_PITCH + 32 * (N * 4 + 16), (hipStream_t)stream);
 }

@@ -77,6 +77,7 @@ class ProjAttn(nn.Module):
         self.use_weight_stationary = True   # bf16 inference: persistent weight-in-register GEMMs (csrc/wreg_gemm.hip)
         self._wc = WeightCache()
         self._vp = None
+        self._vp_event = None
 
     def _reset_parameters(self):
         constant_(self.sampling_offsets.weight.data, 0.)
@@ -119,6 +120,24 @@ class ProjAttn(nn.Module):
             self._vp = torch.zeros(shape, dtype=torch.bfloat16, device=device)
         return self._vp
 
+    def project_values(self, feat, record_event=False):
+        """value = rayconv(input_flatten) (projattn.py:169) in the bf16 pixel-pair layout.  The projection
+        does not depend on the queries, so DQDecoder runs it for every layer on a side stream, overlapped
+        with the previous layers' query-side kernels (record_event=True: the consumer waits on the event)."""
+        dt = feat.dtype
+        n_img, S, _ = feat.shape
+        Wv, bv = self._wc.get("Wv", (self.rayconv.weight,), dt), self._wc.get("bv", (self.rayconv.bias,), torch.float32)
+        vp = self._pair_buffer(n_img, S, feat.device)
+        if self.use_weight_stationary:
+            Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
+            ops.value_proj_pairs_ws(feat, Wv_f, bv, vp)                      # weight-stationary
+        else:
+            ops.value_proj_pairs(feat, Wv, bv, vp)
+        if record_event:
+            self._vp_event = torch.cuda.Event()
+            self._vp_event.record()
+        return vp
+
     def native_forward(self, x, r, feat, levels, V, B, rowmask=None):
         """Inference path on packed inputs.  x (B,Lq,C) f32 = tgt+query_pos; r (V*B,Lq,L,2) the
         per-level reference points; feat (V*B,S,C) channels-last pyramid in the compute dtype.
@@ -144,12 +163,12 @@ class ProjAttn(nn.Module):
             ain = ops.gather_ref(feat, r, x, levels, V, B)                   # projattn.py:148-153,180 (+query)
             oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)          # projattn.py:180-181
         if dt == torch.bfloat16 and self.use_pair_layout:
-            vp = self._pair_buffer(n_img, S, feat.device)
-            if ws:
-                Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
-                ops.value_proj_pairs_ws(feat, Wv_f, bv, vp)                  # projattn.py:169, weight-stationary
+            if self._vp_event is not None:                                   # projected ahead of time on a side stream
+                torch.cuda.current_stream().wait_event(self._vp_event)
+                self._vp_event = None
+                vp = self._vp
             else:
-                ops.value_proj_pairs(feat, Wv, bv, vp)                       # projattn.py:169, pixel-pair layout
+                vp = self.project_values(feat)
             samp = ops.msda_fused_pairs(vp, oa, r, levels)                   # projattn.py:184-200
         else:
             value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
