@@ -31,9 +31,26 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n== PMC (mean per dispatch)")
 for k in sorted(acc, key=lambda k: -sum(acc[k].get("GRBM_GUI_ACTIVE", [0]))):
-    if not any(s in k for s in ("msda", "linear", "chain", "gather", "triang", "pack", "add_ln", "mean_views", "class_head", "rowdot", "project")):
+    if not any(s in k for s in ("msda", "linear", "chain", "wreg", "gather", "triang", "pack", "add_ln", "mean_views", "class_head", "rowdot", "project")):
         continue
     print(k)
     for c in sorted(acc[k]):
         v = acc[k][c]
         print("    %-34s %16.1f  (n=%d)" % (c, sum(v) / len(v), len(v)))
+
+# ---- machine-readable HBM-side traffic of the dominant kernel (read by bench.py -> roofline.traffic)
+import json
+for k in acc:
+    if k.startswith("msda_fused_kernel") and "FETCH_SIZE" in acc[k]:
+        fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
+        write_kb = sum(acc[k].get("WRITE_SIZE", [0])) / max(len(acc[k].get("WRITE_SIZE", [0])), 1)
+        rec = {"kernel": k, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+               "fetch_correction": 2.0,
+               "note": "gfx950 rocprofv3: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B "
+                       "(MI355X_MICROARCH.md, HBM section); calibrated in the same run on kernels with a known read "
+                       "volume: pack_level (fp32 read once) FETCH/actual = 0.49, value projection (103 MB bf16 read once) 0.56",
+               "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
+        with open(os.path.join(out, "pmc_msda.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+        print("\nmsda traffic/launch: %.1f MB (2 x FETCH_SIZE %.1f MB + WRITE_SIZE %.1f MB)"
+              % (rec["traffic_bytes_per_launch"] / 1e6, fetch_kb * 1024 / 1e6, write_kb * 1024 / 1e6))
