@@ -44,7 +44,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", help="cfg2 (headline) | cfg4 | cfg5 | cfg1 | mini5")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--graph", type=int, default=1, help="replay the forward as a captured HIP graph")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="replay the forward as a captured HIP graph (-1 = auto: on for 1 GPU, off when the forward "
+                         "contains RCCL collectives)")
     ap.add_argument("--valid-fraction", type=float, default=None,
                     help="fraction of queries passing the 0.1 threshold (default: all valid = worst case)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -59,11 +61,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MVG_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm; gloo only for plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mvgformer_amd import _lib, ops
     from mvgformer_amd import dist as mdist
@@ -100,7 +107,7 @@ def main():
             out = mdist.gather_outputs(out, NQ, J, None, gather_hidden=False)
         return out
 
-    use_graph = bool(args.graph)
+    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
     graph = None
     with torch.no_grad():
         for _ in range(3):
@@ -139,13 +146,15 @@ def main():
 
         # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
         prof = {}
-        if rank == 0 and args.profile_steps > 0 and world == 1:
-            ops.PROFILE = {}
+        if args.profile_steps > 0:                 # every rank runs it (the sharded forward contains collectives)
+            if rank == 0:
+                ops.PROFILE = {}
             for _ in range(args.profile_steps):
                 forward()
             torch.cuda.synchronize()
-            prof = ops.profile_summary()
-            ops.PROFILE = None
+            if rank == 0:
+                prof = ops.profile_summary()
+                ops.PROFILE = None
 
     if rank != 0:
         if world > 1:
