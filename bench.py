@@ -107,13 +107,20 @@ def main():
             out = mdist.gather_outputs(out, NQ, J, None, gather_hidden=False)
         return out
 
-    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    use_graph = True if args.graph < 0 else bool(args.graph)
     graph = None
     with torch.no_grad():
         for _ in range(3):
             out = forward()
         torch.cuda.synchronize()
-        if use_graph:
+        if use_graph and world > 1:
+            # segments between the collectives are graphs, the RCCL calls stay eager (mvgformer_amd.dist)
+            for layer in dec.layers:
+                layer._any_valid_hook = None
+            graph = mdist.GraphedShardedDecoder(dec, tgt, ref, g.src_views, qpos, ctx, thr, NQ)
+            out = graph.replay()
+            torch.cuda.synchronize()
+        elif use_graph:
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
@@ -146,6 +153,8 @@ def main():
 
         # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
         prof = {}
+        if world > 1:
+            mdist.install_any_valid_sync(dec, None)
         if args.profile_steps > 0:                 # every rank runs it (the sharded forward contains collectives)
             if rank == 0:
                 ops.PROFILE = {}

@@ -220,13 +220,24 @@ class DQDecoderLayer(MvPDecoderLayer):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("DQDecoderLayer.forward: the native path is inference-only; wrap the call "
                                       "in torch.no_grad() (training goes through ProjAttn/DeformFunction autograd)")
+        ctx = self._ctx
+        if ctx is None:
+            ctx = DecoderContext.build(src_views, src_spatial_shapes, level_start_index, meta, self.img_size,
+                                       self.compute_dtype, tgt.shape[0])
+        st = self.forward_features(tgt, query_pos, reference_points, ctx, threshold, indices)
+        if self._any_valid_hook is not None:
+            self._any_valid_hook(st["any_valid"])
+        return self.forward_triangulate(st, ctx)
+
+    # The layer in two halves, so that a query-sharded run can put its one per-layer exchange (the global
+    # "any query valid" flag, mvgformer_amd.dist) between two captured HIP-graph segments.
+    def forward_features(self, tgt, query_pos, reference_points, ctx, threshold, indices=None):
+        """steps 1-4 of dq_decoder.py:850-1045: projection, projective attention, feature update, class
+        head + filter, 2D offsets.  Returns the state consumed by forward_triangulate."""
         B, Lq, C = tgt.shape
         J = self.num_joints
         NQ = Lq // J
         dt = self.compute_dtype
-        ctx = self._ctx
-        if ctx is None:
-            ctx = DecoderContext.build(src_views, src_spatial_shapes, level_start_index, meta, self.img_size, dt, B)
         V = ctx.V
 
         # 1. projective attention features of every view (generate_features, dq_decoder.py:516-593)
@@ -294,9 +305,6 @@ class DQDecoderLayer(MvPDecoderLayer):
                 tgt_update = t1
             prob, valid, any_valid = ops.class_head(tgt_update, self._w("Wc", (self.class_embed.weight,), f32),
                                                     self._w("bc", (self.class_embed.bias,), f32), threshold, B, NQ, J, forced)
-        if self._any_valid_hook is not None:
-            self._any_valid_hook(any_valid)
-
         # 4. 2D offsets from the per-view attention features (calculate_2d_offsets, dq_decoder.py:659-717)
         if o is None:
             hcur = attn
@@ -306,9 +314,14 @@ class DQDecoderLayer(MvPDecoderLayer):
             o = ops.rowdot3(hcur, self._w("Wpe_last", (pose_layers[-1].weight,), f32),
                             self._w("bpe_last", (pose_layers[-1].bias,), f32))
 
-        # 5. triangulation + scatter (learnable_triangulate, dq_decoder.py:399-461,1013-1029)
-        new_ref, ref2d, proj2d = ops.triangulate(r, o, ctx.cams, valid, any_valid, V, B, NQ, J)
-        return tgt_update.view(B, Lq, C), new_ref, ref2d, proj2d, prob
+        return dict(r=r, o=o, valid=valid, any_valid=any_valid, tgt_update=tgt_update.view(B, Lq, C), prob=prob,
+                    dims=(V, B, NQ, J))
+
+    def forward_triangulate(self, st, ctx):
+        """step 5: triangulation + scatter (learnable_triangulate, dq_decoder.py:399-461,1013-1029)."""
+        V, B, NQ, J = st["dims"]
+        new_ref, ref2d, proj2d = ops.triangulate(st["r"], st["o"], ctx.cams, st["valid"], st["any_valid"], V, B, NQ, J)
+        return st["tgt_update"], new_ref, ref2d, proj2d, st["prob"]
 
 
 class MvPDecoder(nn.Module):

@@ -5,8 +5,9 @@ Every person-query is an independent unit of work in the shipped configuration
 the class head, the view-softmax, the undistortion or the DLT couples two queries.  So the
 NQ person-queries are split into contiguous blocks, one per rank (one process per GPU), each
 rank runs the whole decoder on its block with the feature pyramid / cameras / weights
-replicated, and ONE all-gather at the end of the forward assembles the pose set.  There is no
-collective inside the decoder (the reference has none either: SURVEY.md section 2.2).
+replicated, and ONE all-gather at the end of the forward assembles the pose set.  The only other
+exchange is a 4-byte MAX all-reduce per layer that keeps the reference's "no query valid anywhere ->
+force query (0,0)" rule (dq_decoder.py:620-623) global (install_any_valid_sync).
 
 The messages are small (<= 1 MB per rank at 1024 queries without the hidden states), i.e.
 latency-bound: all outputs of a rank are packed into one flat buffer so the exchange is a
@@ -37,15 +38,9 @@ def shard_queries(tgt, query_pos, reference_points, num_joints, world, rank):
     return cut(tgt), cut(query_pos), cut(reference_points), (lo, hi)
 
 
-def gather_outputs(outputs, NQ, num_joints, group=None, gather_hidden=False):
-    """all-gather the sharded decoder outputs.
-
-    outputs = (hs (Ly,B,Lq_loc,C), refs (Ly,B,Lq_loc,3), refs2d (Ly,B,V,Lq_loc,2),
-               projs2d (Ly,B,V,Lq_loc,2), [cls (B,NQ_loc,2)] * Ly)  -- DQDecoder.forward's tuple.
-    Returns the same tuple for all NQ queries (hs is None unless gather_hidden)."""
+def pack_outputs(outputs, NQ, num_joints, world, rank, gather_hidden=False):
+    """per-person records of this rank's block in ONE flat send buffer (nq_max, Ly, B, R) + its geometry."""
     hs, refs, r2d, p2d, cls = outputs
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     J = num_joints
     cls_t = torch.stack(list(cls))                                      # (Ly,B,NQ_loc,2)
     Ly, B = refs.shape[:2]
@@ -55,7 +50,6 @@ def gather_outputs(outputs, NQ, num_joints, group=None, gather_hidden=False):
     lo, hi = shard_bounds(NQ, world, rank)
     nq_loc = hi - lo
     assert refs.shape[2] == nq_loc * J, (refs.shape, nq_loc)
-
     # per-person record: [refs J*3 | refs2d V*J*2 | projs2d V*J*2 | cls 2 | (hs J*C)] per (layer, batch)
     parts = [refs.reshape(Ly, B, nq_loc, J * 3),
              r2d.reshape(Ly, B, V, nq_loc, J * 2).permute(0, 1, 3, 2, 4).reshape(Ly, B, nq_loc, V * J * 2),
@@ -64,11 +58,14 @@ def gather_outputs(outputs, NQ, num_joints, group=None, gather_hidden=False):
     if gather_hidden:
         parts.append(hs.reshape(Ly, B, nq_loc, J * C))
     rec = torch.cat([p.float() for p in parts], -1)                     # (Ly,B,nq_loc,R)
-    R = rec.shape[-1]
-    send = rec.new_zeros((nq_max, Ly, B, R))
+    send = rec.new_zeros((nq_max, Ly, B, rec.shape[-1]))
     send[:nq_loc] = rec.permute(2, 0, 1, 3)
-    recv = rec.new_empty((world * nq_max, Ly, B, R))
-    dist.all_gather_into_tensor(recv, send, group=group)                # the one exchange step
+    return send, dict(Ly=Ly, B=B, V=V, C=C, J=J, NQ=NQ, world=world, nq_max=nq_max, gather_hidden=gather_hidden)
+
+
+def unpack_outputs(recv, geo):
+    """inverse of pack_outputs on the all-gathered buffer (world*nq_max, Ly, B, R)."""
+    Ly, B, V, C, J, NQ, world, nq_max = (geo[k] for k in ("Ly", "B", "V", "C", "J", "NQ", "world", "nq_max"))
     keep = []
     for r_ in range(world):
         a, b = shard_bounds(NQ, world, r_)
@@ -81,8 +78,21 @@ def gather_outputs(outputs, NQ, num_joints, group=None, gather_hidden=False):
     p2d_f = full[..., o:o + V * J * 2].reshape(Ly, B, NQ, V, J, 2).permute(0, 1, 3, 2, 4, 5).reshape(Ly, B, V, NQ * J, 2)
     o += V * J * 2
     cls_f = full[..., o:o + 2]; o += 2
-    hs_f = full[..., o:o + J * C].reshape(Ly, B, NQ * J, C) if gather_hidden else None
+    hs_f = full[..., o:o + J * C].reshape(Ly, B, NQ * J, C) if geo["gather_hidden"] else None
     return hs_f, refs_f.contiguous(), r2d_f.contiguous(), p2d_f.contiguous(), [cls_f[i].contiguous() for i in range(Ly)]
+
+
+def gather_outputs(outputs, NQ, num_joints, group=None, gather_hidden=False):
+    """all-gather the sharded decoder outputs.
+
+    outputs = (hs (Ly,B,Lq_loc,C), refs (Ly,B,Lq_loc,3), refs2d (Ly,B,V,Lq_loc,2),
+               projs2d (Ly,B,V,Lq_loc,2), [cls (B,NQ_loc,2)] * Ly)  -- DQDecoder.forward's tuple.
+    Returns the same tuple for all NQ queries (hs is None unless gather_hidden)."""
+    world = dist.get_world_size(group)
+    send, geo = pack_outputs(outputs, NQ, num_joints, world, dist.get_rank(group), gather_hidden)
+    recv = send.new_empty((world * geo["nq_max"],) + tuple(send.shape[1:]))
+    dist.all_gather_into_tensor(recv, send, group=group)                # the one exchange step
+    return unpack_outputs(recv, geo)
 
 
 def sharded_decoder_forward(decoder, tgt, reference_points, src_views, meta, spatial_shapes, level_start_index,
@@ -120,3 +130,75 @@ def install_any_valid_sync(decoder, group, remove=False):
 
     for layer in decoder.layers:
         layer._any_valid_hook = hook
+
+
+class GraphedShardedDecoder:
+    """The query-sharded forward as HIP-graph SEGMENTS with the collectives issued eagerly in between:
+
+        [pack pyramid + layer-0 features] (all-reduce any_valid_0) [layer-0 triangulate + layer-1 features] ...
+        ... (all-reduce any_valid_last) [last triangulate + stack + pack records] (all-gather) [unpack]
+
+    so the ~25 kernels of a layer cost one graph launch on the host, and no RCCL call is captured into a
+    graph (Ly+2 graph launches and Ly+1 collectives per forward).  Inputs are static tensors: refill them
+    in place (tgt / query_pos / reference_points are this rank's shard) and call replay()."""
+
+    def __init__(self, decoder, tgt, reference_points, src_views, query_pos, ctx, threshold, NQ, group=None,
+                 gather_hidden=False):
+        self.dec, self.ctx, self.group, self.thr, self.NQ = decoder, ctx, group, threshold, NQ
+        self.tgt, self.ref, self.src, self.qpos = tgt, reference_points, src_views, query_pos
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.J = decoder.layers[0].num_joints
+        self.gather_hidden = gather_hidden
+        self.graphs, self.flags = [], []
+        self._capture()
+
+    def _sync_flag(self, any_valid):
+        dist.all_reduce(any_valid, op=dist.ReduceOp.MAX, group=self.group)
+        if self.rank != 0:
+            any_valid.fill_(1)
+
+    def _capture(self):
+        layers = list(self.dec.layers)
+        pool = None
+        outs = []
+
+        def segment(fn):
+            nonlocal pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                res = fn()
+            if pool is None:
+                pool = g.pool()
+            self.graphs.append(g)
+            return res
+
+        ref = self.ref if self.ref.dim() == 4 else self.ref[:, :, None]
+        st = segment(lambda: (self.ctx.pack(self.src), layers[0].forward_features(self.tgt, self.qpos, ref, self.ctx,
+                                                                                   self.thr))[1])
+        for l, layer in enumerate(layers):
+            self.flags.append(st["any_valid"])
+            last = l + 1 == len(layers)
+
+            def body(layer=layer, st=st, last=last, l=l):
+                o = layer.forward_triangulate(st, self.ctx)
+                outs.append(o)
+                if last:
+                    tup = (torch.stack([x[0] for x in outs]), torch.stack([x[1] for x in outs]),
+                           torch.stack([x[2] for x in outs]), torch.stack([x[3] for x in outs]), [x[4] for x in outs])
+                    return pack_outputs(tup, self.NQ, self.J, self.world, self.rank, self.gather_hidden)
+                return layers[l + 1].forward_features(o[0], self.qpos, o[1][:, :, None], self.ctx, self.thr)
+            res = segment(body)
+            if not last:
+                st = res
+        self.send, self.geo = res
+        self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
+        self.out = segment(lambda: unpack_outputs(self.recv, self.geo))
+
+    def replay(self):
+        self.graphs[0].replay()
+        for l, flag in enumerate(self.flags):
+            self._sync_flag(flag)
+            self.graphs[l + 1].replay()
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        self.graphs[-1].replay()
+        return self.out
