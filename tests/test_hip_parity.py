@@ -430,3 +430,32 @@ def test_weight_stationary_gemms_match_tiled_path():
     # offsets/logits: bf16(F)W + bf16(x)W vs bf16(F + x)W -> sampled values agree to bf16 rounding
     assert float((a - b).abs().max()) < 0.08 * float(a.abs().max())
     assert float((a - b).abs().mean()) < 5e-3 * float(a.abs().max())
+
+
+def test_decoder_head_end_to_end_vs_oracle(O):
+    """caller glue (embeddings -> queries, sample_space init, decoder, output dict, pred packing) on the GPU
+    vs the oracle fed with the same queries / reference points."""
+    from mvgformer_amd import caller
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_all")
+    dec = build_decoder_for_case(case, DEV)
+    head = caller.DecoderHead(dec, case.NQ, 15, 256, case.space_size, case.space_center).to(DEV)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        head.joint_embedding.weight.normal_()
+        head.instance_embedding.weight.normal_()
+    gc = case_to_device(_case("mini5_all"), DEV)
+    out, pred = head(gc.src_views, gc.meta, threshold=0.1)
+    qpos, tgt = caller.person_joint_queries(head.joint_embedding.weight.detach().cpu(),
+                                            head.instance_embedding.weight.detach().cpu(), 1)
+    ref = caller.sample_space_reference_points(case.NQ, case.space_size, case.space_center, 1, "cpu")
+    prm = to_torch_state(case.weights)
+    hs, refs, r2d, p2d, cls = O.decoder_forward(prm, case.layers, tgt.contiguous(), ref, case.src_views, case.meta,
+                                                case.spatial_shapes, case.level_start_index, qpos.contiguous(),
+                                                case.img_size, threshold=0.1)
+    assert pred.shape == (1, case.NQ, 15, 5)
+    want_valid = cls[-1][..., 1] > 0.1
+    assert torch.equal((pred[..., 0, 3] == 0).cpu(), want_valid)                    # (score > thr) - 1 == 0 <=> valid
+    assert float((pred[..., 4].cpu()[:, :, 0] - cls[-1][..., 1]).abs().max()) < 2e-3
+    got = out["pred_poses"]["outputs_coord"].cpu()
+    assert float((got - refs[-1]).norm(dim=-1).max()) < 3.0                         # mm, free-running 2 layers
