@@ -217,9 +217,9 @@ class DQDecoderLayer(MvPDecoderLayer):
         if not tgt.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
         self._check_supported()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("DQDecoderLayer.forward: the native path is inference-only; wrap the call "
-                                      "in torch.no_grad() (training goes through ProjAttn/DeformFunction autograd)")
+        if torch.is_grad_enabled() and (tgt.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_autograd(tgt, query_pos, reference_points, src_views, src_spatial_shapes,
+                                         level_start_index, meta, indices, threshold)
         ctx = self._ctx
         if ctx is None:
             ctx = DecoderContext.build(src_views, src_spatial_shapes, level_start_index, meta, self.img_size,
@@ -228,6 +228,71 @@ class DQDecoderLayer(MvPDecoderLayer):
         if self._any_valid_hook is not None:
             self._any_valid_hook(st["any_valid"])
         return self.forward_triangulate(st, ctx)
+
+    def forward_autograd(self, tgt, query_pos, reference_points, src_views, src_spatial_shapes, level_start_index, meta,
+                         indices=None, threshold=0.5):
+        """Training path: the same layer as differentiable torch ops (fp32) with the HIP sampling op
+        (DeformFunction forward + backward kernels) inside ProjAttn -- what run/train_3d.py needs
+        (SURVEY.md section 8 f2).  Dense compute + masking instead of the reference's gather/pad/scatter
+        (every step is per-query, so values and gradients of the kept queries are the same)."""
+        from . import geometry_torch as G
+        B, Lq, C = tgt.shape
+        J = self.num_joints
+        NQ = Lq // J
+        V = len(meta)
+        dev = tgt.device
+        img = torch.tensor(self.img_size, dtype=torch.float32, device=dev)
+        X = reference_points.reshape(B, Lq, 3)
+        if self.detach_refpoints_cameraprj:
+            X = X.detach()                                                    # dq_decoder.py:338-339
+        WH = src_spatial_shapes.flip(-1).float()
+        x = self.with_pos_embed(tgt, query_pos)
+        to_dev = lambda d: {k: v.to(dev) for k, v in d.items()}
+        attn_views, r_views = [], []
+        for v in range(V):
+            cam = to_dev(meta[v]["camera"])
+            A_crop = G.crop_affine(meta[v]["center"], meta[v]["scale"], self.img_size, dev)
+            r, inside = G.project_points(X, cam, meta[v]["center"], A_crop, self.img_size)
+            ref_lvl = r.unsqueeze(2) * WH / (WH - 1)                           # dq_decoder.py:570-573
+            src_v = [s_[v * B:(v + 1) * B] for s_ in src_views]
+            a = self.proj_attn(x, ref_lvl, src_v, None, src_spatial_shapes, level_start_index)
+            attn_views.append(inside.unsqueeze(-1).to(a.dtype) * a)            # dq_decoder.py:585-586
+            r_views.append(r)
+        mean = torch.stack(attn_views, 0).mean(0)
+        tgt_update = self.norm2(tgt + self.dropout2(self.feature_update_mlp(mean)))
+        if self.open_forward_ffn:
+            tgt_update = self.forward_ffn(tgt_update)
+        prob = self.class_embed(tgt_update).view(B, NQ, J, 2).sigmoid().mean(2)
+        if not self.filter_query or self.query_filter_method == "all":
+            valid = torch.ones((B, NQ), dtype=torch.bool, device=dev)
+        elif indices is not None:
+            valid = torch.zeros((B, NQ), dtype=torch.bool, device=dev)
+            for b, q in enumerate(indices):
+                valid[b, torch.as_tensor(q, dtype=torch.long, device=dev)] = True
+        else:
+            valid = prob[..., 1] > threshold
+        if not bool(valid.any()):
+            valid[0, 0] = True                                                 # dq_decoder.py:620-623
+        ref2d, proj2d, logit = [], [], []
+        for v in range(V):
+            off, cl = self.pose_embed(attn_views[v])
+            ref2d.append((r_views[v] + off / img) * img)
+            proj2d.append(r_views[v] * img)
+            logit.append(cl)
+        ref2d, proj2d = torch.stack(ref2d, 1), torch.stack(proj2d, 1)          # (B,V,Lq,2)
+        conf = torch.softmax(torch.stack(logit, 1), 1)
+        cam = {k: torch.stack([meta[v]["camera"][k].to(dev) for v in range(V)], 1)
+               for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
+        Ainv = torch.stack([meta[v]["inv_affine_trans"][:, :2, :].to(dev) for v in range(V)], 1).float()   # (B,V,2,3)
+        uo = torch.matmul(torch.cat([ref2d, torch.ones_like(ref2d[..., :1])], -1), Ainv.transpose(2, 3))
+        X3 = G.dlt(G.proj_matrices(cam), G.undistort(uo, cam), conf)           # (B,Lq,3)
+        vm = valid.view(B, NQ, 1, 1)
+        new_ref = torch.where(vm, X3.view(B, NQ, J, 3), torch.zeros((), device=dev)).reshape(B, Lq, 3)
+        vm2 = valid.view(B, 1, NQ, 1, 1)
+        zero = torch.zeros((), device=dev)
+        ref2d_o = torch.where(vm2, ref2d.view(B, V, NQ, J, 2), zero).reshape(B, V, Lq, 2)
+        proj2d_o = torch.where(vm2, proj2d.view(B, V, NQ, J, 2), zero).reshape(B, V, Lq, 2)
+        return tgt_update, new_ref, ref2d_o, proj2d_o, prob
 
     # The layer in two halves, so that a query-sharded run can put its one per-layer exchange (the global
     # "any query valid" flag, mvgformer_amd.dist) between two captured HIP-graph segments.

@@ -1,0 +1,90 @@
+"""Differentiable torch formulation of the decoder's camera geometry, used ONLY by the training
+(autograd) path of DQDecoderLayer; the inference path runs the HIP kernels of csrc/geom.hip.
+
+  project_points   lib/models/dq_decoder.py:331-397 + lib/utils/cameras.py:167-217
+  undistort        lib/models/dq_decoder.py:119-204 (5 fixed-point iterations)
+  proj_matrices    lib/models/dq_decoder.py:223-246 (P = K [R | -R T])
+  dlt              lib/mvn/utils/multiview.py:170-228 (torch.linalg.svd, differentiable)
+All tensors live on the caller's device; nothing here synchronises with the host except the tiny
+crop-affine construction from (center, scale), done once per forward.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def crop_affine(center, scale, img_size, device):
+    """closed form of get_affine_transform(center, scale, 0, img_size) (lib/utils/transforms.py:72-112) -> (B,2,3)."""
+    c = center.detach().to("cpu", torch.float32).double()
+    st = (scale.detach().to("cpu", torch.float32) * 200.0).double()
+    dw, dh = float(img_size[0]), float(img_size[1])
+    s = torch.where(st[:, 0] >= st[:, 1], dw / st[:, 0], dh / st[:, 1])
+    A = torch.zeros((c.shape[0], 2, 3), dtype=torch.float64)
+    A[:, 0, 0] = s
+    A[:, 1, 1] = s
+    A[:, 0, 2] = dw * 0.5 - s * c[:, 0]
+    A[:, 1, 2] = dh * 0.5 - s * c[:, 1]
+    return A.float().to(device)
+
+
+def project_points(X, cam, center, A_crop, img_size):
+    """X (B,Lq,3) mm -> r (B,Lq,2) normalised network-image coords, inside (B,Lq) bool."""
+    f32 = torch.float32
+    R = cam["R"].to(f32)
+    T = cam["T"].to(f32).reshape(-1, 3, 1)
+    xc = torch.matmul(R, X.transpose(1, 2) - T)
+    y = xc[:, :2] / (xc[:, 2:] + 1e-5)
+    k = cam["k"].to(f32).reshape(-1, 3, 1)
+    p = cam["p"].to(f32).reshape(-1, 2, 1)
+    r2 = (y ** 2).sum(1, keepdim=True)
+    radial = 1 + (k[:, 0:1] * r2 + k[:, 1:2] * r2 ** 2 + k[:, 2:3] * r2 ** 3)
+    tan = p[:, 0:1] * y[:, 1:2] + p[:, 1:2] * y[:, 0:1]
+    y = y * (radial + 2 * tan) + torch.cat([p[:, 1:2], p[:, 0:1]], 1) * r2
+    f = torch.stack([cam["fx"], cam["fy"]], 1).to(f32).reshape(-1, 2, 1)
+    c = torch.stack([cam["cx"], cam["cy"]], 1).to(f32).reshape(-1, 2, 1)
+    u = (f * y + c).transpose(1, 2)
+    wh = center.to(u.device).unsqueeze(1) * 2
+    inside = (u[..., 0] >= 0) & (u[..., 1] >= 0) & (u[..., 0] < wh[..., 0]) & (u[..., 1] < wh[..., 1])
+    u = torch.minimum(torch.clamp(u, min=-1.0), wh.max().to(u.dtype))
+    n = torch.matmul(torch.cat([u, torch.ones_like(u[..., :1])], -1), A_crop.transpose(1, 2))
+    return n / torch.tensor(img_size, dtype=f32, device=u.device), inside
+
+
+def undistort(uo, cam, iters=5):
+    """uo (B,V,N,2) original-image px; cam tensors (B,V,...)."""
+    fx, fy, cx, cy = (cam[k_].float()[..., None] for k_ in ("fx", "fy", "cx", "cy"))
+    k = cam["k"].float().reshape(*cam["k"].shape[:2], 3)
+    p = cam["p"].float().reshape(*cam["p"].shape[:2], 2)
+    k1, k2, k3 = (k[..., i:i + 1] for i in range(3))
+    p1, p2 = p[..., 0:1], p[..., 1:2]
+    x0 = uo[..., 0] * (1 / fx) + (-cx / fx)
+    y0 = uo[..., 1] * (1 / fy) + (-cy / fy)
+    x, y = x0, y0
+    for _ in range(iters):
+        r2 = x * x + y * y
+        icd = 1 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (x0 - dX) * icd
+        y = (y0 - dY) * icd
+    return torch.stack([fx * x + cx, fy * y + cy], -1)
+
+
+def proj_matrices(cam):
+    R = cam["R"].float()
+    T = cam["T"].float().reshape(*R.shape[:2], 3, 1)
+    K = torch.zeros(R.shape[:2] + (3, 3), dtype=torch.float32, device=R.device)
+    K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2] = (cam[k_].float() for k_ in ("fx", "fy", "cx", "cy"))
+    K[..., 2, 2] = 1
+    return K @ torch.cat([R, -R @ T], -1)
+
+
+def dlt(Pm, pts, conf):
+    """Pm (B,V,3,4); pts (B,V,N,2); conf (B,V,N) -> (B,N,3) via the smallest right singular vector."""
+    pt = pts.permute(0, 2, 1, 3)                                     # (B,N,V,2)
+    A = Pm[:, None, :, 2:3, :] * pt[..., None] - Pm[:, None, :, :2, :]
+    A = A * conf.permute(0, 2, 1)[..., None, None]
+    A = A.reshape(A.shape[0], A.shape[1], -1, 4)
+    _, _, Vh = torch.linalg.svd(A)
+    Xh = -Vh[..., 3, :]
+    return Xh[..., :3] / Xh[..., 3:4]

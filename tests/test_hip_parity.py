@@ -459,3 +459,37 @@ def test_decoder_head_end_to_end_vs_oracle(O):
     assert float((pred[..., 4].cpu()[:, :, 0] - cls[-1][..., 1]).abs().max()) < 2e-3
     got = out["pred_poses"]["outputs_coord"].cpu()
     assert float((got - refs[-1]).norm(dim=-1).max()) < 3.0                         # mm, free-running 2 layers
+
+
+def test_decoder_layer_training_path_matches_inference_and_backprops():
+    """autograd path (torch ops + HIP sampling op fwd/bwd) == native inference path (fp32); gradients reach
+    every parameter group the reference trains."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_half")
+    dec = build_decoder_for_case(case, DEV)
+    gc = case_to_device(case, DEV)
+    layer = dec.layers[0]
+    with torch.no_grad():
+        inf = layer(gc.tgt, gc.query_pos, gc.reference_points[:, :, None], gc.src_views, gc.spatial_shapes,
+                    gc.level_start_index, gc.meta, threshold=0.1)
+    layer.train()
+    for m in layer.modules():                       # dropout would randomise the comparison
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    tgt = gc.tgt.clone().requires_grad_(True)
+    out = layer(tgt, gc.query_pos, gc.reference_points[:, :, None], gc.src_views, gc.spatial_shapes,
+                gc.level_start_index, gc.meta, threshold=0.1)
+    assert float((out[0] - inf[0]).abs().max()) < 1e-4
+    assert float((out[4] - inf[4]).abs().max()) < 5e-6
+    assert float((out[3] - inf[3]).abs().max()) < 2e-3 and float((out[2] - inf[2]).abs().max()) < 2e-3
+    err3d = float((out[1] - inf[1]).norm(dim=-1).max().detach())
+    print("training-path 3D vs inference-path: %.3f mm" % err3d)
+    assert err3d < 3.0          # rocSOLVER fp32 SVD vs fp64 normal equations of the same fp32 rows (mm, 4 m scene)
+    loss = out[0].square().mean() + 1e-6 * out[1].square().mean() + out[4].sum() + 1e-4 * out[2].square().mean()
+    loss.backward()
+    assert tgt.grad is not None and torch.isfinite(tgt.grad).all() and float(tgt.grad.abs().max()) > 0
+    for name in ("proj_attn.sampling_offsets.weight", "proj_attn.attention_weights.weight", "proj_attn.rayconv.weight",
+                 "proj_attn.output_proj.weight", "feature_update_mlp.weight", "linear1.weight", "linear2.weight",
+                 "pose_embed.MLP.layers.0.weight", "pose_embed.MLP.layers.2.weight", "class_embed.weight", "norm2.weight"):
+        g = dict(layer.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name
