@@ -142,6 +142,17 @@ int mvg_oa_gather_gemm(const void* feat, const float* ref_lvl, const float* xw, 
                        const int64_t* shapes_host, const int64_t* starts_host, float* oa,
                        int V, int B, int Lq, int L, int S, int N, void* stream);
 
+/* "G-sampling" front end (bf16): bilinear sampling commutes with the offsets/logits Linear, so
+ * G (V*B*S, 192) bf16 = feat @ [Woff;Wattn]^T is computed once per layer on the pyramid (mvg_feat_linear_ws,
+ * weight zero-padded to 256 rows, fragment order) and mvg_msda_gsamp gathers each head's logits/offsets from G
+ * at the reference point (+ xw (B*Lq,192) f32 = query term + bias) before sampling vp -- no (rows x 192)
+ * offsets/logits tensor and no per-(view,query,level) GEMM.  Same result as mvg_oa_gather_gemm +
+ * mvg_msda_fused_pairs up to bf16 rounding of G. */
+int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
+int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl,
+                   const int64_t* shapes_host, const int64_t* starts_host, void* samp,
+                   int N_img, int Lq, int L, int S, int B, void* stream);
+
 /* A.4 (dq_decoder.py:770): mean over views of attn (V,B*Lq,C) `dtype` -> (B*Lq,C) `dtype`. */
 int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream);
 

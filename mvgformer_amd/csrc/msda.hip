@@ -322,6 +322,144 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
   if (live) store_acc<T, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
 }
 
+// ------------------------------------------------------------------------------------------
+// "G-sampling" form of the fused kernel (bf16, pixel-pair value layout, head-per-XCD mapping).
+// Bilinear sampling commutes with a Linear:  Linear(bilinear(feat, p) + x) = bilinear(feat @ W^T, p) + (x @ W^T + b).
+// So instead of gathering 256-channel reference-point features and running a (V*Lq*L x 256 x 192) GEMM per
+// layer (projattn.py:148-153,180-181), the offsets/logits Linear is applied ONCE to the pyramid
+// (G = feat @ Woa^T, a (V*S x 192) GEMM that does not depend on the queries) and every (pair, head) here
+// gathers its own 24 logits + 48 offsets from G at the reference point -- 9 chunks of 8 columns, split over the
+// 4 lanes of the head, parked in LDS -- then proceeds exactly as msda_fused_kernel.  The per-layer
+// (rows x 192) fp32 offsets/logits tensor (177 MB written + read) and its gather-GEMM kernel disappear.
+template <int L>
+__global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                                            const float* __restrict__ xw, const float* __restrict__ r,
+                                                            LevelTable lv, bf16_t* __restrict__ samp, int n_pairs,
+                                                            int Lq, int S, int B) {
+  constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 4;   // SCP: padded scratch row (76 for L=3)
+  typedef RawVec<bf16_t, 8> RV;
+  __shared__ __attribute__((aligned(16))) float scratch[4][16][SCP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x & 7, sub = lane & 3, pl = lane >> 2;
+  int pair = (blockIdx.x >> 3) * 64 + wave * 16 + pl;
+  const bool live = pair < n_pairs;
+  if (!live) pair = n_pairs - 1;
+  const int n = pair / Lq, q = pair - n * Lq, b = n % B;
+  float* sc = &scratch[wave][pl][0];
+
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk
+#pragma unroll
+  for (int k = 0; k < (NCHK + 3) / 4; ++k) {
+    const int ci = sub + 4 * k;
+    if (ci < NCHK) {
+      const bool is_logit = ci < L;
+      const int flat = is_logit ? (m * LP + 8 * ci) : (m * 2 * LP + 8 * (ci - L));
+      const int l = is_logit ? (flat >> 6) : (flat >> 7);                  // level row of the reinterpreted view
+      const int col = is_logit ? (128 + (flat & 63)) : (flat & 127);
+      const int H = lv.H[l], W = lv.W[l];
+      const float Wf = (float)W, Hf = (float)H;
+      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+      const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
+      const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+      const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
+      const float x0f = floorf(ix), y0f = floorf(iy);
+      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      const float tx = ix - x0f, ty = iy - y0f;
+      const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+      const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f, w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+      const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
+      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+      const bf16_t* gb = G + ((long)n * S + lv.start[l]) * 192 + col;
+      const uint4 c00 = *reinterpret_cast<const uint4*>(gb + (long)(y0c * W + x0c) * 192);
+      const uint4 c10 = *reinterpret_cast<const uint4*>(gb + (long)(y0c * W + x1c) * 192);
+      const uint4 c01 = *reinterpret_cast<const uint4*>(gb + (long)(y1c * W + x0c) * 192);
+      const uint4 c11 = *reinterpret_cast<const uint4*>(gb + (long)(y1c * W + x1c) * 192);
+      const float* xq = xw + ((long)b * Lq + q) * 192 + col;
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(xq), xb = *reinterpret_cast<const f32x4*>(xq + 4);
+      const unsigned a4[4] = {c00.x, c00.y, c00.z, c00.w}, b4[4] = {c10.x, c10.y, c10.z, c10.w};
+      const unsigned c4[4] = {c01.x, c01.y, c01.z, c01.w}, d4[4] = {c11.x, c11.y, c11.z, c11.w};
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v[2 * t] = w00 * __uint_as_float(a4[t] << 16) + w10 * __uint_as_float(b4[t] << 16) +
+                   w01 * __uint_as_float(c4[t] << 16) + w11 * __uint_as_float(d4[t] << 16);
+        v[2 * t + 1] = w00 * __uint_as_float(a4[t] & 0xffff0000u) + w10 * __uint_as_float(b4[t] & 0xffff0000u) +
+                       w01 * __uint_as_float(c4[t] & 0xffff0000u) + w11 * __uint_as_float(d4[t] & 0xffff0000u);
+      }
+      float* dst = sc + (is_logit ? 8 * ci : LP + 8 * (ci - L));
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0] + xa[0], v[1] + xa[1], v[2] + xa[2], v[3] + xa[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[0], v[5] + xb[1], v[6] + xb[2], v[7] + xb[3]};
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 1: softmax denominator of the head's logits
+  float mx = -INFINITY;
+  {
+    f32x4 lg[LP / 4];
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i) {
+      lg[i] = *reinterpret_cast<const f32x4*>(sc + 4 * i);
+      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i)
+      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
+    mx += __logf(sum);
+  }
+
+  const bf16_t* vbase = vp + ((long)n * 8 + m) * (S + 1) * 64 + sub * 16;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+
+  // ---- pass 2: batches of NB samples, 4*NB gathers in flight (see msda_fused_kernel)
+#pragma unroll 1
+  for (int it = 0; it < LP / NB; ++it) {
+    const int l = (it * NB) / P;
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+    const float invW = 1.f / Wf, invH = 1.f / Hf;
+    const bf16_t* lvl = vbase + (long)(1 + lv.start[l]) * 64;
+    const f32x4 lg = *reinterpret_cast<const f32x4*>(sc + it * NB);
+    const f32x4 oA = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2);
+    const f32x4 oB = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2 + 4);
+    float cw[NB][4];
+    typename RV::type raw[NB][4];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const float ox = (s < 2) ? oA[2 * s] : oB[2 * (s - 2)], oy = (s < 2) ? oA[2 * s + 1] : oB[2 * (s - 2) + 1];
+      const float lx = refx + ox * invW, ly = refy + oy * invH;       // projattn.py:186-191
+      const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;       // cuh:295-296
+      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+      const int h_low = (int)hl_f, w_low = (int)wl_f;
+      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
+      const float a = inside ? __expf(lg[s] - mx) : 0.f;
+      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+      cw[s][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;
+      cw[s][1] = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
+      cw[s][2] = (hh_ok && wl_ok) ? lh * hw * a : 0.f;
+      cw[s][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
+      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+      const int wp = min(max(w_low, -1), W - 1);
+      raw[s][0] = RV::load(lvl + (hl_c * W + wp) * 64);
+      raw[s][1] = RV::load(lvl + (hl_c * W + wp) * 64 + 8);
+      raw[s][2] = RV::load(lvl + (hh_c * W + wp) * 64);
+      raw[s][3] = RV::load(lvl + (hh_c * W + wp) * 64 + 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s][k], cw[s][k]);
+  }
+  if (live) store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
+}
+
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
 static int g_fused_nb = 4;         // tuning knob: samples per gather batch (4 or 8)
 
@@ -547,6 +685,32 @@ int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl, 
 extern int g_chain_rm;
 extern int g_chain_waves;
 extern int g_chain_a_waves;
+
+int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl, const int64_t* shapes_host,
+                   const int64_t* starts_host, void* samp, int N_img, int Lq, int L, int S, int B, void* stream) {
+  if (!vp || !G || !xw || !ref_lvl || !shapes_host || !starts_host || !samp || B <= 0) return MVG_E_BADARG;
+  LevelTable lv;
+  int e = mvg_fill_levels(&lv, shapes_host, starts_host, L);
+  if (e) return e;
+  const long pairs = (long)N_img * Lq;
+  if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
+  if (pairs == 0) return 0;
+  const int grid = 8 * (int)((pairs + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+#define MVG_GS(LL)                                                                                                \
+  hipLaunchKernelGGL((msda_gsamp_kernel<LL>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp, (const bf16_t*)G, xw, \
+                     ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B)
+  switch (L) {
+    case 1: MVG_GS(1); break;
+    case 2: MVG_GS(2); break;
+    case 3: MVG_GS(3); break;
+    case 4: MVG_GS(4); break;
+    default: return MVG_E_BADARG;
+  }
+#undef MVG_GS
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
 
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;

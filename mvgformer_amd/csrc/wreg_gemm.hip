@@ -34,6 +34,7 @@ struct WregParams {
   const float* xw;        // (B*Lq, N) f32
   LevelTable lv;
   int Lq, B;
+  int rowmajor;           // plain mode: 0 = pixel-pair layout (N = 256), 1 = row-major bf16 (M, N)
 };
 
 __device__ __forceinline__ uint4 blend_bf16x8(const uint4& c00, const uint4& c10, const uint4& c01, const uint4& c11,
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + nn);
+          const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             uint2 pk;
@@ -183,7 +184,11 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
       for (int i = 0; i < NCH; ++i) {
         const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
         const int grow = r0 + row;
-        if (grow < p.M) {
+        if (grow < p.M && p.rowmajor) {
+          if (v16 * 8 < p.N)
+            *reinterpret_cast<f32x4*>(vp + (long)grow * p.N + v16 * 8) =
+                *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
+        } else if (grow < p.M) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
           const int img = grow / p.S_img, s = grow - img * p.S_img;
           const int head = v16 >> 2, ch8 = v16 & 3;
@@ -271,4 +276,15 @@ extern "C" int mvg_oa_gather_gemm(const void* feat, const float* ref_lvl, const 
   if (rows == 0) return 0;
   p.M = (int)rows; p.N = N; p.S_img = S; p.ref_lvl = ref_lvl; p.xw = xw; p.Lq = Lq; p.B = B;
   return launch_wreg<true>(p, 64 * ACT_PITCH + 32 * (N * 4 + 16), (hipStream_t)stream);
+}
+
+// G = feat @ W^T in row-major bf16 (n_img*S, N), N in {64,128,192,256}, no bias: the offsets/logits Linear applied to the
+// pyramid itself (bilinear sampling commutes with the Linear, so the fused sampling kernel gathers G at the reference
+// point instead of running a (rows x 256) GEMM per (view, query, level)).
+extern "C" int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream) {
+  if (!feat || !Wf || !G || n_img <= 0 || S <= 0 || N <= 0 || N > 256 || N % 64 != 0) return MVG_E_BADARG;
+  WregParams p = {};
+  p.A = (const bf16_t*)feat; p.Wf = (const bf16_t*)Wf; p.bias = nullptr; p.out = G;
+  p.M = n_img * S; p.N = N; p.S_img = S; p.rowmajor = 1;
+  return launch_wreg<false>(p, 2 * 32 * ACT_PITCH, (hipStream_t)stream);
 }

@@ -209,6 +209,27 @@ def oa_gather_gemm(feat, r, xw, w_frag, levels, V, B, N=192):
     return oa
 
 
+def feat_linear_ws(feat, w_frag, N=192):
+    """G = feat @ W^T, row-major bf16 (n_img*S, N) (weight-stationary kernel, no bias)."""
+    n_img, S, _ = feat.shape
+    G = torch.empty((n_img * S, N), dtype=torch.bfloat16, device=feat.device)
+    with _timed("feat_linear_ws"):
+      L.check(L.load().mvg_feat_linear_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(G), n_img, S, N, L.stream_ptr()),
+              "mvg_feat_linear_ws")
+    return G
+
+
+def msda_gsamp(vp, G, xw, r, levels, B):
+    """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h)."""
+    n_img = vp.shape[0]
+    Lq = r.shape[1]
+    samp = torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
+    with _timed("msda_fused"):
+      L.check(L.load().mvg_msda_gsamp(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
+                                      L.ptr(samp), n_img, Lq, levels.L, levels.S, B, L.stream_ptr()), "mvg_msda_gsamp")
+    return samp
+
+
 def msda_fused_pairs(vp, oa, r, levels):
     n_img = vp.shape[0]
     Lq = r.shape[1]

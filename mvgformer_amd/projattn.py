@@ -75,6 +75,7 @@ class ProjAttn(nn.Module):
         self.compute_dtype = torch.float32
         self.use_pair_layout = True     # bf16 inference: pixel-pair value layout (half the L2 gather requests)
         self.use_weight_stationary = True   # bf16 inference: persistent weight-in-register GEMMs (csrc/wreg_gemm.hip)
+        self.use_g_sampling = True          # bf16 inference: offsets/logits Linear applied to the pyramid, gathered in the sampler
         self._wc = WeightCache()
         self._vp = None
         self._vp_event = None
@@ -120,6 +121,12 @@ class ProjAttn(nn.Module):
             self._vp = torch.zeros(shape, dtype=torch.bfloat16, device=device)
         return self._vp
 
+    def _wait_values(self):
+        """values were projected ahead of time on a side stream (DQDecoder.overlap_value_projection)."""
+        torch.cuda.current_stream().wait_event(self._vp_event)
+        self._vp_event = None
+        return self._vp
+
     def project_values(self, feat, record_event=False):
         """value = rayconv(input_flatten) (projattn.py:169) in the bf16 pixel-pair layout.  The projection
         does not depend on the queries, so DQDecoder runs it for every layer on a side stream, overlapped
@@ -158,17 +165,17 @@ class ProjAttn(nn.Module):
                                                   .to(dt))
             Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
             xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
+            if self.use_g_sampling and self.use_pair_layout and Woa.shape[0] == 192:
+                # Linear(bilinear(feat)) = bilinear(Linear(feat)): project the pyramid once, gather in the sampler
+                G = ops.feat_linear_ws(feat, Woa_f, 192)
+                vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
+                return ops.msda_gsamp(vp, G, xw, r, levels, B)                # projattn.py:148-200
             oa = ops.oa_gather_gemm(feat, r, xw, Woa_f, levels, V, B, Woa.shape[0])   # projattn.py:148-153,180-181
         else:
             ain = ops.gather_ref(feat, r, x, levels, V, B)                   # projattn.py:148-153,180 (+query)
             oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)          # projattn.py:180-181
         if dt == torch.bfloat16 and self.use_pair_layout:
-            if self._vp_event is not None:                                   # projected ahead of time on a side stream
-                torch.cuda.current_stream().wait_event(self._vp_event)
-                self._vp_event = None
-                vp = self._vp
-            else:
-                vp = self.project_values(feat)
+            vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
             samp = ops.msda_fused_pairs(vp, oa, r, levels)                   # projattn.py:184-200
         else:
             value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
