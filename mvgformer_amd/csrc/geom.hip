@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void rowdot3_kernel(const T* __restrict__ h, c
 }
 
 // ------------------------------------------------------------------------------------------
-// A.6-A.8.  One thread per (batch, query, joint).
+// A.6-A.8.  Eight lanes per (batch, query, joint).
 //  - refined 2D = (r + (dx,dy)/img) * img, view confidence = softmax over views of the logit
 //  - un-crop (inverse affine), K^-1, 5 fixed-point undistortion iterations, K
 //  - DLT rows conf*(x*P2 - P0), conf*(y*P2 - P1) with P = K [R | -R T] in fp32 exactly as the
@@ -244,9 +244,19 @@ __global__ __launch_bounds__(256) void rowdot3_kernel(const T* __restrict__ h, c
 __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][4], const int p, const int q) {
   const double apq = a[p][q];
   if (fabs(apq) < 1e-300) return;
-  const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  // The rotation ANGLE only steers convergence, so it is computed in fp32 (one fast division, one sqrt); what
+  // must hold to fp64 precision is c^2 + s^2 = 1 (the similarity transform stays orthogonal): c = rsqrt(1+t^2)
+  // starts from the fp32 rsqrt and takes two Newton steps in fp64.  (IEEE fp64 div/sqrt sequences were ~80 % of
+  // this kernel's time.)
+  const float theta = (float)(a[q][q] - a[p][p]) / (2.f * (float)apq);
+  if (!(fabsf(theta) <= 3.0e38f)) return;     // a[p][q] is negligible against the diagonal gap (or 0/0): nothing to rotate
+  const float tf = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+  const double t = (double)tf;
+  const double w = t * t + 1.0;
+  double c = (double)rsqrtf((float)w);
+  c = c * (1.5 - 0.5 * w * c * c);
+  c = c * (1.5 - 0.5 * w * c * c);
+  const double s = t * c;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {   // columns p,q of A
     const double akp = a[k][p], akq = a[k][q];
@@ -267,15 +277,31 @@ __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][
   }
 }
 
+// 8 lanes per (batch, query, joint) problem: lane `sub` handles views sub, sub+8, ... (un-crop, undistortion, its
+// two DLT rows and their contribution to the 4x4 Gram matrix), the view-softmax and the Gram matrix are reduced
+// over the 8 lanes with wavefront shuffles, then every lane runs the fp64 Jacobi redundantly (no divergence) and
+// lane 0 stores.  (One thread per problem with a serial view loop took 27 us at cfg-2: 240 wavefronts, each a
+// chain of dependent global loads; this form is one load round trip.)
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, 64);
+  hi = __shfl_xor(hi, mask, 64);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restrict__ r, const float* __restrict__ o,
                                                           const float* __restrict__ cams,
                                                           const uint8_t* __restrict__ valid,
                                                           const int* __restrict__ any_valid,
                                                           float* __restrict__ new_ref, float* __restrict__ ref2d,
                                                           float* __restrict__ proj2d, int V, int B, int NQ, int J) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tidg = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int Lq = NQ * J;
-  if (idx >= (long)B * Lq) return;
+  const long nprob = (long)B * Lq;
+  long idx = tidg >> 3;
+  const int sub = (int)(tidg & 7);
+  const bool live = idx < nprob;
+  if (!live) idx = nprob - 1;                     // keep the 8-lane groups converged for the shuffles
   const int q = (int)(idx % Lq), b = (int)(idx / Lq);
   const int i = q / J;
   bool ok = valid[b * NQ + i] != 0;
@@ -283,9 +309,13 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
 
   // softmax over views of the confidence logit (dq_decoder.py:706-707)
   float mx = -INFINITY;
-  for (int v = 0; v < V; ++v) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
+  for (int v = sub; v < V; v += 8) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
+#pragma unroll
+  for (int m_ = 1; m_ < 8; m_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m_, 64));
   float den = 0.f;
-  for (int v = 0; v < V; ++v) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
+  for (int v = sub; v < V; v += 8) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
+#pragma unroll
+  for (int m_ = 1; m_ < 8; m_ <<= 1) den += __shfl_xor(den, m_, 64);
 
   double G[4][4];
 #pragma unroll
@@ -293,7 +323,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < 4; ++c) G[a][c] = 0.0;
 
-  for (int v = 0; v < V; ++v) {
+  for (int v = sub; v < V; v += 8) {
     const long pair = ((long)v * B + b) * Lq + q;
     const float* cam = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
     const float imgw = cam[36], imgh = cam[37];
@@ -302,11 +332,11 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     const float conf = expf(o[pair * 3 + 2] - mx) / den;
     const float px = rx * imgw, py = ry * imgh;                                   // dq_decoder.py:699
     const float kx = (rx + dx / imgw) * imgw, ky = (ry + dy / imgh) * imgh;       // :679-685,696
-    const long oidx = (((long)b * V + v) * Lq + q) * 2;
-    ref2d[oidx] = ok ? kx : 0.f;
-    ref2d[oidx + 1] = ok ? ky : 0.f;
-    proj2d[oidx] = ok ? px : 0.f;
-    proj2d[oidx + 1] = ok ? py : 0.f;
+    if (live) {
+      const long oidx = (((long)b * V + v) * Lq + q) * 2;
+      *reinterpret_cast<float2*>(ref2d + oidx) = ok ? make_float2(kx, ky) : make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(proj2d + oidx) = ok ? make_float2(px, py) : make_float2(0.f, 0.f);
+    }
     // un-crop (dq_decoder.py:414-420)
     const float uo = cam[27] * kx + cam[28] * ky + cam[29];
     const float vo = cam[30] * kx + cam[31] * ky + cam[32];
@@ -346,6 +376,16 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
 #pragma unroll
       for (int c = a; c < 4; ++c) G[a][c] += (double)a1[a] * (double)a1[c] + (double)a2[a] * (double)a2[c];
   }
+  // Gram matrix over all views: butterfly sum across the 8 lanes of the problem (same result on every lane)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = a; c < 4; ++c) {
+      double g = G[a][c];
+#pragma unroll
+      for (int m_ = 1; m_ < 8; m_ <<= 1) g += shfl_xor_f64(g, m_);
+      G[a][c] = g;
+    }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -358,8 +398,8 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     for (int c = 0; c < 4; ++c) Vm[a][c] = (a == c) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 12; ++sweep) {
     const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
-    const double dg = fabs(G[0][0]) + fabs(G[1][1]) + fabs(G[2][2]) + fabs(G[3][3]);
-    if (off <= 1e-30 * dg) break;
+    const double lg = fmax(fmax(fabs(G[0][0]), fabs(G[1][1])), fmax(fabs(G[2][2]), fabs(G[3][3])));
+    if (off <= 2e-16 * lg) break;     // off-diagonals at the fp64 rounding floor of the matrix: converged
     jacobi_rotate(G, Vm, 0, 1);
     jacobi_rotate(G, Vm, 0, 2);
     jacobi_rotate(G, Vm, 0, 3);
@@ -376,10 +416,12 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
       e0 = Vm[0][c]; e1 = Vm[1][c]; e2 = Vm[2][c]; e3 = Vm[3][c];
     }
   }
-  float* nr = new_ref + ((long)b * Lq + q) * 3;
-  nr[0] = ok ? (float)(e0 / e3) : 0.f;                                            // multiview.py:220-221
-  nr[1] = ok ? (float)(e1 / e3) : 0.f;
-  nr[2] = ok ? (float)(e2 / e3) : 0.f;
+  if (live && sub == 0) {
+    float* nr = new_ref + ((long)b * Lq + q) * 3;
+    nr[0] = ok ? (float)(e0 / e3) : 0.f;                                          // multiview.py:220-221
+    nr[1] = ok ? (float)(e1 / e3) : 0.f;
+    nr[2] = ok ? (float)(e2 / e3) : 0.f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -494,7 +536,7 @@ int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, fl
 int mvg_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
                     float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J, void* stream) {
   if (!r || !o || !cams || !valid || !any_valid || !new_ref || !ref2d || !proj2d || V <= 0) return MVG_E_BADARG;
-  const long total = (long)B * NQ * J;
+  const long total = (long)B * NQ * J * 8;       // 8 lanes per (batch, query, joint)
   if (total == 0) return 0;
   hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, r, o, cams,
                      valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J);
