@@ -331,7 +331,24 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 // gathers its own 24 logits + 48 offsets from G at the reference point -- 9 chunks of 8 columns, split over the
 // 4 lanes of the head, parked in LDS -- then proceeds exactly as msda_fused_kernel.  The per-layer
 // (rows x 192) fp32 offsets/logits tensor (177 MB written + read) and its gather-GEMM kernel disappear.
-template <int L>
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+template <int S>   // value of lane S of every quad (v_mov_b32_dpp quad_perm:[S,S,S,S])
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xf, 0xf, false);
+}
+
+// QUAD = the VALU-lean pass 2 (the kernel is VALU-bound: PMC 73 % VALU-busy, 3180 VALU instructions per wavefront,
+// half of them coordinate/address math that the 4 lanes of a head repeated, a third bf16->fp32 unpacking):
+//   * each lane of the head's quad computes ONE of the 4 samples of a batch (coordinates, zero-padding, softmax
+//     weight, row offsets) and broadcasts 4 words (2 packed bf16 weight pairs, 2 row offsets) with DPP quad_perm;
+//   * the blend runs on v_dot2c_f32_bf16: one v_perm_b32 pairs the same channel of the left / right corner, the
+//     dot2 multiplies by the packed (w_left, w_right) and accumulates in fp32 -- no unpacking to fp32 at all.
+//     (the bilinear x attention weights are rounded to bf16 here; products and sums are fp32.)
+template <int L, bool QUAD, bool DOT2 = true>
 __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                             const float* __restrict__ xw, const float* __restrict__ r,
                                                             LevelTable lv, bf16_t* __restrict__ samp, int n_pairs,
@@ -415,6 +432,80 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 
+  if constexpr (QUAD) {
+    // byte offset of this lane's 16-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
+    const unsigned lane_off = (unsigned)((((long)n * 8 + m) * (S + 1)) * 128 + sub * 32);
+    const char* vp_bytes = reinterpret_cast<const char*>(vp);
+#pragma unroll 1
+    for (int it = 0; it < LP / NB; ++it) {
+      const int l = (it * NB) / P;
+      const int H = lv.H[l], W = lv.W[l];
+      const float Wf = (float)W, Hf = (float)H;
+      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+      // ---- this lane's sample of the batch: s = sub
+      const float lgs = sc[it * NB + sub];
+      const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
+      const float lx = refx + of.x * (1.f / Wf), ly = refy + of.y * (1.f / Hf);     // projattn.py:186-191
+      const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;                       // cuh:295-296
+      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+      const int h_low = (int)hl_f, w_low = (int)wl_f;
+      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
+      const float a = inside ? __expf(lgs - mx) : 0.f;
+      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+      const float c0 = (hl_ok && wl_ok) ? hh * hw * a : 0.f, c1 = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
+      const float c2 = (hh_ok && wl_ok) ? lh * hw * a : 0.f, c3 = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
+      const unsigned my_wt = DOT2 ? pack_bf16x2(c0, c1) : __float_as_uint(c0);
+      const unsigned my_wb = DOT2 ? pack_bf16x2(c2, c3) : __float_as_uint(c2);
+      const unsigned my_w1 = __float_as_uint(c1), my_w3 = __float_as_uint(c3);
+      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+      const int wp = min(max(w_low, -1), W - 1);
+      const unsigned lvl_pairs = (unsigned)(1 + lv.start[l]);
+      const unsigned my_ot = (lvl_pairs + (unsigned)(hl_c * W + wp)) * 128u;           // byte offset of the top pair line
+      const unsigned my_ob = (lvl_pairs + (unsigned)(hh_c * W + wp)) * 128u;
+      // ---- quad broadcast + 16 gathers in flight
+      unsigned wt[NB], wb[NB], w1[NB], w3[NB];
+      uint4 raw[NB][4];
+#define MVG_QS(SS)                                                                                      \
+      {                                                                                                 \
+        wt[SS] = quad_bcast<SS>(my_wt);                                                                 \
+        wb[SS] = quad_bcast<SS>(my_wb);                                                                 \
+        if (!DOT2) { w1[SS] = quad_bcast<SS>(my_w1); w3[SS] = quad_bcast<SS>(my_w3); }                  \
+        const unsigned ot = quad_bcast<SS>(my_ot) + lane_off, ob = quad_bcast<SS>(my_ob) + lane_off;    \
+        raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
+        raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + ot + 16);                               \
+        raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
+        raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + ob + 16);                               \
+      }
+      MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
+#undef MVG_QS
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!DOT2) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          RawVec<bf16_t, 8>::fma(acc, raw[s][0], __uint_as_float(wt[s]));
+          RawVec<bf16_t, 8>::fma(acc, raw[s][1], __uint_as_float(w1[s]));
+          RawVec<bf16_t, 8>::fma(acc, raw[s][2], __uint_as_float(wb[s]));
+          RawVec<bf16_t, 8>::fma(acc, raw[s][3], __uint_as_float(w3[s]));
+        }
+      } else
+#pragma unroll
+      for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);
+          const unsigned lft[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
+          const unsigned rgt[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const unsigned plo = __builtin_amdgcn_perm(rgt[t], lft[t], 0x05040100u);   // (left.ch 2t  , right.ch 2t  )
+            const unsigned phi = __builtin_amdgcn_perm(rgt[t], lft[t], 0x07060302u);   // (left.ch 2t+1, right.ch 2t+1)
+            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, plo), wv, acc[2 * t], false);
+            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, phi), wv, acc[2 * t + 1], false);
+          }
+        }
+    }
+  } else {
   // ---- pass 2: batches of NB samples, 4*NB gathers in flight (see msda_fused_kernel)
 #pragma unroll 1
   for (int it = 0; it < LP / NB; ++it) {
@@ -457,6 +548,7 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
 #pragma unroll
       for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s][k], cw[s][k]);
   }
+  }
   if (live) store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
@@ -479,6 +571,7 @@ static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r
   return 0;
 }
 
+static int g_gsamp_quad = 1;       // tuning knob "gsamp_quad": VALU-lean pass 2 of the G-sampling kernel (quad DPP + dot2)
 static int g_fused_headx = 1;      // tuning knob "fused_headx": head-per-XCD mapping of the pair-layout kernel
 
 static int launch_msda_fused_pairs(const bf16_t* vp, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
@@ -698,8 +791,17 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   const int grid = 8 * (int)((pairs + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
 #define MVG_GS(LL)                                                                                                \
-  hipLaunchKernelGGL((msda_gsamp_kernel<LL>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp, (const bf16_t*)G, xw, \
-                     ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B)
+  do {                                                                                                            \
+    if (g_gsamp_quad == 2)                                                                                        \
+      hipLaunchKernelGGL((msda_gsamp_kernel<LL, true, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp,   \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B);                 \
+    else if (g_gsamp_quad)                                                                                        \
+      hipLaunchKernelGGL((msda_gsamp_kernel<LL, true, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp,    \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B);                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL((msda_gsamp_kernel<LL, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp,         \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B);                 \
+  } while (0)
   switch (L) {
     case 1: MVG_GS(1); break;
     case 2: MVG_GS(2); break;
@@ -719,6 +821,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
+  if (!strcmp(key, "gsamp_quad") && value >= 0 && value <= 2) { g_gsamp_quad = value; return 0; }   // 2: quad + fp32 blend
   if (!strcmp(key, "fused_headx") && (value == 0 || value == 1)) { g_fused_headx = value; return 0; }
   return MVG_E_BADARG;
 }
