@@ -55,7 +55,7 @@ extern "C" {
 int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
 const char* mvg_version(void);
 /* Kernel-variant knobs for A/B measurements (host-only, process-wide; env MVG_TUNE="k=v,..").  Keys:
- *   "fused_cpl_bf16" = 4 | 8, "fused_nb" = 4 | 8, "fused_headx" = 0 | 1 : fused sampling kernel variants;
+ *   "fused_cpl_bf16" = 4 | 8, "fused_nb" = 4 | 8 : generic fused sampling kernel variants;
  *   "chain_rm" = 64 | 128, "chain_a_waves" / "chain_waves" = 4 | 8     : fused Linear-chain geometry. */
 int mvg_set_tuning(const char* key, int value);
 
@@ -119,35 +119,19 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,
                    int N_img, int Lq, int L, int S, void* stream);
 
-/* bf16 fast path of the two calls above with the "pixel-pair" value layout
- *   vp[img][head 8][1+s][ch8 4][col 2][8 ch]  (bf16; (s,col0) = value(s), (s,col1) = value(s+1))
- * in which the two horizontal bilinear corners of a sample are one aligned 128-byte line per head:
- * mvg_value_proj_pairs = rayconv Linear (projattn.py:169) writing vp directly (vp must be zero-filled
- * once by the caller: (n_img*8*(S+1)*64) bf16); mvg_msda_fused_pairs = mvg_msda_fused reading it. */
-int mvg_value_proj_pairs(const void* feat, int a_dtype, const void* W, int w_dtype, const float* bias,
-                         void* vp, int n_img, int S, int K, void* stream);
-int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl,
-                         const int64_t* shapes_host, const int64_t* starts_host, void* samp,
-                         int N_img, int Lq, int L, int S, void* stream);
-
-/* Weight-stationary forms (persistent workgroups, the weight lives in registers; csrc/wreg_gemm.hip):
- * mvg_value_proj_pairs_ws = mvg_value_proj_pairs for bf16 feat, Wf in the fragment order of
- * mvgformer_amd.ops.swizzle_weight; mvg_oa_gather_gemm = mvg_gather_ref + the offsets/logits Linear in one
- * kernel: oa (V*B*Lq*L, N) f32 = bilinear(feat, ref_lvl) @ W^T + xw[(b,q)], where
- * xw (B*Lq, N) f32 = (tgt+query_pos) @ W^T + bias is computed once per layer (N = 192, weight zero-padded
- * to 256 rows before swizzling). */
+/* ---- bf16 fast path of the ProjAttn front end (replaces mvg_gather_ref + 2 x mvg_linear + mvg_msda_fused) ----
+ * Bilinear sampling commutes with a Linear: Linear(bilinear(feat,p) + x) = bilinear(feat@W^T, p) + (x@W^T + b).
+ *   mvg_value_proj_pairs_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written in the
+ *       "pixel-pair" layout vp[img][head 8][1+s][ch 32][2] (word = (value(s)[ch], value(s+1)[ch]); line 0 =
+ *       (0, value(0)); bf16, n_img*8*(S+1)*64 elements): the two horizontal corners of a sample are one 128-B line.
+ *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: [offsets|logits]).
+ *   mvg_msda_gsamp          : per (image, query, head): gathers its 24 logits + 48 offsets from G at the reference
+ *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b, softmax, locations, samples vp -> samp
+ *       (N_img*Lq, 256) bf16.  M=8, D=32, P=8, L<=4.
+ * Weights Wf: bf16, zero-padded to 256 rows, MFMA-fragment order [wn 4][ks 16][j 2][lane 64][8]
+ * (mvgformer_amd.ops.swizzle_weight); the kernels keep them in registers (weight-stationary, csrc/wreg_gemm.hip). */
 int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
                             void* stream);
-int mvg_oa_gather_gemm(const void* feat, const float* ref_lvl, const float* xw, const void* Wf,
-                       const int64_t* shapes_host, const int64_t* starts_host, float* oa,
-                       int V, int B, int Lq, int L, int S, int N, void* stream);
-
-/* "G-sampling" front end (bf16): bilinear sampling commutes with the offsets/logits Linear, so
- * G (V*B*S, 192) bf16 = feat @ [Woff;Wattn]^T is computed once per layer on the pyramid (mvg_feat_linear_ws,
- * weight zero-padded to 256 rows, fragment order) and mvg_msda_gsamp gathers each head's logits/offsets from G
- * at the reference point (+ xw (B*Lq,192) f32 = query term + bias) before sampling vp -- no (rows x 192)
- * offsets/logits tensor and no per-(view,query,level) GEMM.  Same result as mvg_oa_gather_gemm +
- * mvg_msda_fused_pairs up to bf16 rounding of G. */
 int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
 int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl,
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,

@@ -60,21 +60,12 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
   *reinterpret_cast<f32x4*>(lds + row * PITCH + col16 * 16) = v;
 }
 
-// Output placement of the epilogue.
-//   ROWMAJOR : out[row*ldc + col]
-//   PAIRS    : the sampling kernel's bf16 "pixel-pair" value layout (N = 256 = 8 heads x 32 ch,
-//              rows = pixels of S-pixel images):  vp[img][head][1+s][ch8][col][8]  with
-//              (s, col 0) = value(s) and (s, col 1) = value(s+1), so the two horizontal bilinear
-//              corners of any sample are ONE aligned 128-byte line per head.  Every pixel is
-//              therefore written twice (as the left corner of pair s and the right corner of s-1).
-enum { OUT_ROWMAJOR = 0, OUT_PAIRS = 1 };
-
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
-template <typename TA, bool BF16, typename TO, int MODE>
+template <typename TA, bool BF16, typename TO>
 __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, long lda, const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
-                                                     int K, int S_img) {
+                                                     int K) {
   using TW = typename std::conditional<BF16, bf16_t, float>::type;
   const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
@@ -195,16 +186,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
       const int row = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
       const int col = n0 + vcol * CPV;
       if (row < M && col < N) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + srow * EP + vcol * 16);
-        if constexpr (MODE == OUT_ROWMAJOR) {
-          *reinterpret_cast<f32x4*>(out + (long)row * ldc + col) = v;
-        } else {
-          const int img = row / S_img, s = row - img * S_img;
-          const int head = col >> 5, ch8 = (col & 31) >> 3;
-          TO* base = out + (((long)img * 8 + head) * (S_img + 1) + s) * 64 + ch8 * 16;
-          *reinterpret_cast<f32x4*>(base + 64) = v;      // pair 1+s, left corner  (col 0)
-          *reinterpret_cast<f32x4*>(base + 8) = v;       // pair s,   right corner (col 1)
-        }
+        *reinterpret_cast<f32x4*>(out + (long)row * ldc + col) =
+            *reinterpret_cast<const f32x4*>(lds + srow * EP + vcol * 16);
       }
     }
     __syncthreads();
@@ -213,28 +196,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
 
 template <typename TA, bool BF16, typename TO>
 int launch_linear(const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
-                  const uint8_t* rowmask, int relu, int M, int N, int K, int mode, int S_img, hipStream_t st) {
+                  const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-  if (mode == OUT_PAIRS) {
-    if constexpr (sizeof(TO) == 2) {
-      hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, OUT_PAIRS>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias,
-                         (TO*)out, ldc, rowmask, relu, M, N, K, S_img);
-    } else {
-      return MVG_E_BADARG;
-    }
-  } else {
-    hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, OUT_ROWMAJOR>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias,
-                       (TO*)out, ldc, rowmask, relu, M, N, K, S_img);
-  }
+  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias, (TO*)out, ldc,
+                     rowmask, relu, M, N, K);
   MVG_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
 
-static int linear_dispatch(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias,
-                           void* out, int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K,
-                           int mode, int S_img, void* stream) {
+extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
+                          int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {
   if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return MVG_E_BADARG;
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -244,35 +217,19 @@ static int linear_dispatch(const void* A, int a_dtype, int lda, const void* W, i
   const int a_el = (a_dtype == MVG_BF16) ? 2 : 4, o_el = (out_dtype == MVG_BF16) ? 2 : 4;
   if (((long)lda * a_el) % 16 != 0 || (reinterpret_cast<uintptr_t>(A) % 16) != 0 || (reinterpret_cast<uintptr_t>(W) % 16) != 0)
     return MVG_E_BADARG;
-  if (mode == OUT_ROWMAJOR && ((((long)ldc * o_el) % 16) != 0 || (reinterpret_cast<uintptr_t>(out) % 16) != 0)) return MVG_E_BADARG;
-  if (mode == OUT_PAIRS && (N != 256 || out_dtype != MVG_BF16 || S_img <= 0 || M % S_img != 0)) return MVG_E_BADARG;
+  if ((((long)ldc * o_el) % 16) != 0 || (reinterpret_cast<uintptr_t>(out) % 16) != 0) return MVG_E_BADARG;
   if (!bf) {
     if (a_dtype != MVG_F32) return MVG_E_BADARG;   // fp32 MFMA path takes fp32 activations
-    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
-    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
+    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
     return MVG_E_BADARG;
   }
   if (a_dtype == MVG_BF16) {
-    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
-    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
+    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
   } else if (a_dtype == MVG_F32) {
-    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
-    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, mode, S_img, st);
+    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
   }
   return MVG_E_BADARG;
-}
-
-extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
-                          int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {
-  return linear_dispatch(A, a_dtype, lda, W, w_dtype, bias, out, out_dtype, ldc, rowmask, relu, M, N, K, OUT_ROWMAJOR, 0,
-                         stream);
-}
-
-// value projection straight into the sampling kernel's bf16 pixel-pair layout (see OUT_PAIRS):
-// feat (n_img*S, K) @ W (256, K)^T + bias -> vp (n_img, 8, S+1, 4, 2, 8) bf16.  The caller provides vp
-// zero-initialised once (the right-corner slot of the last pixel of each head plane is never written).
-extern "C" int mvg_value_proj_pairs(const void* feat, int a_dtype, const void* W, int w_dtype, const float* bias,
-                                    void* vp, int n_img, int S, int K, void* stream) {
-  return linear_dispatch(feat, a_dtype, K, W, w_dtype, bias, vp, MVG_BF16, 0, nullptr, 0, n_img * S, 256, K, OUT_PAIRS, S,
-                         stream);
 }

@@ -13,6 +13,8 @@
 //   * workgroup -> (image, query) mapping is XCD-aware: the 8 XCDs of the chip each walk a
 //     contiguous range of query blocks, so queries that project next to each other (the
 //     15 joints of a person, neighbouring persons of the query grid) share one XCD's L2.
+// msda_fwd_kernel = the drop-in for Deformable.deform_forward; msda_fused_kernel = generic fused form
+// (fp32 / bf16, pixel-major value); msda_gsamp_kernel = the benchmarked bf16 kernel (see its header).
 #include <string.h>
 
 #include "common.h"
@@ -194,12 +196,7 @@ __device__ __forceinline__ void store_acc(T* p, const float (&acc)[CPL]) {
   }
 }
 
-// HEADX: head-per-XCD work mapping.  Block b works on head (b & 7) -- with the round-robin dispatch
-// of gfx950 (block b -> XCD b % 8) every XCD then touches only ONE head plane of `value`
-// (2.6-5.2 MB per view instead of all 8 heads = 21-41 MB), which its 4-MB L2 can actually hold,
-// so gathers that miss the 32-KB L1 hit in L2 instead of going out to the Infinity Cache / HBM.
-// A wavefront is then 16 (image,query) pairs x 1 head x 4 lanes (CPL = 8).
-template <typename T, int L, int CPL, int NB, bool PAIRS = false, bool HEADX = false>
+template <typename T, int L, int CPL, int NB>
 __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) void msda_fused_kernel(const T* __restrict__ value, const float* __restrict__ oa,
                                                          const float* __restrict__ r, LevelTable lv,
                                                          T* __restrict__ samp, int n_pairs, int Lq, int S) {
@@ -214,17 +211,8 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
   const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
   const int lblock = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int pair, m, sub;
-  if constexpr (HEADX) {
-    static_assert(!HEADX || CPL == 8, "head-per-XCD mapping is written for 4 lanes per head");
-    m = blockIdx.x & 7;
-    pair = (blockIdx.x >> 3) * 64 + wave * 16 + (lane >> 2);
-    sub = lane & 3;
-  } else {
-    pair = (lblock * 4 + wave) * PPW + lane / (8 * LPH);
-    m = (lane / LPH) & 7;
-    sub = lane % LPH;
-  }
+  int pair = (lblock * 4 + wave) * PPW + lane / (8 * LPH);
+  const int m = (lane / LPH) & 7, sub = lane % LPH;
   const bool live = pair < n_pairs;
   if (!live) pair = n_pairs - 1;                       // keep the wavefront converged; store is masked
   const int n = pair / Lq;
@@ -249,11 +237,7 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
     mx += __logf(sum);
   }
 
-  // PAIRS: value is the bf16 pixel-pair layout vp[img][head][1+s][ch8][col][8] written by
-  // mvg_value_proj_pairs: both horizontal corners of a sample are one aligned 128-B line per head
-  // (half the L2 requests of the pixel-major layout, where each corner is its own 64-B segment).
-  const T* vbase = PAIRS ? value + ((long)n * 8 + m) * (S + 1) * 64 + sub * 16
-                         : value + (long)n * S * C + m * D + sub * CPL;
+  const T* vbase = value + (long)n * S * C + m * D + sub * CPL;
   float acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
@@ -268,7 +252,7 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
     const float Wf = (float)W, Hf = (float)H;
     const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
     const float invW = 1.f / Wf, invH = 1.f / Hf;
-    const T* lvl = PAIRS ? vbase + (long)(1 + lv.start[l]) * 64 : vbase + (long)lv.start[l] * C;
+    const T* lvl = vbase + (long)lv.start[l] * C;
     const int fa = m * LP + it * NB;
     f32x4 lg[NB / 4];
 #pragma unroll
@@ -300,18 +284,10 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
       cw[s][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
       const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
       const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
-      if constexpr (PAIRS) {
-        const int wp = min(max(w_low, -1), W - 1);                   // pair index: left corner column
-        raw[s][0] = RV::load(lvl + (hl_c * W + wp) * 64);
-        raw[s][1] = RV::load(lvl + (hl_c * W + wp) * 64 + 8);
-        raw[s][2] = RV::load(lvl + (hh_c * W + wp) * 64);
-        raw[s][3] = RV::load(lvl + (hh_c * W + wp) * 64 + 8);
-      } else {
-        raw[s][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
-        raw[s][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
-        raw[s][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
-        raw[s][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
-      }
+      raw[s][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
+      raw[s][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
+      raw[s][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
+      raw[s][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
     }
     __builtin_amdgcn_sched_barrier(0);   // all 4*NB loads are issued before the first blend
 #pragma unroll
@@ -323,14 +299,30 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 }
 
 // ------------------------------------------------------------------------------------------
-// "G-sampling" form of the fused kernel (bf16, pixel-pair value layout, head-per-XCD mapping).
-// Bilinear sampling commutes with a Linear:  Linear(bilinear(feat, p) + x) = bilinear(feat @ W^T, p) + (x @ W^T + b).
-// So instead of gathering 256-channel reference-point features and running a (V*Lq*L x 256 x 192) GEMM per
-// layer (projattn.py:148-153,180-181), the offsets/logits Linear is applied ONCE to the pyramid
-// (G = feat @ Woa^T, a (V*S x 192) GEMM that does not depend on the queries) and every (pair, head) here
-// gathers its own 24 logits + 48 offsets from G at the reference point -- 9 chunks of 8 columns, split over the
-// 4 lanes of the head, parked in LDS -- then proceeds exactly as msda_fused_kernel.  The per-layer
-// (rows x 192) fp32 offsets/logits tensor (177 MB written + read) and its gather-GEMM kernel disappear.
+// msda_gsamp_kernel -- the bf16 sampling kernel of the decoder (the kernel bench.py's roofline reports).
+//
+// (1) G-sampling.  Bilinear sampling commutes with a Linear:
+//        Linear(bilinear(feat, p) + x) = bilinear(feat @ W^T, p) + (x @ W^T + b).
+//     Instead of gathering 256-channel reference-point features and running a (V*Lq*L x 256 x 192) GEMM per
+//     layer (projattn.py:148-153,180-181), the offsets/logits Linear is applied ONCE to the pyramid
+//     (G = feat @ Woa^T, a (V*S x 192) GEMM independent of the queries) and every (pair, head) gathers its own
+//     24 logits + 48 offsets from G at the reference point (9 chunks of 8 columns, split over the 4 lanes of
+//     the head, parked in LDS) and adds xw = (tgt+query_pos) @ Woa^T + b.  No (rows x 192) fp32 tensor
+//     (177 MB written + read per layer) and no per-(view, query, level) GEMM exist any more.
+// (2) Pixel-pair value layout (written by wreg_gemm.hip):  vp[img][head][1+s][ch 32][2] with the 32-bit word
+//     (value(s)[ch], value(s+1)[ch]): the two horizontal corners of a sample are ONE aligned 128-byte line per
+//     head (half the gather requests of a pixel-major layout: PMC 45 M -> 23 M L1->L2 requests per launch) and
+//     every word is directly an operand of v_dot2c_f32_bf16 with the packed weights (w_left, w_right).
+// (3) Head-per-XCD mapping: block b works on head (b & 7); with gfx950's round-robin dispatch (block b -> XCD
+//     b % 8) each XCD touches one head plane of vp (5 MB per view) instead of all eight, so L1 misses hit in its
+//     4-MB L2 (fabric reads 10.3 M -> 4.5 M requests per launch).  A wavefront = 16 pairs x 1 head x 4 lanes,
+//     each lane owning 8 channels.
+// (4) VALU-lean inner loop (the previous form was VALU-bound: PMC 73 % VALU-busy, 3180 VALU instructions per
+//     wavefront): each lane of a head's quad computes ONE of the 4 samples of a batch (coordinates, zero
+//     padding, softmax weight, row offsets) and broadcasts 4 words with DPP quad_perm; the 16 gathers of the batch
+//     are issued back to back (sched_barrier: hipcc otherwise sinks them to their uses); the blend is 64
+//     v_dot2c_f32_bf16 per batch, fp32 accumulation, no bf16->fp32 unpacking.  (The bilinear x attention
+//     weights are rounded to bf16; products and sums are fp32.)
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
@@ -341,20 +333,12 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xf, 0xf, false);
 }
 
-// QUAD = the VALU-lean pass 2 (the kernel is VALU-bound: PMC 73 % VALU-busy, 3180 VALU instructions per wavefront,
-// half of them coordinate/address math that the 4 lanes of a head repeated, a third bf16->fp32 unpacking):
-//   * each lane of the head's quad computes ONE of the 4 samples of a batch (coordinates, zero-padding, softmax
-//     weight, row offsets) and broadcasts 4 words (2 packed bf16 weight pairs, 2 row offsets) with DPP quad_perm;
-//   * the blend runs on v_dot2c_f32_bf16: one v_perm_b32 pairs the same channel of the left / right corner, the
-//     dot2 multiplies by the packed (w_left, w_right) and accumulates in fp32 -- no unpacking to fp32 at all.
-//     (the bilinear x attention weights are rounded to bf16 here; products and sums are fp32.)
-template <int L, bool QUAD, bool DOT2 = true>
+template <int L>
 __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                             const float* __restrict__ xw, const float* __restrict__ r,
                                                             LevelTable lv, bf16_t* __restrict__ samp, int n_pairs,
                                                             int Lq, int S, int B) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 4;   // SCP: padded scratch row (76 for L=3)
-  typedef RawVec<bf16_t, 8> RV;
   __shared__ __attribute__((aligned(16))) float scratch[4][16][SCP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = blockIdx.x & 7, sub = lane & 3, pl = lane >> 2;
@@ -427,13 +411,12 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
     mx += __logf(sum);
   }
 
-  const bf16_t* vbase = vp + ((long)n * 8 + m) * (S + 1) * 64 + sub * 16;
   float acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 
-  if constexpr (QUAD) {
-    // byte offset of this lane's 16-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
+  {
+    // byte offset of this lane's 32-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
     const unsigned lane_off = (unsigned)((((long)n * 8 + m) * (S + 1)) * 128 + sub * 32);
     const char* vp_bytes = reinterpret_cast<const char*>(vp);
 #pragma unroll 1
@@ -455,22 +438,19 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
       const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
       const float c0 = (hl_ok && wl_ok) ? hh * hw * a : 0.f, c1 = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
       const float c2 = (hh_ok && wl_ok) ? lh * hw * a : 0.f, c3 = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
-      const unsigned my_wt = DOT2 ? pack_bf16x2(c0, c1) : __float_as_uint(c0);
-      const unsigned my_wb = DOT2 ? pack_bf16x2(c2, c3) : __float_as_uint(c2);
-      const unsigned my_w1 = __float_as_uint(c1), my_w3 = __float_as_uint(c3);
+      const unsigned my_wt = pack_bf16x2(c0, c1), my_wb = pack_bf16x2(c2, c3);
       const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
       const int wp = min(max(w_low, -1), W - 1);
       const unsigned lvl_pairs = (unsigned)(1 + lv.start[l]);
       const unsigned my_ot = (lvl_pairs + (unsigned)(hl_c * W + wp)) * 128u;           // byte offset of the top pair line
       const unsigned my_ob = (lvl_pairs + (unsigned)(hh_c * W + wp)) * 128u;
       // ---- quad broadcast + 16 gathers in flight
-      unsigned wt[NB], wb[NB], w1[NB], w3[NB];
+      unsigned wt[NB], wb[NB];
       uint4 raw[NB][4];
 #define MVG_QS(SS)                                                                                      \
       {                                                                                                 \
         wt[SS] = quad_bcast<SS>(my_wt);                                                                 \
         wb[SS] = quad_bcast<SS>(my_wb);                                                                 \
-        if (!DOT2) { w1[SS] = quad_bcast<SS>(my_w1); w3[SS] = quad_bcast<SS>(my_w3); }                  \
         const unsigned ot = quad_bcast<SS>(my_ot) + lane_off, ob = quad_bcast<SS>(my_ob) + lane_off;    \
         raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
         raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + ot + 16);                               \
@@ -480,74 +460,21 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
       MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
 #undef MVG_QS
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!DOT2) {
-#pragma unroll
-        for (int s = 0; s < NB; ++s) {
-          RawVec<bf16_t, 8>::fma(acc, raw[s][0], __uint_as_float(wt[s]));
-          RawVec<bf16_t, 8>::fma(acc, raw[s][1], __uint_as_float(w1[s]));
-          RawVec<bf16_t, 8>::fma(acc, raw[s][2], __uint_as_float(wb[s]));
-          RawVec<bf16_t, 8>::fma(acc, raw[s][3], __uint_as_float(w3[s]));
-        }
-      } else
 #pragma unroll
       for (int s = 0; s < NB; ++s)
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
+          // every 32-bit word of a pair line is (value(s)[ch], value(s+1)[ch]) = the dot2 operand as stored
           const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);
-          const unsigned lft[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
-          const unsigned rgt[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
+          const unsigned c03[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
+          const unsigned c47[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const unsigned plo = __builtin_amdgcn_perm(rgt[t], lft[t], 0x05040100u);   // (left.ch 2t  , right.ch 2t  )
-            const unsigned phi = __builtin_amdgcn_perm(rgt[t], lft[t], 0x07060302u);   // (left.ch 2t+1, right.ch 2t+1)
-            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, plo), wv, acc[2 * t], false);
-            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, phi), wv, acc[2 * t + 1], false);
+            acc[t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, c03[t]), wv, acc[t], false);
+            acc[4 + t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, c47[t]), wv, acc[4 + t], false);
           }
         }
     }
-  } else {
-  // ---- pass 2: batches of NB samples, 4*NB gathers in flight (see msda_fused_kernel)
-#pragma unroll 1
-  for (int it = 0; it < LP / NB; ++it) {
-    const int l = (it * NB) / P;
-    const int H = lv.H[l], W = lv.W[l];
-    const float Wf = (float)W, Hf = (float)H;
-    const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
-    const float invW = 1.f / Wf, invH = 1.f / Hf;
-    const bf16_t* lvl = vbase + (long)(1 + lv.start[l]) * 64;
-    const f32x4 lg = *reinterpret_cast<const f32x4*>(sc + it * NB);
-    const f32x4 oA = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2);
-    const f32x4 oB = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2 + 4);
-    float cw[NB][4];
-    typename RV::type raw[NB][4];
-#pragma unroll
-    for (int s = 0; s < NB; ++s) {
-      const float ox = (s < 2) ? oA[2 * s] : oB[2 * (s - 2)], oy = (s < 2) ? oA[2 * s + 1] : oB[2 * (s - 2) + 1];
-      const float lx = refx + ox * invW, ly = refy + oy * invH;       // projattn.py:186-191
-      const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;       // cuh:295-296
-      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
-      const int h_low = (int)hl_f, w_low = (int)wl_f;
-      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
-      const float a = inside ? __expf(lg[s] - mx) : 0.f;
-      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-      cw[s][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;
-      cw[s][1] = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
-      cw[s][2] = (hh_ok && wl_ok) ? lh * hw * a : 0.f;
-      cw[s][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
-      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-      const int wp = min(max(w_low, -1), W - 1);
-      raw[s][0] = RV::load(lvl + (hl_c * W + wp) * 64);
-      raw[s][1] = RV::load(lvl + (hl_c * W + wp) * 64 + 8);
-      raw[s][2] = RV::load(lvl + (hh_c * W + wp) * 64);
-      raw[s][3] = RV::load(lvl + (hh_c * W + wp) * 64 + 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < NB; ++s)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s][k], cw[s][k]);
-  }
   }
   if (live) store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
@@ -565,36 +492,6 @@ static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r
     case 2: hipLaunchKernelGGL((msda_fused_kernel<T, 2, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
     case 3: hipLaunchKernelGGL((msda_fused_kernel<T, 3, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
     case 4: hipLaunchKernelGGL((msda_fused_kernel<T, 4, CPL, NB>), dim3(grid), dim3(256), 0, st, value, oa, r, lv, samp, n_pairs, Lq, S); break;
-    default: return MVG_E_BADARG;
-  }
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
-
-static int g_gsamp_quad = 1;       // tuning knob "gsamp_quad": VALU-lean pass 2 of the G-sampling kernel (quad DPP + dot2)
-static int g_fused_headx = 1;      // tuning knob "fused_headx": head-per-XCD mapping of the pair-layout kernel
-
-static int launch_msda_fused_pairs(const bf16_t* vp, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
-                                   int n_pairs, int Lq, int S, hipStream_t st) {
-  if (n_pairs <= 0) return 0;
-  if (g_fused_headx) {
-    const int gridx = 8 * ((n_pairs + 63) / 64);
-    switch (lv.L) {
-      case 1: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 1, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-      case 2: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 2, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-      case 3: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 3, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-      case 4: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 4, 8, 4, true, true>), dim3(gridx), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-      default: return MVG_E_BADARG;
-    }
-    MVG_LAUNCH_CHECK();
-    return 0;
-  }
-  const int grid = (n_pairs + 7) / 8;
-  switch (lv.L) {
-    case 1: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 1, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 2: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 2, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 3: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 3, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
-    case 4: hipLaunchKernelGGL((msda_fused_kernel<bf16_t, 4, 8, 4, true>), dim3(grid), dim3(256), 0, st, vp, oa, r, lv, samp, n_pairs, Lq, S); break;
     default: return MVG_E_BADARG;
   }
   MVG_LAUNCH_CHECK();
@@ -763,22 +660,6 @@ int mvg_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
   return 0;
 }
 
-int mvg_msda_fused_pairs(const void* vp, const float* oa, const float* ref_lvl, const int64_t* shapes_host,
-                         const int64_t* starts_host, void* samp, int N_img, int Lq, int L, int S, void* stream) {
-  if (!vp || !oa || !ref_lvl || !shapes_host || !starts_host || !samp) return MVG_E_BADARG;
-  LevelTable lv;
-  int e = mvg_fill_levels(&lv, shapes_host, starts_host, L);
-  if (e) return e;
-  if (L > 4) return MVG_E_BADARG;
-  const long pairs = (long)N_img * Lq;
-  if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
-  return launch_msda_fused_pairs((const bf16_t*)vp, oa, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, (hipStream_t)stream);
-}
-
-extern int g_chain_rm;
-extern int g_chain_waves;
-extern int g_chain_a_waves;
-
 int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl, const int64_t* shapes_host,
                    const int64_t* starts_host, void* samp, int N_img, int Lq, int L, int S, int B, void* stream) {
   if (!vp || !G || !xw || !ref_lvl || !shapes_host || !starts_host || !samp || B <= 0) return MVG_E_BADARG;
@@ -791,17 +672,8 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   const int grid = 8 * (int)((pairs + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
 #define MVG_GS(LL)                                                                                                \
-  do {                                                                                                            \
-    if (g_gsamp_quad == 2)                                                                                        \
-      hipLaunchKernelGGL((msda_gsamp_kernel<LL, true, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp,   \
-                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B);                 \
-    else if (g_gsamp_quad)                                                                                        \
-      hipLaunchKernelGGL((msda_gsamp_kernel<LL, true, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp,    \
-                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B);                 \
-    else                                                                                                          \
-      hipLaunchKernelGGL((msda_gsamp_kernel<LL, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp,         \
-                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B);                 \
-  } while (0)
+  hipLaunchKernelGGL((msda_gsamp_kernel<LL>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp, (const bf16_t*)G, xw, \
+                     ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B)
   switch (L) {
     case 1: MVG_GS(1); break;
     case 2: MVG_GS(2); break;
@@ -814,6 +686,10 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   return 0;
 }
 
+extern int g_chain_rm;
+extern int g_chain_waves;
+extern int g_chain_a_waves;
+
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;
   if (!strcmp(key, "chain_a_waves") && (value == 4 || value == 8)) { g_chain_a_waves = value; return 0; }
@@ -821,8 +697,6 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
-  if (!strcmp(key, "gsamp_quad") && value >= 0 && value <= 2) { g_gsamp_quad = value; return 0; }   // 2: quad + fp32 blend
-  if (!strcmp(key, "fused_headx") && (value == 0 || value == 1)) { g_fused_headx = value; return 0; }
   return MVG_E_BADARG;
 }
 

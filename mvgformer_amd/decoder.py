@@ -459,7 +459,7 @@ class DQDecoder(MvPDecoder):
         pa0 = layer0.proj_attn
         distinct = len({id(l.proj_attn) for l in self.layers}) == len(self.layers)   # share_layer_weights -> one buffer
         if (self.overlap_value_projection and distinct and layer0.compute_dtype == torch.bfloat16
-                and pa0.use_pair_layout and not torch.is_grad_enabled()):
+                and pa0.use_fast_path and not torch.is_grad_enabled()):
             main = torch.cuda.current_stream()
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream()

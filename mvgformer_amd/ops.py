@@ -179,16 +179,6 @@ def msda_fused(value, oa, r, levels):
     return samp
 
 
-def value_proj_pairs(feat, w, bias, vp):
-    """rayconv Linear of the packed pyramid feat (n_img,S,K) written straight into the bf16 pixel-pair
-    layout vp (n_img, 8, S+1, 64) (zero-initialised once by the caller)."""
-    n_img, S, K = feat.shape
-    with _timed("linear_%dx%dx%d" % (n_img * S, 256, K)):
-      L.check(L.load().mvg_value_proj_pairs(L.ptr(feat), L.dtype_code(feat.dtype), L.ptr(w), L.dtype_code(w.dtype),
-                                            L.ptr(bias), L.ptr(vp), n_img, S, K, L.stream_ptr()), "mvg_value_proj_pairs")
-    return vp
-
-
 def value_proj_pairs_ws(feat, w_frag, bias, vp):
     """weight-stationary value projection (bf16 feat, swizzled weight) into the pixel-pair layout."""
     n_img, S, K = feat.shape
@@ -196,17 +186,6 @@ def value_proj_pairs_ws(feat, w_frag, bias, vp):
       L.check(L.load().mvg_value_proj_pairs_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(bias), L.ptr(vp), n_img, S, L.stream_ptr()),
               "mvg_value_proj_pairs_ws")
     return vp
-
-
-def oa_gather_gemm(feat, r, xw, w_frag, levels, V, B, N=192):
-    """fused ref-point bilinear gather + offsets/logits Linear; r (n_img,Lq,L,2), xw (B*Lq,N) f32."""
-    n_img, S, _ = feat.shape
-    Lq = r.shape[1]
-    oa = torch.empty((n_img * Lq * levels.L, N), dtype=torch.float32, device=feat.device)
-    with _timed("oa_gather_gemm"):
-      L.check(L.load().mvg_oa_gather_gemm(L.ptr(feat), L.ptr(r), L.ptr(xw), L.ptr(w_frag), levels.shapes_c, levels.starts_c,
-                                          L.ptr(oa), V, B, Lq, levels.L, S, N, L.stream_ptr()), "mvg_oa_gather_gemm")
-    return oa
 
 
 def feat_linear_ws(feat, w_frag, N=192):
@@ -227,16 +206,6 @@ def msda_gsamp(vp, G, xw, r, levels, B):
     with _timed("msda_fused"):
       L.check(L.load().mvg_msda_gsamp(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
                                       L.ptr(samp), n_img, Lq, levels.L, levels.S, B, L.stream_ptr()), "mvg_msda_gsamp")
-    return samp
-
-
-def msda_fused_pairs(vp, oa, r, levels):
-    n_img = vp.shape[0]
-    Lq = r.shape[1]
-    samp = torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
-    with _timed("msda_fused"):
-      L.check(L.load().mvg_msda_fused_pairs(L.ptr(vp), L.ptr(oa), L.ptr(r), levels.shapes_c, levels.starts_c, L.ptr(samp),
-                                            n_img, Lq, levels.L, levels.S, L.stream_ptr()), "mvg_msda_fused_pairs")
     return samp
 
 
@@ -279,12 +248,6 @@ def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be
           L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out), L.ptr(prob),
           L.ptr(valid), L.ptr(any_valid), B, NQ, J, 1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class")
     return tgt_out, prob, valid, any_valid
-
-
-def swizzle_weight_k(w):
-    """(256, K) weight with K = n*256 consumed in K-chunks of 256 (FFN linear2): fragment order
-    Wf[wn 4][ks K/16][j 2][lane 64][8] -- chunk c starts at ks = 16*c, wave stride (K/16)*1024."""
-    return swizzle_weight(w)
 
 
 def mean_views(attn, V):

@@ -73,9 +73,9 @@ class ProjAttn(nn.Module):
         self._reset_parameters()
         self.projattn_posembed_mode = projattn_posembed_mode
         self.compute_dtype = torch.float32
-        self.use_pair_layout = True     # bf16 inference: pixel-pair value layout (half the L2 gather requests)
-        self.use_weight_stationary = True   # bf16 inference: persistent weight-in-register GEMMs (csrc/wreg_gemm.hip)
-        self.use_g_sampling = True          # bf16 inference: offsets/logits Linear applied to the pyramid, gathered in the sampler
+        # bf16 inference: weight-stationary pyramid GEMMs + pixel-pair value layout + G-sampling kernel
+        # (False: the generic gather -> linear -> fused-sampling kernels, also the fp32 path)
+        self.use_fast_path = True
         self._wc = WeightCache()
         self._vp = None
         self._vp_event = None
@@ -114,11 +114,10 @@ class ProjAttn(nn.Module):
                 wc.get("bp", (self.output_proj.bias,), torch.float32))
 
     def _pair_buffer(self, n_img, S, device):
-        """zero-initialised ONCE (the never-written right-corner slot of each plane's last pixel must
-        stay finite); shared by every call with the same geometry."""
+        """pixel-pair value buffer (every line is fully rewritten by each projection); kept across calls."""
         shape = (n_img, 8, S + 1, 64)
         if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
-            self._vp = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+            self._vp = torch.empty(shape, dtype=torch.bfloat16, device=device)
         return self._vp
 
     def _wait_values(self):
@@ -129,17 +128,14 @@ class ProjAttn(nn.Module):
 
     def project_values(self, feat, record_event=False):
         """value = rayconv(input_flatten) (projattn.py:169) in the bf16 pixel-pair layout.  The projection
-        does not depend on the queries, so DQDecoder runs it for every layer on a side stream, overlapped
-        with the previous layers' query-side kernels (record_event=True: the consumer waits on the event)."""
+        does not depend on the queries, so DQDecoder can run it for every layer on a side stream
+        (record_event=True: the consumer waits on the event)."""
         dt = feat.dtype
         n_img, S, _ = feat.shape
-        Wv, bv = self._wc.get("Wv", (self.rayconv.weight,), dt), self._wc.get("bv", (self.rayconv.bias,), torch.float32)
+        bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
+        Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
         vp = self._pair_buffer(n_img, S, feat.device)
-        if self.use_weight_stationary:
-            Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
-            ops.value_proj_pairs_ws(feat, Wv_f, bv, vp)                      # weight-stationary
-        else:
-            ops.value_proj_pairs(feat, Wv, bv, vp)
+        ops.value_proj_pairs_ws(feat, Wv_f, bv, vp)
         if record_event:
             self._vp_event = torch.cuda.Event()
             self._vp_event.record()
@@ -158,29 +154,20 @@ class ProjAttn(nn.Module):
         dt = feat.dtype
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
-        ws = dt == torch.bfloat16 and self.use_weight_stationary
-        if ws:
-            # (ref feats + query) @ W = ref feats @ W + [query @ W + b]: the query term is computed once per layer
+        if dt == torch.bfloat16 and self.use_fast_path and Woa.shape[0] == 192:
+            # Linear(bilinear(feat) + x) = bilinear(Linear(feat)) + Linear(x): project the pyramid once (G), compute
+            # the query term once per layer (xw), gather offsets/logits inside the sampler (csrc/msda.hip)
             pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
                                                   .to(dt))
             Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
             xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
-            if self.use_g_sampling and self.use_pair_layout and Woa.shape[0] == 192:
-                # Linear(bilinear(feat)) = bilinear(Linear(feat)): project the pyramid once, gather in the sampler
-                G = ops.feat_linear_ws(feat, Woa_f, 192)
-                vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
-                return ops.msda_gsamp(vp, G, xw, r, levels, B)                # projattn.py:148-200
-            oa = ops.oa_gather_gemm(feat, r, xw, Woa_f, levels, V, B, Woa.shape[0])   # projattn.py:148-153,180-181
-        else:
-            ain = ops.gather_ref(feat, r, x, levels, V, B)                   # projattn.py:148-153,180 (+query)
-            oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)          # projattn.py:180-181
-        if dt == torch.bfloat16 and self.use_pair_layout:
+            G = ops.feat_linear_ws(feat, Woa_f, 192)
             vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
-            samp = ops.msda_fused_pairs(vp, oa, r, levels)                   # projattn.py:184-200
-        else:
-            value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
-            samp = ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
-        return samp
+            return ops.msda_gsamp(vp, G, xw, r, levels, B)                   # projattn.py:148-200
+        ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
+        oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
+        value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
+        return ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
 
     # ------------------------------------------------------------------------------- forward
     def forward(self, query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,

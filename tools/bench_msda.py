@@ -46,22 +46,26 @@ with torch.no_grad():
         return out
 
     if dtype == torch.bfloat16:
-        vp = pa._pair_buffer(ctx.V, S, value.device)
-        ops.value_proj_pairs(ctx.feat, Wv, bv, vp)
+        vp = pa.project_values(ctx.feat)
+        xw = ops.linear(x.reshape(-1, 256), Woa, boa, out_dtype=torch.float32)
+        Woa_f = pa._wc.get("Woa_frag", (pa.sampling_offsets.weight, pa.attention_weights.weight), dtype,
+                           lambda a_, b_: ops.swizzle_weight(torch.cat([a_, b_, a_.new_zeros(64, 256)], 0).to(dtype)))
+        G = ops.feat_linear_ws(ctx.feat, Woa_f, 192)
         for _ in range(3):
-            ops.msda_fused_pairs(vp, oa, ref_lvl, ctx.levels)
+            ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1)
         torch.cuda.synchronize()
         s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s_.record()
         for _ in range(20):
-            outp = ops.msda_fused_pairs(vp, oa, ref_lvl, ctx.levels)
+            outp = ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1)
         e_.record()
         torch.cuda.synchronize()
         us = s_.elapsed_time(e_) / 20 * 1e3
-        print("%-28s %8.1f us  %7.1f GB/s algorithmic" % ("PAIRS cpl=8 nb=4", us, bytes_launch / us / 1e3))
+        print("%-28s %8.1f us  %7.1f GB/s algorithmic" % ("G-sampling (fast path)", us, bytes_launch / us / 1e3))
         lib.mvg_set_tuning(b"fused_cpl_bf16", 8); lib.mvg_set_tuning(b"fused_nb", 4)
         ref = ops.msda_fused(value, oa, ref_lvl, ctx.levels)
-        print("    pairs == pixel-major:", bool(torch.equal(outp, ref)))
+        d = (outp.float() - ref.float()).abs()
+        print("    vs generic fused kernel: max |diff| %.3e  mean %.3e  (|ref| max %.2f)" % (float(d.max()), float(d.mean()), float(ref.float().abs().max())))
     base = None
     knobs = [("fused_cpl_bf16", 8), ("fused_cpl_bf16", 4)] if dtype == torch.bfloat16 else [("fused_cpl_bf16", 8)]
     for ck, cv in knobs:
