@@ -160,9 +160,11 @@ class ProjAttn(nn.Module):
             pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
                                                   .to(dt))
             Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
+            # order: the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is
+            # the freshest resident of the 256-MB Infinity Cache when the sampler starts
+            vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
             xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
             G = ops.feat_linear_ws(feat, Woa_f, 192)
-            vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
             return ops.msda_gsamp(vp, G, xw, r, levels, B)                   # projattn.py:148-200
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
