@@ -14,7 +14,7 @@ Panoptic CMU0 geometry, 5 views, 1024 queries x 15 joints, 4 layers, feature map
 (BASELINE.json configs[2]) and the pose set is assembled with one RCCL all-gather per forward.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     : the sampling kernel (msda_fused), HIP-event timed per launch on its stream
+  roofline     : the sampling kernel (msda_gsamp / msda_fused), HIP-event timed per launch on its stream
   cpu_baseline : the CPU oracle (oracle/decoder_ref.py, "port") timed on <= 32 host threads on a
                  bounded sample (as many of the 4 layers as fit in ~30 s), scaled to samples/s
 """
@@ -175,7 +175,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed                          # samples / s (whole job: one sample per step)
 
-    # roofline of the dominant kernel: one msda_fused launch covers all V views of one layer
+    # roofline of the dominant kernel: one sampling-kernel launch covers all V views of one layer
     Lq_loc = (hi - lo) * J
     S = int(sum(h * w for h, w in case.shapes))
     bytes_launch = V * algorithmic_bytes_per_view_layer(S, 256, Lq_loc, 8, len(case.shapes), 8, elem)
@@ -187,10 +187,11 @@ def main():
     if os.path.exists(pmc_path) and args.config in ("cfg2", "cfg3") and args.dtype == "bf16" and world == 1:
         with open(pmc_path) as f:
             traffic = int(json.load(f)["traffic_bytes_per_launch"])
-    if "msda_fused" in prof:
-        n, ms = prof["msda_fused"]
+    samp_key = "msda_gsamp" if "msda_gsamp" in prof else "msda_fused"     # bf16 fast path / generic fused kernel
+    if samp_key in prof:
+        n, ms = prof[samp_key]
         ach = bytes_launch / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "msda_fused_kernel", "achieved": round(ach, 1), "peak": 8000.0,
+        roof = {"bound": "hbm", "kernel": samp_key + "_kernel", "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch}
     kern = {k: {"launches": n, "avg_us": round(ms * 1e3, 2)} for k, (n, ms) in sorted(prof.items())}

@@ -203,7 +203,7 @@ def msda_gsamp(vp, G, xw, r, levels, B):
     n_img = vp.shape[0]
     Lq = r.shape[1]
     samp = torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
-    with _timed("msda_fused"):
+    with _timed("msda_gsamp"):
       L.check(L.load().mvg_msda_gsamp(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
                                       L.ptr(samp), n_img, Lq, levels.L, levels.S, B, L.stream_ptr()), "mvg_msda_gsamp")
     return samp

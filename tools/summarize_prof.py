@@ -41,7 +41,7 @@ for k in sorted(acc, key=lambda k: -sum(acc[k].get("GRBM_GUI_ACTIVE", [0]))):
 # ---- machine-readable HBM-side traffic of the dominant kernel (read by bench.py -> roofline.traffic)
 import json
 for k in acc:
-    if k.startswith("msda_fused_kernel") and "FETCH_SIZE" in acc[k]:
+    if k.startswith("msda_gsamp_kernel") and "FETCH_SIZE" in acc[k]:
         fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
         write_kb = sum(acc[k].get("WRITE_SIZE", [0])) / max(len(acc[k].get("WRITE_SIZE", [0])), 1)
         rec = {"kernel": k, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
