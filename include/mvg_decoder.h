@@ -127,7 +127,9 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
  *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: [offsets|logits]).
  *   mvg_msda_gsamp          : per (image, query, head): gathers its 24 logits + 48 offsets from G at the reference
  *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b, softmax, locations, samples vp -> samp
- *       (N_img*Lq, 256) bf16.  M=8, D=32, P=8, L<=4.
+ *       (N_img*Lq, 256) bf16.  M=8, D=32, P=8, L<=4.  pair_mask (N_img*Lq) u8 or NULL: rows with mask 0 are
+ *       written as zeros without being sampled (the consumer multiplies exactly these rows by the in-image mask,
+ *       dq_decoder.py:585-586).  order (N_img*Lq) i32 or NULL: slot i of the launch computes pair order[i].
  * Weights Wf: bf16, zero-padded to 256 rows, MFMA-fragment order [wn 4][ks 16][j 2][lane 64][8]
  * (mvgformer_amd.ops.swizzle_weight); the kernels keep them in registers (weight-stationary, csrc/wreg_gemm.hip). */
 int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
@@ -135,7 +137,14 @@ int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const float* bias,
 int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
 int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl,
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,
+                   const uint8_t* pair_mask, const int32_t* order,
                    int N_img, int Lq, int L, int S, int B, void* stream);
+
+/* Processing order for mvg_msda_gsamp: per image, the Lq (image, query) pairs counting-sorted by the Morton code of
+ * the level-0 cell block of their reference point, pairs with inside == 0 last.  order (N_img*Lq) int32 holds
+ * global pair indices (n*Lq + q); it changes where a pair is computed, never its result.  inside may be NULL. */
+int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* shapes_host, int L, int32_t* order,
+                  int N_img, int Lq, void* stream);
 
 /* A.4 (dq_decoder.py:770): mean over views of attn (V,B*Lq,C) `dtype` -> (B*Lq,C) `dtype`. */
 int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream);

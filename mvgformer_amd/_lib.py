@@ -34,7 +34,8 @@ SIGNATURES = {
     "mvg_chain_update_ffn_class": [_vp, _i] + [_vp] * 13 + [_f] + [_vp] * 5 + [_i] * 4 + [_vp],
     "mvg_value_proj_pairs_ws": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_feat_linear_ws": [_vp, _vp, _vp, _i, _i, _i, _vp],
-    "mvg_msda_gsamp": [_vp] * 7 + [_i] * 5 + [_vp],
+    "mvg_msda_gsamp": [_vp] * 9 + [_i] * 5 + [_vp],
+    "mvg_bin_pairs": [_vp] * 3 + [_i] + [_vp] + [_i] * 2 + [_vp],
     "mvg_mean_views": [_vp, _i, _vp, _i, _i, _i, _vp],
     "mvg_add_layernorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_class_head": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

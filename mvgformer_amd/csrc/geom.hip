@@ -425,6 +425,72 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// bin_pairs_kernel -- processing order of the (image, query) pairs for the sampling kernel.
+// The sampling kernel's time is set by L1 misses of its gathers; queries arrive in person-major order, which is
+// random in the image.  One workgroup per image counting-sorts its Lq pairs by the Morton code of the level-0
+// cell block (2^shift x 2^shift cells) their reference point falls into; pairs outside the image (masked by
+// the consumer, dq_decoder.py:585-586) get the last key.  Consecutive slots of `order` are then neighbours in the
+// feature maps, so the 64 pairs of a sampling workgroup share their pair lines.  The order inside a bin is
+// whatever the LDS atomics produce: `order` only decides WHERE a pair is computed, never its result.
+constexpr int BIN_BITS = 6, BIN_KEYS = 1 << (2 * BIN_BITS);   // 64 x 64 cell blocks + 1 key for "outside"
+
+__device__ __forceinline__ unsigned spread1(unsigned v) {        // 6 bits -> every second bit
+  v &= 0x3fu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void bin_pairs_kernel(const float* __restrict__ ref_lvl,
+                                                         const uint8_t* __restrict__ inside, int* __restrict__ order,
+                                                         int Lq, int L, int W0, int H0, int shift) {
+  __shared__ int hist[BIN_KEYS + 1];
+  __shared__ int wave_tot[16];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i <= BIN_KEYS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  auto key_of = [&](int q) -> int {
+    const long pair = (long)n * Lq + q;
+    if (inside && !inside[pair]) return BIN_KEYS;
+    const float rx = ref_lvl[pair * L * 2], ry = ref_lvl[pair * L * 2 + 1];     // level-0 reference point
+    const int cx = min(max((int)(fminf(fmaxf(rx, 0.f), 1.f) * (float)W0), 0), W0 - 1) >> shift;
+    const int cy = min(max((int)(fminf(fmaxf(ry, 0.f), 1.f) * (float)H0), 0), H0 - 1) >> shift;
+    return (int)(spread1((unsigned)cx) | (spread1((unsigned)cy) << 1));
+  };
+  for (int q = tid; q < Lq; q += 1024) atomicAdd(&hist[key_of(q)], 1);
+  __syncthreads();
+  // exclusive scan of the 4096 keys: 4 per thread, wave shuffles, then the 16 wave totals
+  const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+  const int mine = c0 + c1 + c2 + c3;
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if ((tid & 63) >= d) incl += up;
+  }
+  if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+  int total = 0;
+  for (int w = 0; w < 16; ++w) total += wave_tot[w];
+  __syncthreads();
+  const int ex = base + incl - mine;
+  hist[4 * tid] = ex;
+  hist[4 * tid + 1] = ex + c0;
+  hist[4 * tid + 2] = ex + c0 + c1;
+  hist[4 * tid + 3] = ex + c0 + c1 + c2;
+  if (tid == 0) hist[BIN_KEYS] = total;          // the "outside" pairs go last
+  __syncthreads();
+  for (int q = tid; q < Lq; q += 1024) {
+    const int pos = atomicAdd(&hist[key_of(q)], 1);
+    order[(long)n * Lq + pos] = n * Lq + q;
+  }
+}
+
 extern "C" {
 
 int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W, int S, int start,
@@ -453,6 +519,21 @@ int mvg_project(const float* X, const float* cams, const int64_t* shapes_host, i
   if (total == 0) return 0;
   hipLaunchKernelGGL(project_kernel, dim3(mvg_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, X, cams, lv, r,
                      ref_lvl, inside, B, Lq, total);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* shapes_host, int L, int32_t* order,
+                  int N_img, int Lq, void* stream) {
+  if (!ref_lvl || !shapes_host || !order || L <= 0 || N_img < 0 || Lq < 0) return MVG_E_BADARG;
+  if ((long)N_img * Lq > 0x7fffffffL) return MVG_E_BADARG;
+  if (N_img == 0 || Lq == 0) return 0;
+  const int H0 = (int)shapes_host[0], W0 = (int)shapes_host[1];
+  if (H0 <= 0 || W0 <= 0) return MVG_E_BADARG;
+  int shift = 2;                                  // 4 x 4 level-0 cells per bin, coarser for maps wider than 256 cells
+  while (((W0 - 1) >> shift) >= (1 << BIN_BITS) || ((H0 - 1) >> shift) >= (1 << BIN_BITS)) ++shift;
+  hipLaunchKernelGGL(bin_pairs_kernel, dim3(N_img), dim3(1024), 0, (hipStream_t)stream, ref_lvl, inside, (int*)order, Lq, L,
+                     W0, H0, shift);
   MVG_LAUNCH_CHECK();
   return 0;
 }

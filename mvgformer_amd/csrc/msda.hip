@@ -336,15 +336,24 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
 template <int L>
 __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                             const float* __restrict__ xw, const float* __restrict__ r,
-                                                            LevelTable lv, bf16_t* __restrict__ samp, int n_pairs,
+                                                            LevelTable lv, bf16_t* __restrict__ samp,
+                                                            const uint8_t* __restrict__ pair_mask,
+                                                            const int* __restrict__ order, int n_pairs,
                                                             int Lq, int S, int B) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 4;   // SCP: padded scratch row (76 for L=3)
   __shared__ __attribute__((aligned(16))) float scratch[4][16][SCP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = blockIdx.x & 7, sub = lane & 3, pl = lane >> 2;
-  int pair = (blockIdx.x >> 3) * 64 + wave * 16 + pl;
-  const bool live = pair < n_pairs;
-  if (!live) pair = n_pairs - 1;
+  // The 4 lanes of a quad share one (pair, head) and every LDS scratch row is private to its quad, so lanes may
+  // leave early (no workgroup barrier below): slots past the end, and pairs the caller masks out (reference
+  // points outside the image: the consumer multiplies their rows by 0, dq_decoder.py:585-586) -- zero-filled.
+  const int slot = (blockIdx.x >> 3) * 64 + wave * 16 + pl;
+  if (slot >= n_pairs) return;
+  const int pair = order ? order[slot] : slot;
+  if (pair_mask && !pair_mask[pair]) {
+    *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
+    return;
+  }
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
   float* sc = &scratch[wave][pl][0];
 
@@ -393,7 +402,10 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[0], v[5] + xb[1], v[6] + xb[2], v[7] + xb[3]};
     }
   }
-  __syncthreads();
+  // quad-private scratch: LDS operations of one wavefront execute in order, only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // ---- pass 1: softmax denominator of the head's logits
   float mx = -INFINITY;
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
         }
     }
   }
-  if (live) store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
+  store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
@@ -661,7 +673,8 @@ int mvg_msda_backward_f32(const float* value, const int64_t* spatial_shapes, con
 }
 
 int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl, const int64_t* shapes_host,
-                   const int64_t* starts_host, void* samp, int N_img, int Lq, int L, int S, int B, void* stream) {
+                   const int64_t* starts_host, void* samp, const uint8_t* pair_mask, const int32_t* order, int N_img,
+                   int Lq, int L, int S, int B, void* stream) {
   if (!vp || !G || !xw || !ref_lvl || !shapes_host || !starts_host || !samp || B <= 0) return MVG_E_BADARG;
   LevelTable lv;
   int e = mvg_fill_levels(&lv, shapes_host, starts_host, L);
@@ -673,7 +686,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   hipStream_t st = (hipStream_t)stream;
 #define MVG_GS(LL)                                                                                                \
   hipLaunchKernelGGL((msda_gsamp_kernel<LL>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp, (const bf16_t*)G, xw, \
-                     ref_lvl, lv, (bf16_t*)samp, (int)pairs, Lq, S, B)
+                     ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S, B)
   switch (L) {
     case 1: MVG_GS(1); break;
     case 2: MVG_GS(2); break;
@@ -689,6 +702,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
 extern int g_chain_rm;
 extern int g_chain_waves;
 extern int g_chain_a_waves;
+extern int g_wreg_grid;
 
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;
@@ -696,6 +710,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_waves") && (value == 4 || value == 8)) { g_chain_waves = value; return 0; }
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
+  if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
   if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
   return MVG_E_BADARG;
 }

@@ -9,14 +9,17 @@
 // 200 000 rows is as much traffic as the activations (measured: 107 us for the value projection = 510 MB, 200 MB
 // of it weights).  Here 512 persistent workgroups load the weight ONCE into registers -- each of the 4
 // wavefronts keeps its 64 output columns x 256 k = 32 KB as 128 VGPRs in MFMA-fragment order -- and stream
-// 32-row tiles through LDS: the k-loop is pure ds_read_b128 + v_mfma_f32_32x32x16_bf16, the next tile is
-// prefetched into registers across the MFMAs and the epilogue, two workgroups per CU overlap each other.
+// 32-row tiles through LDS: the k-loop is pure ds_read_b128 + v_mfma_f32_32x32x16_bf16; the loads of the next
+// tile and the stores of the previous one are issued together at the start of an iteration and waited for one
+// MFMA + epilogue phase later; two workgroups per CU overlap each other.
 //
 // Pixel-pair layout (consumed by msda_gsamp_kernel):  vp[img][head 8][1+s][ch 32][2] bf16, the 32-bit word of
 // channel ch in line 1+s is (value(s)[ch], value(s+1)[ch]); line 0 is (0, value(0)), the right half of the last
 // pixel's line is 0.  Tiles overlap by one row (tile t = rows [31t, 31t+32)) so that every tile owns the
 // right-hand neighbour of its last output row.
 #include "common.h"
+
+int g_wreg_grid = 512;   // tuning knob (mvg_set_tuning "wreg_grid"): persistent workgroups
 
 namespace {
 
@@ -35,10 +38,12 @@ struct WregParams {
 
 __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;                       // RM x 256 bf16 A tile
-  char* stage = smem + RM * ACT_PITCH;    // RM x 256 bf16 output tile
+  char* act = smem;                                   // RM x 256 bf16 A tile
+  char* stage0 = smem + RM * ACT_PITCH;               // 2 x (RM x 256 bf16) output tiles (double-buffered)
+  float* bias_s = reinterpret_cast<float*>(smem + 3 * RM * ACT_PITCH);   // 256 f32
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, rl = lane & 31, h = lane >> 5;
   const bool wave_has_cols = wn * 64 < p.N;
+  bias_s[tid] = p.bias ? p.bias[tid] : 0.f;
 
   // ---- the weight slice of this wavefront -> registers, once
   f32x4 wreg[16][2];
@@ -53,26 +58,74 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
 
   const int TS = p.rowmajor ? RM : RM - 1;      // tile stride in rows (pair layout: one row of overlap)
   const int ntiles = (p.M + TS - 1) / TS;
-  uint4 xpre[NCH];                              // next A tile, in flight across the MFMAs / epilogue
-  auto prefetch = [&](int tile) {
+  bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+  // chunk c = i*256 + tid of a tile: row = c >> 5, 16-byte column v16 = c & 31 (NCH chunks per thread)
+  auto load_chunk = [&](int tile, int i) -> uint4 {
+    const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
     const int rr = min(tile, ntiles - 1) * TS;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
-      xpre[i] = *reinterpret_cast<const uint4*>(p.A + (long)min(rr + row, p.M - 1) * 256 + v16 * 8);
-    }
+    return *reinterpret_cast<const uint4*>(p.A + (long)min(rr + row, p.M - 1) * 256 + v16 * 8);
   };
-  prefetch(blockIdx.x);
-#pragma unroll 1
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // global stores of a finished tile from its staging buffer
+  auto store_tile = [&](int tile, const char* stage) {
     const int r0 = tile * TS;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
-      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = xpre[i];
+      const int grow = r0 + row;
+      if (grow >= p.M) continue;
+      if (p.rowmajor) {
+        if (v16 * 8 < p.N)
+          *reinterpret_cast<f32x4*>(outp + (long)grow * p.N + v16 * 8) =
+              *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
+      } else if (row < RM - 1) {
+        // pair line 1+s of (img, head) = 128 bytes = 32 channels x (value(s), value(s+1)); the 4 threads of a
+        // head write its two 64-byte halves with one store each: thread q4 covers channels 4*q4.. and 16+4*q4..
+        const int img = grow / p.S_img, s = grow - img * p.S_img;
+        const int head = v16 >> 2, q4 = v16 & 3;
+        const bool last = s + 1 >= p.S_img;              // no right neighbour across an image boundary
+        const char* lrow = stage + row * ACT_PITCH + head * 64 + q4 * 8;
+        const uint2 la = *reinterpret_cast<const uint2*>(lrow), lb = *reinterpret_cast<const uint2*>(lrow + 32);
+        uint2 ra = *reinterpret_cast<const uint2*>(lrow + ACT_PITCH), rb = *reinterpret_cast<const uint2*>(lrow + ACT_PITCH + 32);
+        if (last) ra = rb = uint2{0u, 0u};
+        bf16_t* line = outp + (((long)img * 8 + head) * (p.S_img + 1) + 1 + s) * 64 + q4 * 8;
+        *reinterpret_cast<uint4*>(line) =
+            uint4{__builtin_amdgcn_perm(ra.x, la.x, 0x05040100u), __builtin_amdgcn_perm(ra.x, la.x, 0x07060302u),
+                  __builtin_amdgcn_perm(ra.y, la.y, 0x05040100u), __builtin_amdgcn_perm(ra.y, la.y, 0x07060302u)};
+        *reinterpret_cast<uint4*>(line + 32) =
+            uint4{__builtin_amdgcn_perm(rb.x, lb.x, 0x05040100u), __builtin_amdgcn_perm(rb.x, lb.x, 0x07060302u),
+                  __builtin_amdgcn_perm(rb.y, lb.y, 0x05040100u), __builtin_amdgcn_perm(rb.y, lb.y, 0x07060302u)};
+        if (s == 0) {                                  // line 0 of the plane: (0, value(0)) -- the w_low = -1 column
+          *reinterpret_cast<uint4*>(line - 64) = uint4{la.x << 16, la.x & 0xffff0000u, la.y << 16, la.y & 0xffff0000u};
+          *reinterpret_cast<uint4*>(line - 64 + 32) = uint4{lb.x << 16, lb.x & 0xffff0000u, lb.y << 16, lb.y & 0xffff0000u};
+        }
+      }
+    }
+  };
+
+  // Software pipeline.  All global traffic of an iteration is issued at its start -- the stores of the PREVIOUS
+  // tile (from the other staging buffer), then the loads of the NEXT tile -- and is only waited for at the top of
+  // the next iteration, one MFMA + epilogue phase later (gfx9 has a single in-order vmcnt for loads and stores:
+  // a store issued after a load would be waited for together with it).
+  uint4 xp0 = load_chunk(blockIdx.x, 0), xp1 = load_chunk(blockIdx.x, 1), xp2 = load_chunk(blockIdx.x, 2),
+        xp3 = load_chunk(blockIdx.x, 3);
+  static_assert(NCH == 4, "prefetch registers are written out for 4 chunks per thread");
+  int it = 0, prev_tile = -1;
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    {
+      const int row = tid >> 5, v16 = tid & 31;        // chunk i: row + 8*i
+      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = xp0;
+      *reinterpret_cast<uint4*>(act + (row + 8) * ACT_PITCH + v16 * 16) = xp1;
+      *reinterpret_cast<uint4*>(act + (row + 16) * ACT_PITCH + v16 * 16) = xp2;
+      *reinterpret_cast<uint4*>(act + (row + 24) * ACT_PITCH + v16 * 16) = xp3;
     }
     __syncthreads();
-    prefetch(tile + gridDim.x);
+    char* stage = stage0 + (it & 1) * RM * ACT_PITCH;
+    if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);
+    xp0 = load_chunk(tile + gridDim.x, 0);
+    xp1 = load_chunk(tile + gridDim.x, 1);
+    xp2 = load_chunk(tile + gridDim.x, 2);
+    xp3 = load_chunk(tile + gridDim.x, 3);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- MFMA: acc[j] = A_tile(32 x 256) . W_slice(64 cols)^T, weights from registers
@@ -92,67 +145,29 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
       }
     }
 
-    // ---------------- epilogue: + bias -> bf16 -> staging tile -> coalesced stores
+    // ---------------- epilogue: + bias -> bf16 -> staging tile
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;
-        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nn);
         uint2 pk;
         pk.x = (unsigned)f32_to_bf16(acc[j][4 * g] + bv[0]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 1] + bv[1]) << 16);
         pk.y = (unsigned)f32_to_bf16(acc[j][4 * g + 2] + bv[2]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 3] + bv[3]) << 16);
         *reinterpret_cast<uint2*>(stage + rl * ACT_PITCH + nn * 2) = pk;
       }
-    __syncthreads();
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
-      const int grow = r0 + row;
-      if (grow >= p.M) continue;
-      if (p.rowmajor) {
-        if (v16 * 8 < p.N)
-          *reinterpret_cast<f32x4*>(outp + (long)grow * p.N + v16 * 8) =
-              *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
-      } else if (row < RM - 1) {
-        // pair line 1+s of (img, head): this thread writes its 8 channels = 32 contiguous bytes
-        const int img = grow / p.S_img, s = grow - img * p.S_img;
-        const int head = v16 >> 2, ch8 = v16 & 3;
-        const uint4 lf = *reinterpret_cast<const uint4*>(stage + row * ACT_PITCH + v16 * 16);
-        uint4 rt = *reinterpret_cast<const uint4*>(stage + (row + 1) * ACT_PITCH + v16 * 16);
-        if (s + 1 >= p.S_img) rt = uint4{0u, 0u, 0u, 0u};         // no right neighbour across an image boundary
-        const unsigned l4[4] = {lf.x, lf.y, lf.z, lf.w}, r4[4] = {rt.x, rt.y, rt.z, rt.w};
-        unsigned w8[8];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          w8[2 * t] = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);       // (left.ch 2t  , right.ch 2t  )
-          w8[2 * t + 1] = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);   // (left.ch 2t+1, right.ch 2t+1)
-        }
-        bf16_t* line = outp + (((long)img * 8 + head) * (p.S_img + 1) + 1 + s) * 64 + ch8 * 16;
-        *reinterpret_cast<uint4*>(line) = uint4{w8[0], w8[1], w8[2], w8[3]};
-        *reinterpret_cast<uint4*>(line + 8) = uint4{w8[4], w8[5], w8[6], w8[7]};
-        if (s == 0) {                                  // line 0 of the plane: (0, value(0)) -- the w_low = -1 column
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            w8[2 * t] = l4[t] << 16;
-            w8[2 * t + 1] = l4[t] & 0xffff0000u;
-          }
-          *reinterpret_cast<uint4*>(line - 64) = uint4{w8[0], w8[1], w8[2], w8[3]};
-          *reinterpret_cast<uint4*>(line - 64 + 8) = uint4{w8[4], w8[5], w8[6], w8[7]};
-        }
-      }
-    }
-    // next iteration: the act writes are ordered after this tile's MFMA reads by the barrier above, the next
-    // staging writes after these staging reads by the barrier that follows the act writes
+    prev_tile = tile;
+    __syncthreads();      // act may be overwritten, this tile's staging buffer is complete
   }
+  if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);
 }
 
 int launch_wreg(const WregParams& p, hipStream_t st) {
-  const size_t lds = 2 * RM * ACT_PITCH;
+  const size_t lds = 3 * RM * ACT_PITCH + 256 * sizeof(float);
   const int TS = p.rowmajor ? RM : RM - 1;
   const int ntiles = (p.M + TS - 1) / TS;
-  const int grid = ntiles < 512 ? ntiles : 512;      // persistent: 2 workgroups per CU
+  const int grid = ntiles < g_wreg_grid ? ntiles : g_wreg_grid;      // persistent: 2 workgroups per CU
   hipLaunchKernelGGL(wreg_gemm_kernel, dim3(grid), dim3(256), lds, st, p);
   MVG_LAUNCH_CHECK();
   return 0;

@@ -315,7 +315,7 @@ class DQDecoderLayer(MvPDecoderLayer):
                   pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256)
         o = None
         if fuse_a:
-            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B)
+            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1))
             sw = lambda w: ops.swizzle_weight(w.to(dt))
             attn, o = ops.chain_attn_pose(
                 samp, inside.view(-1),

@@ -198,15 +198,33 @@ def feat_linear_ws(feat, w_frag, N=192):
     return G
 
 
-def msda_gsamp(vp, G, xw, r, levels, B):
-    """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h)."""
+def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None):
+    """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h).
+    pair_mask (n_img*Lq) u8: rows with 0 are zero-filled, not sampled; order (n_img*Lq) i32 from bin_pairs."""
     n_img = vp.shape[0]
     Lq = r.shape[1]
     samp = torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
+    if pair_mask is not None:
+        assert pair_mask.dtype == torch.uint8 and pair_mask.numel() == n_img * Lq and pair_mask.is_contiguous()
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == n_img * Lq and order.is_contiguous()
     with _timed("msda_gsamp"):
       L.check(L.load().mvg_msda_gsamp(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
-                                      L.ptr(samp), n_img, Lq, levels.L, levels.S, B, L.stream_ptr()), "mvg_msda_gsamp")
+                                      L.ptr(samp), None if pair_mask is None else L.ptr(pair_mask),
+                                      None if order is None else L.ptr(order), n_img, Lq, levels.L, levels.S, B,
+                                      L.stream_ptr()), "mvg_msda_gsamp")
     return samp
+
+
+def bin_pairs(r, inside, levels):
+    """processing order of the (image, query) pairs for msda_gsamp: Morton-sorted by level-0 cell block, pairs with
+    inside == 0 last.  r (n_img, Lq, L, 2) per-level reference points; inside (n_img, Lq) u8 or None."""
+    n_img, Lq = r.shape[0], r.shape[1]
+    order = torch.empty((n_img * Lq,), dtype=torch.int32, device=r.device)
+    with _timed("bin_pairs"):
+      L.check(L.load().mvg_bin_pairs(L.ptr(r), None if inside is None else L.ptr(inside), levels.shapes_c, levels.L,
+                                     L.ptr(order), n_img, Lq, L.stream_ptr()), "mvg_bin_pairs")
+    return order
 
 
 def swizzle_weight(w):

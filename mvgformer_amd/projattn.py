@@ -76,6 +76,7 @@ class ProjAttn(nn.Module):
         # bf16 inference: weight-stationary pyramid GEMMs + pixel-pair value layout + G-sampling kernel
         # (False: the generic gather -> linear -> fused-sampling kernels, also the fp32 path)
         self.use_fast_path = True
+        self.sort_pairs = True            # bf16 fast path: sample the pairs in image-space (Morton) order
         self._wc = WeightCache()
         self._vp = None
         self._vp_event = None
@@ -145,12 +146,14 @@ class ProjAttn(nn.Module):
         """Inference path on packed inputs.  x (B,Lq,C) f32 = tgt+query_pos; r (V*B,Lq,L,2) the
         per-level reference points; feat (V*B,S,C) channels-last pyramid in the compute dtype.
         Returns (V*B*Lq, C)."""
-        samp = self.native_sample(x, r, feat, levels, V, B)
+        samp = self.native_sample(x, r, feat, levels, V, B, pair_mask=rowmask)
         _, _, _, _, Wp, bp = self.weights(feat.dtype)
         return ops.linear(samp, Wp, bp, out_dtype=feat.dtype, rowmask=rowmask)   # projattn.py:203 (+ dq_decoder.py:585)
 
-    def native_sample(self, x, r, feat, levels, V, B):
-        """everything of native_forward up to (not including) output_proj: (V*B*Lq, C) sampled values."""
+    def native_sample(self, x, r, feat, levels, V, B, pair_mask=None):
+        """everything of native_forward up to (not including) output_proj: (V*B*Lq, C) sampled values.
+        pair_mask (V*B*Lq) u8: rows the caller is going to multiply by 0 (reference point outside the image,
+        dq_decoder.py:585-586); the bf16 fast path returns zeros for them instead of sampling."""
         dt = feat.dtype
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
@@ -165,7 +168,8 @@ class ProjAttn(nn.Module):
             vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
             xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
             G = ops.feat_linear_ws(feat, Woa_f, 192)
-            return ops.msda_gsamp(vp, G, xw, r, levels, B)                   # projattn.py:148-200
+            order = ops.bin_pairs(r, pair_mask, levels) if self.sort_pairs else None
+            return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
         value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169

@@ -471,3 +471,56 @@ def test_bf16_fast_path_matches_generic_kernels():
     assert torch.isfinite(b).all()
     assert float((a - b).abs().max()) < 0.08 * float(a.abs().max())
     assert float((a - b).abs().mean()) < 4e-3 * float(a.abs().max())
+
+
+def test_pair_binning_and_masked_sampling_are_exact():
+    """mvg_bin_pairs: a permutation per image, in-image pairs first in nondecreasing Morton key of the level-0
+    4x4-cell block, masked pairs last.  mvg_msda_gsamp with (pair_mask, order): bit-identical rows for the kept
+    pairs, zeros for the masked ones (what dq_decoder.py:585-586 multiplies by 0 anyway)."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_b2")
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    pa = dec.layers[0].proj_attn
+    with torch.no_grad():
+        ctx = DecoderContext.build(gc.src_views, gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size,
+                                   torch.bfloat16, case.B)
+        r, ref_lvl, inside = ops.project(gc.reference_points, ctx.cams, ctx.levels, ctx.V, case.B)
+        inside = inside.clone()
+        inside[:, 1::3] = 0                                       # make sure both classes occur in every image
+        n_img, Lq = inside.shape
+        order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
+        o = order.view(n_img, Lq).long().cpu()
+        H0, W0 = [int(v) for v in ctx.levels.shapes[0]]
+
+        def morton(cx, cy):
+            k = 0
+            for bit in range(6):
+                k |= ((cx >> bit) & 1) << (2 * bit) | ((cy >> bit) & 1) << (2 * bit + 1)
+            return k
+        ins_c, ref_c = inside.cpu(), ref_lvl.cpu()
+        for n in range(n_img):
+            assert sorted(o[n].tolist()) == list(range(n * Lq, (n + 1) * Lq))
+            keys = []
+            for gp in o[n].tolist():
+                q = gp - n * Lq
+                if not ins_c[n, q]:
+                    keys.append(4096)
+                    continue
+                rx, ry = np.float32(ref_c[n, q, 0, 0]), np.float32(ref_c[n, q, 0, 1])     # fp32 like the kernel
+                cx = min(max(int(np.clip(rx, np.float32(0), np.float32(1)) * np.float32(W0)), 0), W0 - 1) >> 2
+                cy = min(max(int(np.clip(ry, np.float32(0), np.float32(1)) * np.float32(H0)), 0), H0 - 1) >> 2
+                keys.append(morton(cx, cy))
+            assert keys == sorted(keys), "image %d not in Morton order" % n
+        x = (gc.tgt + gc.query_pos).contiguous()
+        pa.sort_pairs = False
+        full = pa.native_sample(x, ref_lvl, ctx.feat, ctx.levels, ctx.V, case.B)
+        pa.sort_pairs = True
+        part = pa.native_sample(x, ref_lvl, ctx.feat, ctx.levels, ctx.V, case.B, pair_mask=inside.view(-1))
+        resorted = pa.native_sample(x, ref_lvl, ctx.feat, ctx.levels, ctx.V, case.B)
+    keep = inside.view(-1).bool()
+    assert torch.equal(resorted, full)
+    assert torch.equal(part[keep], full[keep])
+    assert int(part[~keep].float().abs().sum()) == 0 and int((~keep).sum()) > 0

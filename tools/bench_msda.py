@@ -62,6 +62,30 @@ with torch.no_grad():
         torch.cuda.synchronize()
         us = s_.elapsed_time(e_) / 20 * 1e3
         print("%-28s %8.1f us  %7.1f GB/s algorithmic" % ("G-sampling (fast path)", us, bytes_launch / us / 1e3))
+        msk = inside.view(-1)
+        print("    in-image fraction of the pairs: %.3f" % float(msk.float().mean()))
+        order = ops.bin_pairs(ref_lvl, msk, ctx.levels)
+        order_all = ops.bin_pairs(ref_lvl, None, ctx.levels)
+        for tag, kw in (("  + pair mask", dict(pair_mask=msk)), ("  + Morton order", dict(order=order_all)),
+                        ("  + mask + Morton order", dict(pair_mask=msk, order=order))):
+            for _ in range(3):
+                ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1, **kw)
+            torch.cuda.synchronize()
+            s_.record()
+            for _ in range(20):
+                o2 = ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1, **kw)
+            e_.record()
+            torch.cuda.synchronize()
+            us = s_.elapsed_time(e_) / 20 * 1e3
+            keep = msk.bool() if "pair_mask" in kw else torch.ones_like(msk).bool()
+            same = bool((o2[keep] == outp[keep]).all()) and bool((o2[~keep] == 0).all())
+            print("%-28s %8.1f us  %7.1f GB/s algorithmic   identical rows: %s" % (tag, us, bytes_launch / us / 1e3, same))
+        s_.record()
+        for _ in range(20):
+            ops.bin_pairs(ref_lvl, msk, ctx.levels)
+        e_.record()
+        torch.cuda.synchronize()
+        print("%-28s %8.1f us" % ("  bin_pairs", s_.elapsed_time(e_) / 20 * 1e3))
         lib.mvg_set_tuning(b"fused_cpl_bf16", 8); lib.mvg_set_tuning(b"fused_nb", 4)
         ref = ops.msda_fused(value, oa, ref_lvl, ctx.levels)
         d = (outp.float() - ref.float()).abs()
