@@ -444,6 +444,7 @@ __device__ __forceinline__ unsigned spread1(unsigned v) {        // 6 bits -> ev
   return v;
 }
 
+template <int KPT>   // keys per thread: Lq <= 1024 * KPT
 __global__ __launch_bounds__(1024) void bin_pairs_kernel(const float* __restrict__ ref_lvl,
                                                          const uint8_t* __restrict__ inside, int* __restrict__ order,
                                                          int Lq, int L, int W0, int H0, int shift) {
@@ -451,16 +452,30 @@ __global__ __launch_bounds__(1024) void bin_pairs_kernel(const float* __restrict
   __shared__ int wave_tot[16];
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i <= BIN_KEYS; i += 1024) hist[i] = 0;
+  // all loads of the thread's pairs are issued before the first key is used (one memory round trip)
+  float rx[KPT], ry[KPT];
+  uint8_t in[KPT];
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const long pair = (long)n * Lq + min(tid + 1024 * k, Lq - 1);
+    const float2 rr = *reinterpret_cast<const float2*>(ref_lvl + pair * L * 2);     // level-0 reference point
+    rx[k] = rr.x;
+    ry[k] = rr.y;
+    in[k] = inside ? inside[pair] : (uint8_t)1;
+  }
   __syncthreads();
-  auto key_of = [&](int q) -> int {
-    const long pair = (long)n * Lq + q;
-    if (inside && !inside[pair]) return BIN_KEYS;
-    const float rx = ref_lvl[pair * L * 2], ry = ref_lvl[pair * L * 2 + 1];     // level-0 reference point
-    const int cx = min(max((int)(fminf(fmaxf(rx, 0.f), 1.f) * (float)W0), 0), W0 - 1) >> shift;
-    const int cy = min(max((int)(fminf(fmaxf(ry, 0.f), 1.f) * (float)H0), 0), H0 - 1) >> shift;
-    return (int)(spread1((unsigned)cx) | (spread1((unsigned)cy) << 1));
-  };
-  for (int q = tid; q < Lq; q += 1024) atomicAdd(&hist[key_of(q)], 1);
+  int key[KPT];
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const int cx = min(max((int)(fminf(fmaxf(rx[k], 0.f), 1.f) * (float)W0), 0), W0 - 1) >> shift;
+    const int cy = min(max((int)(fminf(fmaxf(ry[k], 0.f), 1.f) * (float)H0), 0), H0 - 1) >> shift;
+    key[k] = in[k] ? (int)(spread1((unsigned)cx) | (spread1((unsigned)cy) << 1)) : BIN_KEYS;
+    const bool live = tid + 1024 * k < Lq;
+    // the "outside" key is shared by a large part of the pairs: one LDS atomic per wavefront, not per lane
+    const unsigned long long outm = __ballot(live && key[k] == BIN_KEYS);
+    if (live && key[k] != BIN_KEYS) atomicAdd(&hist[key[k]], 1);
+    if (outm && (tid & 63) == 0) atomicAdd(&hist[BIN_KEYS], __popcll(outm));
+  }
   __syncthreads();
   // exclusive scan of the 4096 keys: 4 per thread, wave shuffles, then the 16 wave totals
   const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
@@ -473,10 +488,13 @@ __global__ __launch_bounds__(1024) void bin_pairs_kernel(const float* __restrict
   }
   if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
-  int total = 0;
-  for (int w = 0; w < 16; ++w) total += wave_tot[w];
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int t = wave_tot[w];
+    base += (w < (tid >> 6)) ? t : 0;
+    total += t;
+  }
   __syncthreads();
   const int ex = base + incl - mine;
   hist[4 * tid] = ex;
@@ -485,9 +503,18 @@ __global__ __launch_bounds__(1024) void bin_pairs_kernel(const float* __restrict
   hist[4 * tid + 3] = ex + c0 + c1 + c2;
   if (tid == 0) hist[BIN_KEYS] = total;          // the "outside" pairs go last
   __syncthreads();
-  for (int q = tid; q < Lq; q += 1024) {
-    const int pos = atomicAdd(&hist[key_of(q)], 1);
-    order[(long)n * Lq + pos] = n * Lq + q;
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const bool live = tid + 1024 * k < Lq;
+    const bool out = live && key[k] == BIN_KEYS;
+    const unsigned long long outm = __ballot(out);
+    int pos = 0;
+    if (live && !out) pos = atomicAdd(&hist[key[k]], 1);
+    int obase = 0;
+    if (outm && (tid & 63) == 0) obase = atomicAdd(&hist[BIN_KEYS], __popcll(outm));
+    obase = __shfl(obase, 0, 64);
+    if (out) pos = obase + __popcll(outm & ((1ull << (tid & 63)) - 1ull));
+    if (live) order[(long)n * Lq + pos] = n * Lq + tid + 1024 * k;
   }
 }
 
@@ -532,8 +559,14 @@ int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* sh
   if (H0 <= 0 || W0 <= 0) return MVG_E_BADARG;
   int shift = 2;                                  // 4 x 4 level-0 cells per bin, coarser for maps wider than 256 cells
   while (((W0 - 1) >> shift) >= (1 << BIN_BITS) || ((H0 - 1) >> shift) >= (1 << BIN_BITS)) ++shift;
-  hipLaunchKernelGGL(bin_pairs_kernel, dim3(N_img), dim3(1024), 0, (hipStream_t)stream, ref_lvl, inside, (int*)order, Lq, L,
-                     W0, H0, shift);
+#define MVG_BIN(K)                                                                                               \
+  hipLaunchKernelGGL((bin_pairs_kernel<K>), dim3(N_img), dim3(1024), 0, (hipStream_t)stream, ref_lvl, inside,   \
+                     (int*)order, Lq, L, W0, H0, shift)
+  if (Lq <= 16 * 1024) MVG_BIN(16);
+  else if (Lq <= 32 * 1024) MVG_BIN(32);
+  else if (Lq <= 64 * 1024) MVG_BIN(64);
+  else return MVG_E_BADARG;                       // more than 65 536 tokens per image: run the sampler unordered
+#undef MVG_BIN
   MVG_LAUNCH_CHECK();
   return 0;
 }

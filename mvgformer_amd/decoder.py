@@ -315,7 +315,15 @@ class DQDecoderLayer(MvPDecoderLayer):
                   pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256)
         o = None
         if fuse_a:
-            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1))
+            order = None
+            if self.proj_attn.sort_pairs == "first" and dt == torch.bfloat16 and Lq <= 65536:
+                # processing order of the (image, query) pairs from the first layer's projections, reused by the
+                # later layers (their reference points are refinements of the same 3D points)
+                if getattr(ctx, "order", None) is None or ctx.order.numel() != V * B * Lq:
+                    ctx.order = ops.bin_pairs(ref_lvl, None, ctx.levels)
+                order = ctx.order
+            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
+                                                order=order)
             sw = lambda w: ops.swizzle_weight(w.to(dt))
             attn, o = ops.chain_attn_pose(
                 samp, inside.view(-1),
@@ -450,6 +458,7 @@ class DQDecoder(MvPDecoder):
                                        layer0.compute_dtype, tgt.shape[0])
         elif ctx.feat is None:
             ctx.pack(src_views)
+        ctx.order = None
         inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
         ref_points_2d = None
         # The value projections (27 % of the FLOPs) depend only on the pyramid: run all of them on a side

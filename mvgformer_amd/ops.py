@@ -216,15 +216,33 @@ def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None):
     return samp
 
 
-def bin_pairs(r, inside, levels):
+def bin_pairs(r, inside, levels, out=None):
     """processing order of the (image, query) pairs for msda_gsamp: Morton-sorted by level-0 cell block, pairs with
     inside == 0 last.  r (n_img, Lq, L, 2) per-level reference points; inside (n_img, Lq) u8 or None."""
     n_img, Lq = r.shape[0], r.shape[1]
-    order = torch.empty((n_img * Lq,), dtype=torch.int32, device=r.device)
+    if Lq > 65536:          # the binning kernel keeps a thread's keys in registers (<= 64 per thread)
+        return None
+    if out is None:
+        out = torch.empty((n_img * Lq,), dtype=torch.int32, device=r.device)
+    order = out
     with _timed("bin_pairs"):
       L.check(L.load().mvg_bin_pairs(L.ptr(r), None if inside is None else L.ptr(inside), levels.shapes_c, levels.L,
                                      L.ptr(order), n_img, Lq, L.stream_ptr()), "mvg_bin_pairs")
     return order
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """one auxiliary HIP stream per device for small kernels that overlap with the main stream (fork/join with
+    wait_stream: legal inside HIP-graph capture)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[idx]
 
 
 def swizzle_weight(w):

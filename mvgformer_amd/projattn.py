@@ -13,6 +13,8 @@ from __future__ import annotations
 import math
 import warnings
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -76,7 +78,11 @@ class ProjAttn(nn.Module):
         # bf16 inference: weight-stationary pyramid GEMMs + pixel-pair value layout + G-sampling kernel
         # (False: the generic gather -> linear -> fused-sampling kernels, also the fp32 path)
         self.use_fast_path = True
-        self.sort_pairs = True            # bf16 fast path: sample the pairs in image-space (Morton) order
+        # bf16 fast path: sample the pairs in image-space (Morton) order.  True: binned per layer; "side": same, on a
+        # side stream; "first": DQDecoder bins once per forward (first layer) and reuses the order; False: query order
+        self.sort_pairs = os.environ.get("MVG_SORT_PAIRS", "layer")
+        if self.sort_pairs in ("0", "off", "False"):
+            self.sort_pairs = False
         self._wc = WeightCache()
         self._vp = None
         self._vp_event = None
@@ -150,7 +156,7 @@ class ProjAttn(nn.Module):
         _, _, _, _, Wp, bp = self.weights(feat.dtype)
         return ops.linear(samp, Wp, bp, out_dtype=feat.dtype, rowmask=rowmask)   # projattn.py:203 (+ dq_decoder.py:585)
 
-    def native_sample(self, x, r, feat, levels, V, B, pair_mask=None):
+    def native_sample(self, x, r, feat, levels, V, B, pair_mask=None, order=None):
         """everything of native_forward up to (not including) output_proj: (V*B*Lq, C) sampled values.
         pair_mask (V*B*Lq) u8: rows the caller is going to multiply by 0 (reference point outside the image,
         dq_decoder.py:585-586); the bf16 fast path returns zeros for them instead of sampling."""
@@ -163,12 +169,26 @@ class ProjAttn(nn.Module):
             pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
                                                   .to(dt))
             Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
-            # order: the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is
-            # the freshest resident of the 256-MB Infinity Cache when the sampler starts
-            vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
+            # the processing order of the pairs: given by the caller (reused across layers), or binned here -- on the
+            # main stream, or (sort_pairs == "side") on a side stream under the query-term GEMM
+            side = None
+            mode = self.sort_pairs if r.shape[1] <= 65536 else False
+            if order is None and mode:
+                order = torch.empty((r.shape[0] * r.shape[1],), dtype=torch.int32, device=r.device)
+                if mode == "side":
+                    side = ops.side_stream(r.device)
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        ops.bin_pairs(r, pair_mask, levels, out=order)
+                else:
+                    ops.bin_pairs(r, pair_mask, levels, out=order)
             xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            # the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is the
+            # freshest resident of the 256-MB Infinity Cache when the sampler starts
+            vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
             G = ops.feat_linear_ws(feat, Woa_f, 192)
-            order = ops.bin_pairs(r, pair_mask, levels) if self.sort_pairs else None
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
