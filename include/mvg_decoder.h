@@ -170,10 +170,15 @@ int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, fl
  *   attn = inside * (samp @ Wp^T + bp)                       (stored: input of the view mean)
  *   o    = W2 relu(W1 relu(W0 attn + b0) + b1) + b2          (dx, dy, confidence logit)
  * samp/attn (rows,256) bf16; Wp,W0,W1 (256,256) bf16; W2 (3,256) f32; biases f32; o (rows,3) f32.
- * Replaces mvg_linear x3 + mvg_rowdot3 of the unfused path; activations stay in LDS. */
+ * Replaces mvg_linear x3 + mvg_rowdot3 of the unfused path; activations stay in LDS.
+ * order (rows) i32 or NULL: tile row i of the launch works on row order[i] (mvg_bin_pairs: masked rows last).
+ * o_masked (3) f32 or NULL: o of a row with inside == 0 (the MLP of a zero row; obtain it by running this entry
+ * point on one masked row).  When given, 64-row tiles without a single in-image row only write attn = 0 and
+ * o = o_masked instead of running the chain. */
 int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
                         const void* W0, const float* b0, const void* W1, const float* b1,
-                        const float* W2, const float* b2, void* attn, float* o, int rows, void* stream);
+                        const float* W2, const float* b2, void* attn, float* o,
+                        const int32_t* order, const float* o_masked, int rows, void* stream);
 
 /* Fused bf16 chain per joint token (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-908):
  *   t1 = LN2(tgt + Wu mean_v(attn_v) + bu);  tgt' = LN3(t1 + W2 relu(W1 t1 + b1) + b2) (has_ffn) else t1;

@@ -126,13 +126,45 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
                                                       const bf16_t* __restrict__ W0, const float* __restrict__ b0,
                                                       const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                       const float* __restrict__ W2, const float* __restrict__ b2,
-                                                      bf16_t* __restrict__ attn, float* __restrict__ o, int R) {
+                                                      bf16_t* __restrict__ attn, float* __restrict__ o,
+                                                      const int* __restrict__ order, const float* __restrict__ o_masked,
+                                                      int R) {
   constexpr int MT = RM / 32 / (NT / 256);                  // row tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
+  int* rid = reinterpret_cast<int*>(smem + RM * ACT_PITCH);  // global row of every tile row (-1: past the end)
   const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
   const int r0 = blockIdx.x * RM, row0 = (tid >> 8) * MT * 32;
   const int rot = (blockIdx.x * 7 + ((tid >> 6) & 3) * 3) & 15;   // de-synchronise the weight walk (see stage_gemm)
+
+  // Tile row i works on global row order[r0 + i] (the sampler's processing order: rows whose reference point is
+  // outside the image come last, mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
+  // and o = the MLP of a zero row for all of its rows: o_masked holds that row's result (computed by this very
+  // kernel on one masked row), so such tiles only write their outputs.
+  bool mine = false;
+  if (tid < RM) {
+    const int slot = r0 + tid;
+    const int g = slot < R ? (order ? order[slot] : slot) : -1;
+    rid[tid] = g;
+    mine = g >= 0 && inside[g] != 0;
+  }
+  const bool any_inside = __syncthreads_or(mine) != 0;
+  if (!any_inside && o_masked) {
+    const float m0 = o_masked[0], m1 = o_masked[1], m2 = o_masked[2];
+#pragma unroll
+    for (int c0 = 0; c0 < RM * 32; c0 += NT) {
+      const int c = c0 + tid, row = c >> 5, v16 = c & 31;
+      const int g = rid[row];
+      if (g >= 0) *reinterpret_cast<f32x4*>(attn + (long)g * 256 + v16 * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < RM && rid[tid] >= 0) {
+      float* og = o + (long)rid[tid] * 3;
+      og[0] = m0;
+      og[1] = m1;
+      og[2] = m2;
+    }
+    return;
+  }
 
   // samp tile -> LDS (16-byte vectors, rows past R are zero); all loads in flight before the first write
   {
@@ -141,21 +173,21 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
     for (int i = 0; i < RM * 32 / NT; ++i) {
       const int c = i * NT + tid, row = c >> 5, v16 = c & 31;
       // clamped address + select instead of a branch: a guarded load makes hipcc wait vmcnt(0) per element
-      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)min(r0 + row, R - 1) * 256 + v16 * 8);
+      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid[row], 0) * 256 + v16 * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < RM * 32 / NT; ++i) {
       const int c = i * NT + tid, row = c >> 5, v16 = c & 31;
-      *reinterpret_cast<f32x4*>(act + row * ACT_PITCH + v16 * 16) = (r0 + row < R) ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(act + row * ACT_PITCH + v16 * 16) = (rid[row] >= 0) ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   f32x16 acc[MT][2];
   bool keep[MT], all[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int row = r0 + row0 + mt * 32 + rl;
-    keep[mt] = (inside[min(row, R - 1)] != 0) && (row < R);      // dq_decoder.py:585-586
+    const int g = rid[row0 + mt * 32 + rl];
+    keep[mt] = g >= 0 && inside[max(g, 0)] != 0;                 // dq_decoder.py:585-586
     all[mt] = true;
   }
   __syncthreads();
@@ -167,8 +199,9 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int c0 = 0; c0 < RM * 32; c0 += NT) {
     const int c = c0 + tid, row = c >> 5, v16 = c & 31;
-    if (r0 + row < R)
-      *reinterpret_cast<f32x4*>(attn + (long)(r0 + row) * 256 + v16 * 8) =
+    const int g = rid[row];
+    if (g >= 0)
+      *reinterpret_cast<f32x4*>(attn + (long)g * 256 + v16 * 8) =
           *reinterpret_cast<const f32x4*>(act + row * ACT_PITCH + v16 * 16);
   }
   // pose_embed MLP layers 0, 1 (ReLU)
@@ -206,10 +239,11 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   for (int off = 1; off < TPR; off <<= 1)
 #pragma unroll
     for (int k = 0; k < 3; ++k) s[k] += __shfl_xor(s[k], off, 64);
-  if (part == 0 && r0 + row < R) {
-    o[(long)(r0 + row) * 3 + 0] = s[0] + b2[0];
-    o[(long)(r0 + row) * 3 + 1] = s[1] + b2[1];
-    o[(long)(r0 + row) * 3 + 2] = s[2] + b2[2];
+  if (part == 0 && rid[row] >= 0) {
+    float* og = o + (long)rid[row] * 3;
+    og[0] = s[0] + b2[0];
+    og[1] = s[1] + b2[1];
+    og[2] = s[2] + b2[2];
   }
 }
 
@@ -391,8 +425,8 @@ int g_chain_rm = 64;   // tuning knob "chain_rm": rows per workgroup of the fuse
 template <int RM, int NT>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
-                          float* o, int rows, hipStream_t st) {
-  const size_t lds = RM * ACT_PITCH;
+                          float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
+  const size_t lds = RM * ACT_PITCH + RM * sizeof(int);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT>),
@@ -401,21 +435,23 @@ static int launch_chain_a(const void* samp, const uint8_t* inside, const void* W
     configured = true;
   }
   hipLaunchKernelGGL((chain_a_kernel<RM, NT>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
-                     (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, rows);
+                     (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, order,
+                     o_masked, rows);
   MVG_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
                                    const void* W0, const float* b0, const void* W1, const float* b1, const float* W2,
-                                   const float* b2, void* attn, float* o, int rows, void* stream) {
+                                   const float* b2, void* attn, float* o, const int32_t* order, const float* o_masked,
+                                   int rows, void* stream) {
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (g_chain_rm == 128 && g_chain_a_waves == 8) return launch_chain_a<128, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
-  if (g_chain_rm == 128) return launch_chain_a<128, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
-  if (g_chain_a_waves == 8) return launch_chain_a<64, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
-  return launch_chain_a<64, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, rows, st);
+  if (g_chain_rm == 128 && g_chain_a_waves == 8) return launch_chain_a<128, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 128) return launch_chain_a<128, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_a_waves == 8) return launch_chain_a<64, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  return launch_chain_a<64, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
 }
 
 extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,

@@ -315,23 +315,28 @@ class DQDecoderLayer(MvPDecoderLayer):
                   pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256)
         o = None
         if fuse_a:
+            # processing order of the (image, query) pairs: image-space (Morton) order, pairs outside the image last
+            # (mvg_bin_pairs); shared by the sampler (L1 locality, masked pairs skipped) and chain A (all-masked
+            # tiles skipped).  "first": binned once per forward from the first layer's projections.
             order = None
-            if self.proj_attn.sort_pairs == "first" and dt == torch.bfloat16 and Lq <= 65536:
-                # processing order of the (image, query) pairs from the first layer's projections, reused by the
-                # later layers (their reference points are refinements of the same 3D points)
+            mode = self.proj_attn.sort_pairs if Lq <= 65536 else False
+            if mode == "first":
                 if getattr(ctx, "order", None) is None or ctx.order.numel() != V * B * Lq:
                     ctx.order = ops.bin_pairs(ref_lvl, None, ctx.levels)
                 order = ctx.order
+            elif mode:
+                order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
                                                 order=order)
             sw = lambda w: ops.swizzle_weight(w.to(dt))
-            attn, o = ops.chain_attn_pose(
-                samp, inside.view(-1),
-                self._w("Wp_sw", (self.proj_attn.output_proj.weight,), dt, sw),
-                self._w("bp", (self.proj_attn.output_proj.bias,), f32),
-                self._w("Wpe0_sw", (pose_layers[0].weight,), dt, sw), self._w("bpe0", (pose_layers[0].bias,), f32),
-                self._w("Wpe1_sw", (pose_layers[1].weight,), dt, sw), self._w("bpe1", (pose_layers[1].bias,), f32),
-                self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
+            wts = (self._w("Wp_sw", (self.proj_attn.output_proj.weight,), dt, sw),
+                   self._w("bp", (self.proj_attn.output_proj.bias,), f32),
+                   self._w("Wpe0_sw", (pose_layers[0].weight,), dt, sw), self._w("bpe0", (pose_layers[0].bias,), f32),
+                   self._w("Wpe1_sw", (pose_layers[1].weight,), dt, sw), self._w("bpe1", (pose_layers[1].bias,), f32),
+                   self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
+            pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
+            o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
+            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
             attn = self.proj_attn.native_forward(x, ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
 

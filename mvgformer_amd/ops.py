@@ -255,17 +255,37 @@ def swizzle_weight(w):
     return t.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)
 
 
-def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2):
+def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
     """fused output_proj (* in-image mask) + 3-layer pose MLP; Wp/W0/W1 in swizzle_weight order.
+    order (rows) i32: row processing order (bin_pairs: masked rows last); o_masked (3) f32 from
+    chain_masked_row_output: lets all-masked 64-row tiles skip the chain.
     Returns (attn bf16 (rows,256), o f32 (rows,3))."""
     rows = samp.shape[0]
     attn = torch.empty((rows, 256), dtype=torch.bfloat16, device=samp.device)
     o = torch.empty((rows, 3), dtype=torch.float32, device=samp.device)
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == rows and order.is_contiguous()
     with _timed("chain_attn_pose"):
       L.check(L.load().mvg_chain_attn_pose(L.ptr(samp), L.ptr(inside), L.ptr(Wp), L.ptr(bp), L.ptr(W0), L.ptr(b0), L.ptr(W1),
-                                           L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o), rows, L.stream_ptr()),
+                                           L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
+                                           None if order is None else L.ptr(order),
+                                           None if o_masked is None else L.ptr(o_masked), rows, L.stream_ptr()),
               "mvg_chain_attn_pose")
     return attn, o
+
+
+def chain_masked_row_output(Wp, bp, W0, b0, W1, b1, W2, b2):
+    """o (3,) f32 of a row with inside == 0: the chain run on one masked row (weights only -> cacheable)."""
+    dev = Wp.device
+    samp = torch.zeros((1, 256), dtype=torch.bfloat16, device=dev)
+    inside = torch.zeros((1,), dtype=torch.uint8, device=dev)
+    global PROFILE
+    saved, PROFILE = PROFILE, None
+    try:
+        _, o = chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2)
+    finally:
+        PROFILE = saved
+    return o.reshape(3)
 
 
 def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,

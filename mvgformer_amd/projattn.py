@@ -78,8 +78,8 @@ class ProjAttn(nn.Module):
         # bf16 inference: weight-stationary pyramid GEMMs + pixel-pair value layout + G-sampling kernel
         # (False: the generic gather -> linear -> fused-sampling kernels, also the fp32 path)
         self.use_fast_path = True
-        # bf16 fast path: sample the pairs in image-space (Morton) order.  True: binned per layer; "side": same, on a
-        # side stream; "first": DQDecoder bins once per forward (first layer) and reuses the order; False: query order
+        # bf16 fast path: sample the pairs in image-space (Morton) order.  "layer"/True: binned per layer; "first":
+        # DQDecoderLayer bins once per forward (first layer) and reuses the order; False: query order
         self.sort_pairs = os.environ.get("MVG_SORT_PAIRS", "layer")
         if self.sort_pairs in ("0", "off", "False"):
             self.sort_pairs = False
@@ -169,22 +169,10 @@ class ProjAttn(nn.Module):
             pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
                                                   .to(dt))
             Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
-            # the processing order of the pairs: given by the caller (reused across layers), or binned here -- on the
-            # main stream, or (sort_pairs == "side") on a side stream under the query-term GEMM
-            side = None
-            mode = self.sort_pairs if r.shape[1] <= 65536 else False
-            if order is None and mode:
-                order = torch.empty((r.shape[0] * r.shape[1],), dtype=torch.int32, device=r.device)
-                if mode == "side":
-                    side = ops.side_stream(r.device)
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        ops.bin_pairs(r, pair_mask, levels, out=order)
-                else:
-                    ops.bin_pairs(r, pair_mask, levels, out=order)
+            # processing order of the pairs: given by the caller (DQDecoderLayer shares it with chain A) or binned here
+            if order is None and self.sort_pairs and r.shape[1] <= 65536:
+                order = ops.bin_pairs(r, pair_mask, levels)
             xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
             # the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is the
             # freshest resident of the 256-MB Infinity Cache when the sampler starts
             vp = self.project_values(feat) if self._vp_event is None else self._wait_values()

@@ -524,3 +524,29 @@ def test_pair_binning_and_masked_sampling_are_exact():
     assert torch.equal(resorted, full)
     assert torch.equal(part[keep], full[keep])
     assert int(part[~keep].float().abs().sum()) == 0 and int((~keep).sum()) > 0
+
+
+def test_chain_a_row_order_and_masked_tile_skip():
+    """mvg_chain_attn_pose with (order, o_masked): rows are processed in the binned order and 64-row tiles without an
+    in-image row only write attn = 0 / o = o_masked -- same outputs as the plain launch (tile composition changes
+    the fp32 accumulation order of a row: bf16-ulp agreement, not bit identity)."""
+    from mvgformer_amd import ops
+    torch.manual_seed(5)
+    rows = 64 * 9 + 17
+    samp = torch.randn(rows, 256, device=DEV).to(torch.bfloat16)
+    inside = (torch.rand(rows, device=DEV) < 0.4).to(torch.uint8)
+    inside[64:320] = 0                                            # whole masked tiles also without reordering
+    mk = lambda n, k: (torch.randn(n, k, device=DEV) / 16).to(torch.bfloat16)
+    Wp, W0, W1 = (ops.swizzle_weight(mk(256, 256)) for _ in range(3))
+    bp, b0, b1 = (torch.randn(256, device=DEV) * 0.1 for _ in range(3))
+    W2, b2 = torch.randn(3, 256, device=DEV) / 16, torch.randn(3, device=DEV)
+    wts = (Wp, bp, W0, b0, W1, b1, W2, b2)
+    attn0, o0 = ops.chain_attn_pose(samp, inside, *wts)
+    o_masked = ops.chain_masked_row_output(*wts)
+    perm = torch.argsort(1 - inside.int(), stable=True).to(torch.int32)     # in-image rows first, like mvg_bin_pairs
+    for order in (None, perm):
+        attn1, o1 = ops.chain_attn_pose(samp, inside, *wts, order=order, o_masked=o_masked)
+        assert torch.equal(attn1[inside == 0], torch.zeros_like(attn1[inside == 0]))
+        assert float((attn1.float() - attn0.float()).abs().max()) <= 2e-2 * float(attn0.float().abs().max())
+        assert float((o1 - o0).abs().max()) <= 2e-3 * float(o0.abs().max())
+        assert float((o1[inside == 0] - o_masked).abs().max()) <= 2e-3 * float(o0.abs().max())
