@@ -420,7 +420,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 
 int g_chain_waves = 8;    // tuning knob "chain_waves": wavefronts per workgroup of chain B (4 | 8); measured 86 -> 69 us
 int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 measured slower: 93 vs 79 us)
-int g_chain_rm = 64;   // tuning knob "chain_rm": rows per workgroup of the fused chains (64 | 128)
+int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128); 128: 65 -> 55 us (half the
+                       // weight bytes per row through the L1 miss path, the resource that bounds these kernels)
 
 template <int RM, int NT>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,

@@ -52,6 +52,17 @@ template <> __device__ __forceinline__ float load1<bf16_t>(const bf16_t* p) { re
 template <typename T> __device__ __forceinline__ void store1(T* p, float v);
 template <> __device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+// 4 consecutive elements, pointer aligned to 4 elements
+template <typename T> __device__ __forceinline__ void store_vec4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store_vec4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store_vec4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  uint2 pk;
+  pk.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+  pk.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(d) << 16);
+  *reinterpret_cast<uint2*>(p) = pk;
+}
 
 // Levels are passed by value to kernels (L <= MVG_MAX_LEVELS)
 #define MVG_MAX_LEVELS 8

@@ -5,27 +5,42 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------
-// NCHW level -> channels-last pyramid rows.  32x32 tile transpose through LDS (padded to
-// 33 columns: conflict-free for the column reads), 128-B coalesced on both sides.
+// NCHW level -> channels-last pyramid rows.  64 (pixels) x 64 (channels) tile transposed through LDS (65-float
+// pitch: conflict-free both ways): reads are 256-byte runs of one channel plane, writes 128-byte (bf16) /
+// 256-byte (fp32) runs of one pixel row, 4 channels per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_level_kernel(const float* __restrict__ src, T* __restrict__ feat, int C,
                                                          int HW, int S, int start) {
-  __shared__ float tile[32][33];
-  const int n = blockIdx.z;
-  const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, tid = threadIdx.x;
+  const int hw0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = tid & 63, ty = tid >> 6;
   const float* sp = src + (long)n * C * HW;
+  float v[16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, hw = hw0 + tx;
-    tile[ty + 8 * i][tx] = (c < C && hw < HW) ? sp[(long)c * HW + hw] : 0.f;
+  for (int i = 0; i < 16; ++i) {    // clamped address + select: every load of the thread is in flight at once
+    const int c = min(c0 + ty + 4 * i, C - 1), hw = min(hw0 + tx, HW - 1);
+    v[i] = sp[(long)c * HW + hw];
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[ty + 4 * i][tx] = v[i];
   __syncthreads();
   T* fp = feat + ((long)n * S + start) * C;
+  const int cq = tid & 15, p = tid >> 4, c = c0 + 4 * cq;
+  const bool vec = (C & 3) == 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int hw = hw0 + ty + 8 * i, c = c0 + tx;
-    if (hw < HW && c < C) store1<T>(fp + (long)hw * C + c, tile[tx][ty + 8 * i]);
+    const int hw = hw0 + p + 16 * i;
+    if (hw >= HW || c >= C) continue;
+    const float a0 = tile[4 * cq][p + 16 * i], a1 = tile[4 * cq + 1][p + 16 * i], a2 = tile[4 * cq + 2][p + 16 * i],
+                a3 = tile[4 * cq + 3][p + 16 * i];
+    T* dst = fp + (long)hw * C + c;
+    if (vec) {
+      store_vec4<T>(dst, a0, a1, a2, a3);
+    } else {
+      const float a[4] = {a0, a1, a2, a3};
+      for (int k = 0; k < 4 && c + k < C; ++k) store1<T>(dst + k, a[k]);
+    }
   }
 }
 
@@ -524,7 +539,7 @@ int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int 
                    void* stream) {
   if (!src_nchw || !feat || N_img <= 0 || C <= 0 || H <= 0 || W <= 0 || start < 0 || start + H * W > S) return MVG_E_BADARG;
   const int HW = H * W;
-  dim3 grid((HW + 31) / 32, (C + 31) / 32, N_img);
+  dim3 grid((HW + 63) / 64, (C + 63) / 64, N_img);
   if (dtype == MVG_F32)
     hipLaunchKernelGGL((pack_level_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src_nchw, (float*)feat, C, HW, S, start);
   else if (dtype == MVG_BF16)

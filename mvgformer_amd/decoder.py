@@ -164,6 +164,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.use_fused_chains = True    # bf16 inference: LDS-resident Linear chains (csrc/chain.hip)
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
+        self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
         # "no query valid anywhere -> force query (0,0)" rule (dq_decoder.py:620-623) global
         self._any_valid_hook = None
@@ -366,7 +367,7 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self._w("g3", (self.norm3.weight,), f32) if ffn else None,
                 self._w("b3", (self.norm3.bias,), f32) if ffn else None,
                 self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32),
-                threshold, B, NQ, J, forced, ffn)
+                threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out)
         else:
             mean = ops.mean_views(attn, V)
             u = ops.linear(mean, self._w("Wu", (self.feature_update_mlp.weight,), dt),
@@ -483,9 +484,14 @@ class DQDecoder(MvPDecoder):
             with torch.cuda.stream(side):
                 for layer in self.layers:
                     layer.proj_attn.project_values(ctx.feat, record_event=True)
+        # the fused chain writes every layer's hidden state straight into its slice of the stacked output
+        hs_buf = None
+        if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
+            hs_buf = torch.empty((len(self.layers),) + tuple(tgt.shape), dtype=torch.float32, device=tgt.device)
         try:
             for lid, layer in enumerate(self.layers):
                 layer._ctx = ctx
+                layer._tgt_out = None if hs_buf is None else hs_buf[lid]
                 output, reference_points, ref_points_2d, projs_2d_absolute, outputs_class = layer(
                     output, query_pos, reference_points[:, :, None] if reference_points.dim() == 3 else reference_points,
                     src_views, src_spatial_shapes, src_level_start_index, meta, src_padding_mask,
@@ -500,11 +506,15 @@ class DQDecoder(MvPDecoder):
         finally:
             for layer in self.layers:
                 layer._ctx = None
+                layer._tgt_out = None
                 layer.proj_attn._vp_event = None
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
         if self.return_intermediate:
-            return torch.stack(inter), torch.stack(inter_ref), torch.stack(inter_2d), torch.stack(inter_proj), classes
+            in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape
+                                                  for i, t in enumerate(inter))
+            hs = hs_buf if in_place else torch.stack(inter)
+            return hs, torch.stack(inter_ref), torch.stack(inter_2d), torch.stack(inter_proj), classes
         return output, reference_points, ref_points_2d
 
 

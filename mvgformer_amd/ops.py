@@ -289,12 +289,16 @@ def chain_masked_row_output(Wp, bp, W0, b0, W1, b1, W2, b2):
 
 
 def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
-                           forced_valid=None, has_ffn=True):
+                           forced_valid=None, has_ffn=True, tgt_out=None):
     """fused view-mean + update MLP + LN2 + FFN + LN3 + class head (weights in swizzle_weight order).
     Returns (tgt_update f32 (B*NQ*J,256), prob (B,NQ,2), valid (B,NQ) u8, any_valid int32[1])."""
     dev = attn.device
     rows = B * NQ * J
-    tgt_out = torch.empty((rows, 256), dtype=torch.float32, device=dev)
+    if tgt_out is None:
+        tgt_out = torch.empty((rows, 256), dtype=torch.float32, device=dev)
+    else:       # caller-owned destination (e.g. a slice of the stacked per-layer output)
+        assert tgt_out.dtype == torch.float32 and tgt_out.numel() == rows * 256 and tgt_out.is_contiguous()
+        tgt_out = tgt_out.view(rows, 256)
     prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
     valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
     any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
