@@ -333,21 +333,21 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xf, 0xf, false);
 }
 
-template <int L>
-__global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+template <int L, int NT>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
+__global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                             const float* __restrict__ xw, const float* __restrict__ r,
                                                             LevelTable lv, bf16_t* __restrict__ samp,
                                                             const uint8_t* __restrict__ pair_mask,
                                                             const int* __restrict__ order, int n_pairs,
                                                             int Lq, int S, int B) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 4;   // SCP: padded scratch row (76 for L=3)
-  __shared__ __attribute__((aligned(16))) float scratch[4][16][SCP];
+  __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = blockIdx.x & 7, sub = lane & 3, pl = lane >> 2;
   // The 4 lanes of a quad share one (pair, head) and every LDS scratch row is private to its quad, so lanes may
   // leave early (no workgroup barrier below): slots past the end, and pairs the caller masks out (reference
   // points outside the image: the consumer multiplies their rows by 0, dq_decoder.py:585-586) -- zero-filled.
-  const int slot = (blockIdx.x >> 3) * 64 + wave * 16 + pl;
+  const int slot = (blockIdx.x >> 3) * (NT / 4) + wave * 16 + pl;
   if (slot >= n_pairs) return;
   const int pair = order ? order[slot] : slot;
   if (pair_mask && !pair_mask[pair]) {
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(256, 3) void msda_gsamp_kernel(const bf16_t* __rest
 
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
 static int g_fused_nb = 4;         // tuning knob: samples per gather batch (4 or 8)
+static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
 static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r, const LevelTable& lv, T* samp,
@@ -682,18 +683,21 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   const long pairs = (long)N_img * Lq;
   if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
   if (pairs == 0) return 0;
-  const int grid = 8 * (int)((pairs + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
-#define MVG_GS(LL)                                                                                                \
-  hipLaunchKernelGGL((msda_gsamp_kernel<LL>), dim3(grid), dim3(256), 0, st, (const bf16_t*)vp, (const bf16_t*)G, xw, \
-                     ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S, B)
+#define MVG_GS(LL, NT)                                                                                            \
+  hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * (int)((pairs + NT / 4 - 1) / (NT / 4))), dim3(NT), 0, st, \
+                     (const bf16_t*)vp, (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order,       \
+                     (int)pairs, Lq, S, B)
+#define MVG_GSN(LL)                                                                                               \
+  if (g_gsamp_threads == 1024) MVG_GS(LL, 1024); else if (g_gsamp_threads == 512) MVG_GS(LL, 512); else MVG_GS(LL, 256)
   switch (L) {
-    case 1: MVG_GS(1); break;
-    case 2: MVG_GS(2); break;
-    case 3: MVG_GS(3); break;
-    case 4: MVG_GS(4); break;
+    case 1: MVG_GSN(1); break;
+    case 2: MVG_GSN(2); break;
+    case 3: MVG_GSN(3); break;
+    case 4: MVG_GSN(4); break;
     default: return MVG_E_BADARG;
   }
+#undef MVG_GSN
 #undef MVG_GS
   MVG_LAUNCH_CHECK();
   return 0;
@@ -711,6 +715,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
+  if (!strcmp(key, "gsamp_threads") && (value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
   return MVG_E_BADARG;
 }

@@ -165,6 +165,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
+        self._flag = None      # set by DQDecoder.forward: this layer's zeroed any-valid flag (int32[1])
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
         # "no query valid anywhere -> force query (0,0)" rule (dq_decoder.py:620-623) global
         self._any_valid_hook = None
@@ -367,7 +368,7 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self._w("g3", (self.norm3.weight,), f32) if ffn else None,
                 self._w("b3", (self.norm3.bias,), f32) if ffn else None,
                 self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32),
-                threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out)
+                threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out, any_valid=self._flag)
         else:
             mean = ops.mean_views(attn, V)
             u = ops.linear(mean, self._w("Wu", (self.feature_update_mlp.weight,), dt),
@@ -488,10 +489,12 @@ class DQDecoder(MvPDecoder):
         hs_buf = None
         if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
             hs_buf = torch.empty((len(self.layers),) + tuple(tgt.shape), dtype=torch.float32, device=tgt.device)
+        flags = torch.zeros((len(self.layers),), dtype=torch.int32, device=tgt.device) if tgt.is_cuda else None
         try:
             for lid, layer in enumerate(self.layers):
                 layer._ctx = ctx
                 layer._tgt_out = None if hs_buf is None else hs_buf[lid]
+                layer._flag = None if flags is None else flags[lid:lid + 1]
                 output, reference_points, ref_points_2d, projs_2d_absolute, outputs_class = layer(
                     output, query_pos, reference_points[:, :, None] if reference_points.dim() == 3 else reference_points,
                     src_views, src_spatial_shapes, src_level_start_index, meta, src_padding_mask,
@@ -507,6 +510,7 @@ class DQDecoder(MvPDecoder):
             for layer in self.layers:
                 layer._ctx = None
                 layer._tgt_out = None
+                layer._flag = None
                 layer.proj_attn._vp_event = None
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)

@@ -289,7 +289,7 @@ def chain_masked_row_output(Wp, bp, W0, b0, W1, b1, W2, b2):
 
 
 def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
-                           forced_valid=None, has_ffn=True, tgt_out=None):
+                           forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None):
     """fused view-mean + update MLP + LN2 + FFN + LN3 + class head (weights in swizzle_weight order).
     Returns (tgt_update f32 (B*NQ*J,256), prob (B,NQ,2), valid (B,NQ) u8, any_valid int32[1])."""
     dev = attn.device
@@ -301,7 +301,8 @@ def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be
         tgt_out = tgt_out.view(rows, 256)
     prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
     valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
-    any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    if any_valid is None:       # else: a caller-owned int32[1] that is already zero
+        any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
     with _timed("chain_update_ffn_class"):
       L.check(L.load().mvg_chain_update_ffn_class(
           L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
