@@ -49,6 +49,10 @@ def main():
                          "contains RCCL collectives)")
     ap.add_argument("--valid-fraction", type=float, default=None,
                     help="fraction of queries passing the 0.1 threshold (default: all valid = worst case)")
+    ap.add_argument("--producer", default="nchw", choices=["nchw", "nhwc", "inplace"],
+                    help="layout the feature pyramid is handed over in (SURVEY 8 f3): nchw = fp32 NCHW maps as the "
+                         "reference's backbone emits them (default, the headline configuration); nhwc = channels-last "
+                         "maps in the compute dtype; inplace = the producer wrote into DecoderContext.pyramid_buffers()")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -99,9 +103,17 @@ def main():
     # host-side, per-sample preparation that belongs to data loading (camera records)
     ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, 1, dev)
 
+    src_views = g.src_views
+    if args.producer == "nhwc":
+        src_views = [s.to(dtype).to(memory_format=torch.channels_last) for s in g.src_views]
+    elif args.producer == "inplace":
+        src_views = ctx.pyramid_buffers(channels=g.src_views[0].shape[1])
+        for dst, s in zip(src_views, g.src_views):
+            dst.copy_(s)
+
     def forward():
         ctx.feat = None
-        out = dec(tgt, ref, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None, query_pos=qpos,
+        out = dec(tgt, ref, src_views, g.meta, g.spatial_shapes, g.level_start_index, None, query_pos=qpos,
                   threshold=thr, context=ctx)
         if world > 1:
             out = mdist.gather_outputs(out, NQ, J, None, gather_hidden=False)
@@ -234,6 +246,9 @@ def main():
                    "%s: %d views, %d queries x %d joints, %d layers, ~%.0f%% queries valid"
                    % (args.config, V, NQ, J, Ly, 100 * args.valid_fraction),
                    "parallelism": "queries sharded x%d + all-gather" % world if world > 1 else "single GPU",
+                   "pyramid_handoff": {"nchw": "NCHW fp32 (reference producer format), packed per step",
+                                       "nhwc": "channels-last %s, copied per step" % args.dtype,
+                                       "inplace": "produced in the packed layout (no per-step pack)"}[args.producer],
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
     }

@@ -76,6 +76,7 @@ class DecoderContext:
     def __init__(self, levels, cams, V, B, dtype):
         self.levels, self.cams, self.V, self.B, self.dtype = levels, cams, V, B, dtype
         self.feat = None
+        self._buffer = None    # producer-owned packed pyramid (pyramid_buffers)
 
     @classmethod
     def prepare(cls, spatial_shapes, level_start_index, meta, img_size, dtype, batch_size, device):
@@ -87,8 +88,18 @@ class DecoderContext:
     def pack(self, src_views):
         if src_views[0].shape[0] != self.V * self.B:
             raise RuntimeError("meta describes %d images, src_views hold %d" % (self.V * self.B, src_views[0].shape[0]))
-        self.feat = ops.pack_pyramid(src_views, self.levels, self.dtype)
+        out = self._buffer if (self._buffer is not None and self._buffer.shape[0] == src_views[0].shape[0]) else None
+        self.feat = ops.pack_pyramid(src_views, self.levels, self.dtype, out=out)
         return self
+
+    def pyramid_buffers(self, channels=256, device=None):
+        """Producer hand-off: allocates the packed pyramid and returns its L levels as
+        (V*B, C, H_l, W_l) channels-last views in the compute dtype.  A backbone that writes its feature maps
+        into these tensors (or hands them back as ``src_views``) makes ``pack`` free: no 206-MB NCHW->channels-last
+        pass (projattn.py:160's cat + permute) per forward."""
+        dev = device if device is not None else self.cams.device
+        self._buffer = torch.empty((self.V * self.B, self.levels.S, channels), dtype=self.dtype, device=dev)
+        return ops.pyramid_level_views(self._buffer, self.levels)
 
     @classmethod
     def build(cls, src_views, spatial_shapes, level_start_index, meta, img_size, dtype, batch_size):

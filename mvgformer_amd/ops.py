@@ -113,19 +113,48 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
 
 
 # ----------------------------------------------------------------------------- stage ops
-def pack_pyramid(src_views, levels, dtype):
-    """list of L (N_img,C,H,W) fp32 maps -> channels-last pyramid (N_img,S,C) in `dtype`."""
+def pyramid_level_views(feat, levels):
+    """The L levels of a packed pyramid (n_img, S, C) as (n_img, C, H_l, W_l) tensors in channels-last strides --
+    what a producer (the backbone's last deconvolutions run in torch.channels_last) writes into so that
+    pack_pyramid has nothing left to do."""
+    n_img, _, Cc = feat.shape
+    views = []
+    for l in range(levels.L):
+        H, W = int(levels.shapes[l, 0]), int(levels.shapes[l, 1])
+        st = int(levels.starts[l])
+        views.append(feat[:, st:st + H * W, :].view(n_img, H, W, Cc).permute(0, 3, 1, 2))
+    return views
+
+
+def pack_pyramid(src_views, levels, dtype, out=None):
+    """list of L (N_img,C,H,W) maps -> channels-last pyramid (N_img,S,C) in `dtype`.
+
+    Per level, by layout of the producer's tensor:
+      * it IS the level view of `out` (pyramid_level_views) in `dtype`: produced in place, nothing to do;
+      * torch.channels_last memory format (fp32 / bf16 / fp16): one cast+copy, no transposition;
+      * NCHW (what the reference's backbone emits, pose_resnet.py:198-216): LDS-tiled transpose kernel."""
     lib = L.load()
     n_img, Cc = src_views[0].shape[:2]
-    feat = torch.empty((n_img, levels.S, Cc), dtype=dtype, device=src_views[0].device)
+    feat = out if out is not None else torch.empty((n_img, levels.S, Cc), dtype=dtype, device=src_views[0].device)
+    if tuple(feat.shape) != (n_img, levels.S, Cc) or feat.dtype != dtype or not feat.is_contiguous():
+        raise RuntimeError("pack_pyramid: out must be a contiguous (%d,%d,%d) %s tensor" % (n_img, levels.S, Cc, dtype))
+    dst_views = pyramid_level_views(feat, levels)
     for l, src in enumerate(src_views):
         L.require_cuda(src)
-        s = src.float().contiguous()
         H, W = int(levels.shapes[l, 0]), int(levels.shapes[l, 1])
-        if tuple(s.shape) != (n_img, Cc, H, W):
-            raise RuntimeError("src_views[%d] has shape %s, expected %s" % (l, tuple(s.shape), (n_img, Cc, H, W)))
-        L.check(lib.mvg_pack_level(L.ptr(s), L.ptr(feat), L.dtype_code(dtype), n_img, Cc, H, W, levels.S,
-                                   int(levels.starts[l]), L.stream_ptr()), "mvg_pack_level")
+        if tuple(src.shape) != (n_img, Cc, H, W):
+            raise RuntimeError("src_views[%d] has shape %s, expected %s" % (l, tuple(src.shape), (n_img, Cc, H, W)))
+        dst = dst_views[l]
+        if src.data_ptr() == dst.data_ptr() and src.stride() == dst.stride() and src.dtype == dtype:
+            continue
+        if src.is_contiguous(memory_format=torch.channels_last) and not src.is_contiguous():
+            with _timed("pack_level_nhwc"):
+                dst.copy_(src)
+            continue
+        s = src.float().contiguous()
+        with _timed("pack_level"):
+          L.check(lib.mvg_pack_level(L.ptr(s), L.ptr(feat), L.dtype_code(dtype), n_img, Cc, H, W, levels.S,
+                                     int(levels.starts[l]), L.stream_ptr()), "mvg_pack_level")
     return feat
 
 

@@ -550,3 +550,45 @@ def test_chain_a_row_order_and_masked_tile_skip():
         assert float((attn1.float() - attn0.float()).abs().max()) <= 2e-2 * float(attn0.float().abs().max())
         assert float((o1 - o0).abs().max()) <= 2e-3 * float(o0.abs().max())
         assert float((o1[inside == 0] - o_masked).abs().max()) <= 2e-3 * float(o0.abs().max())
+
+
+def test_pyramid_producer_handoff_layouts():
+    """the packed pyramid is identical whether the producer hands over NCHW fp32 maps
+    (transpose kernel), channels-last maps (cast + copy) or writes into the level views of the context's own
+    buffer (nothing to do) -- and the decoder output does not depend on the route."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_all")
+    gc = case_to_device(case, DEV)
+    for dt in (torch.bfloat16, torch.float32):
+        ctx = DecoderContext.prepare(gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size, dt, case.B, DEV)
+        a = ctx.pack(gc.src_views).feat.clone()
+        nhwc = [s.to(memory_format=torch.channels_last) for s in gc.src_views]
+        assert not nhwc[0].is_contiguous()
+        b = ctx.pack(nhwc).feat.clone()
+        bufs = ctx.pyramid_buffers(channels=gc.src_views[0].shape[1])
+        for dst, s in zip(bufs, gc.src_views):
+            dst.copy_(s)                                          # the "producer" writes its maps in place
+        ops.PROFILE = {}
+        try:
+            c = ctx.pack(bufs).feat
+            assert ops.PROFILE == {}, "in-place produced levels must not be copied"
+        finally:
+            ops.PROFILE = None
+        assert c.data_ptr() == ctx._buffer.data_ptr()
+        assert torch.equal(a, b) and torch.equal(a, c)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        ref = dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                  query_pos=gc.query_pos, threshold=0.1)
+        ctx = DecoderContext.prepare(gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size, torch.bfloat16,
+                                     case.B, DEV)
+        bufs = ctx.pyramid_buffers(channels=gc.src_views[0].shape[1])
+        for dst, s in zip(bufs, gc.src_views):
+            dst.copy_(s)
+        ctx.pack(bufs)
+        out = dec(gc.tgt, gc.reference_points, bufs, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                  query_pos=gc.query_pos, threshold=0.1, context=ctx)
+    for x, y in zip(ref[:4], out[:4]):
+        assert torch.equal(x, y)
