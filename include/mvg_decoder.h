@@ -185,13 +185,18 @@ int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp,
  *   prob = mean_j sigmoid(Wc tgt' + bc);  valid = prob[...,1] > threshold (or forced_valid).
  * attn (V, B*NQ*J, 256) bf16; tgt/tgt_out (B*NQ*J, 256) f32; Wu (256,256), W1 (1024,256), W2 (256,1024) bf16
  * in the fragment order of csrc/chain.hip (mvgformer_amd.ops.swizzle_weight); LN params / biases f32;
- * any_valid must be zeroed by the caller.  Replaces mean_views + 3 linears + 2 add_layernorm + class_head. */
+ * any_valid must be zeroed by the caller.  Replaces mean_views + 3 linears + 2 add_layernorm + class_head.
+ * Optional tail (W_next != NULL): xw_next (B*NQ*J, n_next) f32 = (tgt' + query_pos) @ W_next^T + b_next, the query
+ * term of the NEXT layer's offsets/logits Linear (the xw operand of mvg_msda_gsamp), computed while the rows are in
+ * LDS.  W_next: (256,256) bf16 fragment order, rows >= n_next zero; b_next: 256 f32 (zero padded); query_pos
+ * (B*NQ*J, 256) f32 or NULL; n_next <= 256, multiple of 4. */
 int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,
                                const float* g2, const float* be2, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g3, const float* be3,
                                const float* Wc, const float* bc, float threshold,
                                const uint8_t* forced_valid, float* tgt_out, float* prob, uint8_t* valid,
-                               int* any_valid, int B, int NQ, int J, int has_ffn, void* stream);
+                               int* any_valid, const float* query_pos, const void* W_next, const float* b_next,
+                               float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream);
 
 /* A.6-A.8 (dq_decoder.py:659-717,399-461,119-246,1013-1029; multiview.py:170-269):
  * 2D refinement, view-softmax confidence, un-crop, 5-iteration undistortion, DLT rows,

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     const float* __restrict__ b2, const float* __restrict__ g3, const float* __restrict__ be3,
     const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
     float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
-    int rows, int J, int nq_total, int has_ffn) {
+    const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
+    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
   constexpr int RM = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                       // RM x 256 bf16 : GEMM operand (mean, then t1)
@@ -390,6 +391,14 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       y = d * rstd * *reinterpret_cast<const f32x4*>(g3 + lane * 4) + *reinterpret_cast<const f32x4*>(be3 + lane * 4);
     }
     if (row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + lane * 4) = y;
+    if (Wn) {   // operand of the next layer's query-term GEMM: tgt' + query_pos (bf16), into the now free act tile
+      f32x4 x = y;
+      if (qpos && row < nrow) x += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + row) * 256 + lane * 4);
+      uint2 pk;
+      pk.x = (unsigned)f32_to_bf16(x[0]) | ((unsigned)f32_to_bf16(x[1]) << 16);
+      pk.y = (unsigned)f32_to_bf16(x[2]) | ((unsigned)f32_to_bf16(x[3]) << 16);
+      *reinterpret_cast<uint2*>(act + row * ACT_PITCH + lane * 8) = pk;
+    }
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + lane * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + lane * 4);
     const float a0 = wsum(y[0] * w0[0] + y[1] * w0[1] + y[2] * w0[2] + y[3] * w0[3]) + bc[0];
     const float a1 = wsum(y[0] * w1[0] + y[1] * w1[1] + y[2] * w1[2] + y[3] * w1[3]) + bc[1];
@@ -413,6 +422,18 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     const bool ok = forced ? (forced[qi] != 0) : (p1 > threshold);                   // dq_decoder.py:605
     valid[qi] = ok ? 1 : 0;
     if (ok) atomicOr(any_valid, 1);
+  }
+  if (Wn) {
+    // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets/logits Linear
+    //      (projattn.py:180-181), computed while the rows are still in LDS (saves a 15 360-row GEMM launch and the
+    //      elementwise add per layer).  The barrier above ordered the act writes and the last xb reads.
+    stage_gemm<MT, 16, BRING>(act, Wn, acc, tid, true, rot + 7);
+    acc_to_x<MT>(xb, acc, bn, false, tid);
+    __syncthreads();
+    for (int row = wave; row < nrow; row += NW)
+      if (lane * 4 < n_next)
+        *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + row) * n_next + lane * 4) =
+            *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
   }
 }
 
@@ -459,11 +480,14 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
                                           const float* g2, const float* be2, const void* W1, const float* b1,
                                           const void* W2, const float* b2, const float* g3, const float* be3,
                                           const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
-                                          float* tgt_out, float* prob, uint8_t* valid, int* any_valid, int B, int NQ,
-                                          int J, int has_ffn, void* stream) {
+                                          float* tgt_out, float* prob, uint8_t* valid, int* any_valid,
+                                          const float* query_pos, const void* W_next, const float* b_next,
+                                          float* xw_next, int n_next, int B, int NQ, int J, int has_ffn,
+                                          void* stream) {
   if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
   if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
   if (V <= 0 || J <= 0 || J > 64 || B < 0 || NQ < 0) return MVG_E_BADARG;
+  if (W_next && (!b_next || !xw_next || n_next <= 0 || n_next > 256 || n_next % 4 != 0)) return MVG_E_BADARG;
   const int nq_total = B * NQ, rows = nq_total * J;
   if (rows == 0) return 0;
   const int qpt = 64 / J;
@@ -481,7 +505,8 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
 #define MVG_CB(R, NTH)                                                                                                  \
   hipLaunchKernelGGL((chain_b_kernel<R, NTH>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
                      (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc,     \
-                     threshold, forced_valid, tgt_out, prob, valid, any_valid, rows, J, nq_total, has_ffn)
+                     threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next,  \
+                     n_next, rows, J, nq_total, has_ffn)
   if (g_chain_waves == 8) MVG_CB(4, 512);
   else MVG_CB(4, 256);
 #undef MVG_CB

@@ -177,6 +177,8 @@ class DQDecoderLayer(MvPDecoderLayer):
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
         self._flag = None      # set by DQDecoder.forward: this layer's zeroed any-valid flag (int32[1])
+        self._next_layer = None   # set by DQDecoder.forward: the layer that consumes this layer's output
+        self._xw_in = None        # set by the previous layer: this layer's query term (B*Lq,192) f32
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
         # "no query valid anywhere -> force query (0,0)" rule (dq_decoder.py:620-623) global
         self._any_valid_hook = None
@@ -321,7 +323,10 @@ class DQDecoderLayer(MvPDecoderLayer):
         # 1. projective attention features of every view (generate_features, dq_decoder.py:516-593)
         X = reference_points.detach().reshape(B, Lq, 3).float().contiguous()
         r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
-        x = self.with_pos_embed(tgt.float(), None if query_pos is None else query_pos.float()).contiguous()
+        x = lambda: self.with_pos_embed(tgt.float(), None if query_pos is None else query_pos.float()).contiguous()
+        xw_in, self._xw_in = self._xw_in, None     # query term computed by the previous layer's chain B (or None)
+        if xw_in is not None and tuple(xw_in.shape) != (B * Lq, 192):
+            xw_in = None
         f32 = torch.float32
         pose_layers = self.pose_embed.MLP.layers
         fuse_a = (dt == torch.bfloat16 and self.use_fused_chains and len(pose_layers) == 3 and
@@ -340,7 +345,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             elif mode:
                 order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
-                                                order=order)
+                                                order=order, xw=xw_in)
             sw = lambda w: ops.swizzle_weight(w.to(dt))
             wts = (self._w("Wp_sw", (self.proj_attn.output_proj.weight,), dt, sw),
                    self._w("bp", (self.proj_attn.output_proj.bias,), f32),
@@ -351,7 +356,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
             attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
-            attn = self.proj_attn.native_forward(x, ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
+            attn = self.proj_attn.native_forward(x(), ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
 
         # 2.+3. update the query features (update_feature 'MLP', dq_decoder.py:763-778 + forward_ffn),
         #       class head + filter (dq_decoder.py:889-908)
@@ -368,7 +373,15 @@ class DQDecoderLayer(MvPDecoderLayer):
         if fuse_b:
             sw = lambda w: ops.swizzle_weight(w.to(dt))
             ffn = self.open_forward_ffn
-            tgt_update, prob, valid, any_valid = ops.chain_update_ffn_class(
+            # the next layer's query term xw = (tgt' + query_pos) W^T + b rides on this chain (its rows are in LDS)
+            nxt = self._next_layer[0] if self._next_layer else None     # (kept in a tuple: not a sub-module)
+            next_proj = None
+            if (nxt is not None and nxt.compute_dtype == dt and nxt.use_fused_chains and nxt.proj_attn.uses_fast_path(dt)
+                    and (query_pos is None or query_pos.shape == tgt.shape)):
+                Wn, bn, n_next = nxt.proj_attn.query_term_weights(dt)
+                qp = None if query_pos is None else query_pos.float().reshape(B * Lq, C).contiguous()
+                next_proj = (qp, Wn, bn, n_next)
+            res = ops.chain_update_ffn_class(
                 attn, V, tgt32,
                 self._w("Wu_sw", (self.feature_update_mlp.weight,), dt, sw), self._w("bu", (self.feature_update_mlp.bias,), f32),
                 self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
@@ -379,7 +392,10 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self._w("g3", (self.norm3.weight,), f32) if ffn else None,
                 self._w("b3", (self.norm3.bias,), f32) if ffn else None,
                 self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32),
-                threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out, any_valid=self._flag)
+                threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
+            tgt_update, prob, valid, any_valid = res[:4]
+            if next_proj is not None:
+                nxt._xw_in = res[4]
         else:
             mean = ops.mean_views(attn, V)
             u = ops.linear(mean, self._w("Wu", (self.feature_update_mlp.weight,), dt),
@@ -454,6 +470,8 @@ class DQDecoder(MvPDecoder):
         # kernels already saturate the L2/fabric, so the overlap buys nothing; kept as an option
         self.overlap_value_projection = False
         self._side_stream = None
+        # layer l's fused chain B also computes layer l+1's query term xw = (tgt' + query_pos) W^T + b (bf16 path)
+        self.fuse_next_query_term = True
 
     def set_compute_dtype(self, dtype):
         for layer in self.layers:
@@ -506,6 +524,8 @@ class DQDecoder(MvPDecoder):
                 layer._ctx = ctx
                 layer._tgt_out = None if hs_buf is None else hs_buf[lid]
                 layer._flag = None if flags is None else flags[lid:lid + 1]
+                layer._next_layer = ((self.layers[lid + 1],) if (self.fuse_next_query_term and lid + 1 < len(self.layers))
+                                     else None)
                 output, reference_points, ref_points_2d, projs_2d_absolute, outputs_class = layer(
                     output, query_pos, reference_points[:, :, None] if reference_points.dim() == 3 else reference_points,
                     src_views, src_spatial_shapes, src_level_start_index, meta, src_padding_mask,
@@ -522,6 +542,8 @@ class DQDecoder(MvPDecoder):
                 layer._ctx = None
                 layer._tgt_out = None
                 layer._flag = None
+                layer._next_layer = None
+                layer._xw_in = None
                 layer.proj_attn._vp_event = None
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)

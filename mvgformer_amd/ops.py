@@ -318,7 +318,7 @@ def chain_masked_row_output(Wp, bp, W0, b0, W1, b1, W2, b2):
 
 
 def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
-                           forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None):
+                           forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None):
     """fused view-mean + update MLP + LN2 + FFN + LN3 + class head (weights in swizzle_weight order).
     Returns (tgt_update f32 (B*NQ*J,256), prob (B,NQ,2), valid (B,NQ) u8, any_valid int32[1])."""
     dev = attn.device
@@ -330,13 +330,26 @@ def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be
         tgt_out = tgt_out.view(rows, 256)
     prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
     valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
+    # next_query_proj = (query_pos (rows,256) f32 | None, W_next fragments (256,256) bf16, b_next (256,) f32, n_next):
+    # also emit xw_next = (tgt' + query_pos) @ W_next^T + b_next for the next layer's sampler
+    qpos = Wn = bn = xw_next = None
+    n_next = 0
+    if next_query_proj is not None:
+        qpos, Wn, bn, n_next = next_query_proj
+        assert Wn.dtype == torch.bfloat16 and Wn.numel() == 256 * 256 and bn.numel() == 256 and bn.dtype == torch.float32
+        if qpos is not None:
+            assert qpos.dtype == torch.float32 and qpos.numel() == rows * 256 and qpos.is_contiguous()
+        xw_next = torch.empty((rows, n_next), dtype=torch.float32, device=dev)
     if any_valid is None:       # else: a caller-owned int32[1] that is already zero
         any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
     with _timed("chain_update_ffn_class"):
       L.check(L.load().mvg_chain_update_ffn_class(
           L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
           L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out), L.ptr(prob),
-          L.ptr(valid), L.ptr(any_valid), B, NQ, J, 1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class")
+          L.ptr(valid), L.ptr(any_valid), L.ptr(qpos), L.ptr(Wn), L.ptr(bn), L.ptr(xw_next), n_next, B, NQ, J,
+          1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class")
+    if next_query_proj is not None:
+        return tgt_out, prob, valid, any_valid, xw_next
     return tgt_out, prob, valid, any_valid
 
 

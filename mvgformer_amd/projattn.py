@@ -156,14 +156,32 @@ class ProjAttn(nn.Module):
         _, _, _, _, Wp, bp = self.weights(feat.dtype)
         return ops.linear(samp, Wp, bp, out_dtype=feat.dtype, rowmask=rowmask)   # projattn.py:203 (+ dq_decoder.py:585)
 
-    def native_sample(self, x, r, feat, levels, V, B, pair_mask=None, order=None):
+    def uses_fast_path(self, dt):
+        return (dt == torch.bfloat16 and self.use_fast_path and
+                self.sampling_offsets.out_features + self.attention_weights.out_features == 192)
+
+    def query_term_weights(self, dt):
+        """operands of xw = (tgt + query_pos) @ [Woff; Wattn]^T + b as the fused chain B of the PREVIOUS layer takes
+        them: (weight fragments (256,256) bf16 zero-padded, bias (256,) f32 zero-padded, n = 192)."""
+        pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
+                                              .to(dt))
+        Wf = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
+        bpad = lambda a, b: torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0])], 0)
+        bn = self._wc.get("boa_pad", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, bpad)
+        return Wf, bn, self.sampling_offsets.out_features + self.attention_weights.out_features
+
+    def native_sample(self, x, r, feat, levels, V, B, pair_mask=None, order=None, xw=None):
         """everything of native_forward up to (not including) output_proj: (V*B*Lq, C) sampled values.
+        x (B,Lq,C) f32 = tgt + query_pos, or a callable returning it (only evaluated when needed: with xw given --
+        the query term (B*Lq,192) precomputed by the previous layer -- the bf16 fast path never touches x).
         pair_mask (V*B*Lq) u8: rows the caller is going to multiply by 0 (reference point outside the image,
         dq_decoder.py:585-586); the bf16 fast path returns zeros for them instead of sampling."""
         dt = feat.dtype
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
-        if dt == torch.bfloat16 and self.use_fast_path and Woa.shape[0] == 192:
+        if callable(x) and not (self.uses_fast_path(dt) and xw is not None):
+            x = x()
+        if self.uses_fast_path(dt):
             # Linear(bilinear(feat) + x) = bilinear(Linear(feat)) + Linear(x): project the pyramid once (G), compute
             # the query term once per layer (xw), gather offsets/logits inside the sampler (csrc/msda.hip)
             pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
@@ -172,7 +190,8 @@ class ProjAttn(nn.Module):
             # processing order of the pairs: given by the caller (DQDecoderLayer shares it with chain A) or binned here
             if order is None and self.sort_pairs and r.shape[1] <= 65536:
                 order = ops.bin_pairs(r, pair_mask, levels)
-            xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
+            if xw is None:      # else: already computed by the previous layer's fused chain B
+                xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
             # the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is the
             # freshest resident of the 256-MB Infinity Cache when the sampler starts
             vp = self.project_values(feat) if self._vp_event is None else self._wait_values()

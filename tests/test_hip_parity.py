@@ -592,3 +592,32 @@ def test_pyramid_producer_handoff_layouts():
                   query_pos=gc.query_pos, threshold=0.1, context=ctx)
     for x, y in zip(ref[:4], out[:4]):
         assert torch.equal(x, y)
+
+
+def test_next_layer_query_term_fused_into_chain_b():
+    """layer l's chain B emits layer l+1's query term xw = (tgt' + query_pos) W^T + b: same decoder outputs as the
+    standalone add + GEMM (identical bf16 rounding of the operand, different fp32 accumulation order)."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_b2")
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    assert len(dec.layers) >= 2
+    outs = []
+    with torch.no_grad():
+        for fuse in (True, False):
+            dec.fuse_next_query_term = fuse
+            outs.append(dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index,
+                            None, query_pos=gc.query_pos, threshold=0.1))
+    a, b = outs
+    assert float((a[0] - b[0]).abs().max()) < 2e-2 * float(b[0].abs().max())          # hidden states
+    assert float((a[1] - b[1]).abs().max()) < 1.0                                      # 3D points, mm
+    assert torch.equal(a[1] == 0, b[1] == 0)
+    # without query_pos the fused operand is tgt' alone
+    with torch.no_grad():
+        dec.fuse_next_query_term = True
+        c = dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                query_pos=None, threshold=0.1)
+        dec.fuse_next_query_term = False
+        d = dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                query_pos=None, threshold=0.1)
+    assert float((c[0] - d[0]).abs().max()) < 2e-2 * float(d[0].abs().max())

@@ -80,6 +80,25 @@ with torch.no_grad():
             keep = msk.bool() if "pair_mask" in kw else torch.ones_like(msk).bool()
             same = bool((o2[keep] == outp[keep]).all()) and bool((o2[~keep] == 0).all())
             print("%-28s %8.1f us  %7.1f GB/s algorithmic   identical rows: %s" % (tag, us, bytes_launch / us / 1e3, same))
+        # locality probes: where does the time go when (a) every pair samples the same place (all L1 hits), (b) the
+        # reference points are uniformly random (sorted / unsorted)?
+        def timed(tag, rr, **kw):
+            for _ in range(3):
+                ops.msda_gsamp(vp, G, xw, rr, ctx.levels, 1, **kw)
+            torch.cuda.synchronize()
+            s_.record()
+            for _ in range(20):
+                ops.msda_gsamp(vp, G, xw, rr, ctx.levels, 1, **kw)
+            e_.record()
+            torch.cuda.synchronize()
+            print("%-28s %8.1f us" % (tag, s_.elapsed_time(e_) / 20 * 1e3))
+        same = torch.full_like(ref_lvl, 0.5)
+        timed("  probe: all pairs at (.5,.5)", same)
+        rnd = torch.rand_like(ref_lvl[:, :, :1, :]).expand_as(ref_lvl).contiguous()
+        timed("  probe: random refs", rnd)
+        timed("  probe: random refs, sorted", rnd, order=ops.bin_pairs(rnd, None, ctx.levels))
+        half = ref_lvl.clone(); half[:, :, :, :] = ref_lvl[:, :1, :, :] * 0 + torch.rand_like(ref_lvl[:, :, :1, :]) * 0.25 + 0.3
+        timed("  probe: refs in a 1/16 window", half.contiguous())
         s_.record()
         for _ in range(20):
             ops.bin_pairs(ref_lvl, msk, ctx.levels)
