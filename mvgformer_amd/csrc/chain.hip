@@ -39,28 +39,49 @@ constexpr int ACT_PITCH = 528;   // bytes per activation row in LDS (256 bf16 + 
 // load latency, MFMA utilisation 13 %); with a per-workgroup rotation the requests spread over the
 // whole weight at any instant.  (fp32 accumulation order changes with rot: results agree with the
 // unfused kernels to fp32 rounding, not bit for bit.)
-template <int MT, int KSTEPS, int RING = 4>
+// Wave -> sub-tile mapping of a stage (JN = 32-column blocks per wavefront):
+//   JN = 2: wave w owns columns [64 (w&3), +64) of row block (w>>2) -- 4 waves cover the 256 columns, 8 waves two
+//           row blocks (both groups stream the SAME weight fragments: twice the L2->L1 traffic);
+//   JN = 1: wave w owns columns [32 w, +32) of ALL MT row blocks -- 8 waves, every weight fragment is loaded by
+//           exactly one wave (chain B: 641 -> 350 MB through the L1 miss path per launch).
+template <int JN>
+struct WaveMap {
+  int wn, j0, row0;
+  __device__ __forceinline__ WaveMap(int tid, int mt_rows) {
+    if (JN == 2) {
+      wn = (tid >> 6) & 3;
+      j0 = 0;
+      row0 = (tid >> 8) * mt_rows;
+    } else {
+      wn = (tid >> 7) & 3;
+      j0 = (tid >> 6) & 1;
+      row0 = 0;
+    }
+  }
+};
+
+template <int MT, int KSTEPS, int RING = 4, int JN = 2>
 __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const bf16_t* __restrict__ Wf,
-                                           f32x16 (&acc)[MT][2], int tid, bool zero, int rot,
+                                           f32x16 (&acc)[MT][JN], int tid, bool zero, int rot,
                                            int wn_stride = KSTEPS * 1024) {
   static_assert((KSTEPS & (KSTEPS - 1)) == 0, "KSTEPS must be a power of two");
-  // 4 column slices (wn) x NRB row blocks of MT*32 rows: waves 0-3 take rows [0, MT*32), waves 4-7 the next block
-  const int lane = tid & 63, wn = (tid >> 6) & 3, row0 = (tid >> 8) * MT * 32, rl = lane & 31, h = lane >> 5;
+  const WaveMap<JN> wm(tid, MT * 32);
+  const int lane = tid & 63, rl = lane & 31, h = lane >> 5, row0 = wm.row0;
   if (zero) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < JN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mt][j][e] = 0.f;
   }
-  const bf16_t* wp = Wf + (long)wn * wn_stride + lane * 8;   // wn_stride: elements between the wave slices
-  f32x4 ring[RING][2];
+  const bf16_t* wp = Wf + (long)wm.wn * wn_stride + wm.j0 * 512 + lane * 8;   // wn_stride: elements between the wave slices
+  f32x4 ring[RING][JN];
 #pragma unroll
   for (int p = 0; p < RING; ++p) {
     const int kq = (p + rot) & (KSTEPS - 1);
-    ring[p][0] = *reinterpret_cast<const f32x4*>(wp + kq * 1024);
-    ring[p][1] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + 512);
+#pragma unroll
+    for (int j = 0; j < JN; ++j) ring[p][j] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + j * 512);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -70,19 +91,20 @@ __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const b
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       a[mt] = *reinterpret_cast<const f32x4*>(act + (row0 + mt * 32 + rl) * ACT_PITCH + kc * 32 + 16 * h);
-    const f32x4 b0 = ring[ks % RING][0], b1 = ring[ks % RING][1];
+    f32x4 b[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) b[j] = ring[ks % RING][j];
     if (ks + RING < KSTEPS) {
       const int kq = (ks + RING + rot) & (KSTEPS - 1);
-      ring[ks % RING][0] = *reinterpret_cast<const f32x4*>(wp + kq * 1024);
-      ring[ks % RING][1] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + 512);
+#pragma unroll
+      for (int j = 0; j < JN; ++j) ring[ks % RING][j] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + j * 512);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, a[mt]),
-                                                          acc[mt][0], 0, 0, 0);
-      acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, a[mt]),
-                                                          acc[mt][1], 0, 0, 0);
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < JN; ++j)
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[mt]),
+                                                            acc[mt][j], 0, 0, 0);
     // pin the k-step: without this hipcc sinks the ring refills down to their uses (issue -> vmcnt(0)
     // -> MFMA in the same step, i.e. no prefetch distance at all; measured MFMA utilisation 13 %)
     __builtin_amdgcn_sched_barrier(0);
@@ -91,15 +113,16 @@ __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const b
 
 // acc (+bias, relu, row keep-mask) -> bf16 activation tile in LDS, IN PLACE: the caller puts a
 // __syncthreads() before (every wave finished reading `act`) and after (next stage may read).
-template <int MT>
-__device__ __forceinline__ void write_act(char* __restrict__ act, const f32x16 (&acc)[MT][2],
+template <int MT, int JN = 2>
+__device__ __forceinline__ void write_act(char* __restrict__ act, const f32x16 (&acc)[MT][JN],
                                           const float* __restrict__ bias, bool relu, const bool (&keep)[MT], int tid) {
-  const int lane = tid & 63, wn = (tid >> 6) & 3, row0 = (tid >> 8) * MT * 32, rl = lane & 31, h = lane >> 5;
+  const WaveMap<JN> wm(tid, MT * 32);
+  const int lane = tid & 63, rl = lane & 31, h = lane >> 5, row0 = wm.row0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = wn * 64 + j * 32 + 8 * g + 4 * h;
+      const int n = wm.wn * 64 + (wm.j0 + j) * 32 + 8 * g + 4 * h;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -259,16 +282,26 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 
+// sum over the 8 lanes of a lane group (lanes 8g .. 8g+7), result in all of them: 3 DPP adds (quad_perm xor 1,
+// quad_perm xor 2, row_half_mirror) instead of the 6 ds_bpermute round trips of a 64-lane butterfly
+__device__ __forceinline__ float sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+  return v;
+}
+
 // acc (+bias) -> fp32 LDS tile xb[row][n] (add = accumulate onto what is there)
-template <int MT>
-__device__ __forceinline__ void acc_to_x(char* __restrict__ xb, const f32x16 (&acc)[MT][2], const float* __restrict__ bias,
+template <int MT, int JN = 2>
+__device__ __forceinline__ void acc_to_x(char* __restrict__ xb, const f32x16 (&acc)[MT][JN], const float* __restrict__ bias,
                                          bool add, int tid) {
-  const int lane = tid & 63, wn = (tid >> 6) & 3, row0 = (tid >> 8) * MT * 32, rl = lane & 31, h = lane >> 5;
+  const WaveMap<JN> wm(tid, MT * 32);
+  const int lane = tid & 63, rl = lane & 31, h = lane >> 5, row0 = wm.row0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = wn * 64 + j * 32 + 8 * g + 4 * h;
+      const int n = wm.wn * 64 + (wm.j0 + j) * 32 + 8 * g + 4 * h;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -281,7 +314,7 @@ __device__ __forceinline__ void acc_to_x(char* __restrict__ xb, const f32x16 (&a
     }
 }
 
-template <int BRING, int NT>
+template <int BRING, int NT, int JN>
 __global__ __launch_bounds__(NT) void chain_b_kernel(
     const bf16_t* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu,
     const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
@@ -297,112 +330,197 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   char* hbuf = smem + RM * ACT_PITCH;     // RM x 256 bf16 : FFN hidden chunk
   char* xb = hbuf + RM * ACT_PITCH;       // RM x 256 fp32 : pre-LN sums / t1 / tgt'
   float* pr = reinterpret_cast<float*>(xb + RM * XP);   // RM x 2 per-row class probabilities
-  constexpr int MT = 2 / (NT / 256), NW = NT / 64;
+  constexpr int MT = (JN == 1) ? 2 : 2 / (NT / 256), NW = NT / 64;   // JN = 1: every wave covers both row blocks
+  static_assert(JN == 2 || NT == 512, "column-split mapping needs 8 wavefronts");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qpt = RM / J;                                // queries per tile (4 for J = 15)
   const int rpt = qpt * J;                               // real rows per tile (60)
   const int q0 = blockIdx.x * qpt, r0 = q0 * J;
   const int nrow = min(rpt, rows - r0);
-  const int rot = (blockIdx.x * 7 + (wave & 3) * 3) & 15;
+  const int rot = (blockIdx.x * 7 + (JN == 1 ? wave : (wave & 3)) * 3) & 15;
 
-  // ---- mean over views (dq_decoder.py:770) -> act (bf16)
+  // Row phases (LayerNorms, class head): 8 lanes per row, a wavefront works on 8 rows at once; lane (g = lane>>3,
+  // part = lane&7) holds the 8 channel quads part, part+8, ..., part+56 of row  wave*8 + g (+ 8*NW per pass), so a
+  // row statistic is a 32-value local sum + a 3-step DPP reduction, and no loop over rows serialises memory or
+  // cross-lane latencies.  tgt is fetched here, long before its use.
+  constexpr int RPASS = RM / (8 * NW);                  // 1 with 8 wavefronts, 2 with 4
+  const int rgrp = lane >> 3, part = lane & 7;
+  f32x4 tg[RPASS][8];
+#pragma unroll
+  for (int ps = 0; ps < RPASS; ++ps)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      tg[ps][i] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(ps * 8 * NW + wave * 8 + rgrp, nrow - 1)) * 256 +
+                                                  (part + 8 * i) * 4);
+
+  // ---- mean over views (dq_decoder.py:770) -> act (bf16); two 16-byte chunks per thread and pass, 16 loads in flight
   {
     const float inv = 1.f / (float)V;
+    constexpr int NCHUNK = RM * 32 / NT;
+    static_assert(NCHUNK % 2 == 0, "chunks are processed in pairs");
 #pragma unroll 1
-    for (int i = 0; i < RM * 32 / NT; ++i) {
-      const int c = i * NT + tid, row = c >> 5, v16 = c & 31;
-      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const long off = (long)(r0 + min(row, nrow - 1)) * 256 + v16 * 8;
-      // views in groups of 8 with all loads of a group in flight (clamped index + zero weight instead
-      // of a guard: a guarded load makes hipcc wait vmcnt(0) per element)
+    for (int i = 0; i < NCHUNK; i += 2) {
+      float s[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s[u][t] = 0.f;
+      long off[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = (i + u) * NT + tid;
+        off[u] = (long)(r0 + min(c >> 5, nrow - 1)) * 256 + (c & 31) * 8;
+      }
+      // views in groups of 8 (clamped index + zero weight instead of a guard: a guarded load makes hipcc wait
+      // vmcnt(0) per element)
       for (int v0 = 0; v0 < V; v0 += 8) {
-        uint4 x[8];
+        uint4 x[2][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          x[k] = *reinterpret_cast<const uint4*>(attn + (long)min(v0 + k, V - 1) * rows * 256 + off);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float wv = (v0 + k < V) ? 1.f : 0.f;
-          const unsigned w4[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+          for (int k = 0; k < 8; ++k)
+            x[u][k] = *reinterpret_cast<const uint4*>(attn + (long)min(v0 + k, V - 1) * rows * 256 + off[u]);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            s[2 * t] = fmaf(wv, __uint_as_float(w4[t] << 16), s[2 * t]);
-            s[2 * t + 1] = fmaf(wv, __uint_as_float(w4[t] & 0xffff0000u), s[2 * t + 1]);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float wv = (v0 + k < V) ? 1.f : 0.f;
+            const unsigned w4[4] = {x[u][k].x, x[u][k].y, x[u][k].z, x[u][k].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              s[u][2 * t] = fmaf(wv, __uint_as_float(w4[t] << 16), s[u][2 * t]);
+              s[u][2 * t + 1] = fmaf(wv, __uint_as_float(w4[t] & 0xffff0000u), s[u][2 * t + 1]);
+            }
           }
-        }
       }
-      uint4 o;
-      unsigned* op = reinterpret_cast<unsigned*>(&o);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float a = row < nrow ? s[2 * t] * inv : 0.f, b = row < nrow ? s[2 * t + 1] * inv : 0.f;
-        op[t] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+      for (int u = 0; u < 2; ++u) {
+        const int c = (i + u) * NT + tid, row = c >> 5, v16 = c & 31;
+        uint4 o;
+        unsigned* op = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float a = row < nrow ? s[u][2 * t] * inv : 0.f, b = row < nrow ? s[u][2 * t + 1] * inv : 0.f;
+          op[t] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+        }
+        *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = o;
       }
-      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = o;
     }
   }
   __syncthreads();
 
   // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
-  f32x16 acc[MT][2];
-  stage_gemm<MT, 16, BRING>(act, Wu, acc, tid, true, rot);
-  acc_to_x<MT>(xb, acc, bu, false, tid);
+  f32x16 acc[MT][JN];
+  stage_gemm<MT, 16, BRING, JN>(act, Wu, acc, tid, true, rot);
+  acc_to_x<MT, JN>(xb, acc, bu, false, tid);
   __syncthreads();
-  for (int row = wave; row < RM; row += NW) {           // one wavefront per row, 4 channels per lane
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
-    if (row < nrow) v += *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + row) * 256 + lane * 4);
-    const float mean = wsum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
-    const f32x4 d = v - mean;
-    const float rstd = 1.f / sqrtf(wsum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f) + 1e-5f);
-    const f32x4 y = d * rstd * *reinterpret_cast<const f32x4*>(g2 + lane * 4) + *reinterpret_cast<const f32x4*>(be2 + lane * 4);
-    *reinterpret_cast<f32x4*>(xb + row * XP + lane * 16) = y;                       // t1 (fp32, residual)
-    uint2 pk;
-    pk.x = (unsigned)f32_to_bf16(y[0]) | ((unsigned)f32_to_bf16(y[1]) << 16);
-    pk.y = (unsigned)f32_to_bf16(y[2]) | ((unsigned)f32_to_bf16(y[3]) << 16);
-    *reinterpret_cast<uint2*>(act + row * ACT_PITCH + lane * 8) = pk;               // t1 (bf16, GEMM operand)
+#pragma unroll
+  for (int ps = 0; ps < RPASS; ++ps) {
+    const int row = ps * 8 * NW + wave * 8 + rgrp;
+    f32x4 v[8];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = *reinterpret_cast<const f32x4*>(xb + row * XP + (part + 8 * i) * 16);
+      if (row < nrow) v[i] += tg[ps][i];
+      sm += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = sum8(sm) * (1.f / 256.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = v[i] - mean;
+      sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+    const float rstd = 1.f / sqrtf(sum8(sq) * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = part + 8 * i;
+      const f32x4 y = v[i] * rstd * *reinterpret_cast<const f32x4*>(g2 + c4 * 4) + *reinterpret_cast<const f32x4*>(be2 + c4 * 4);
+      *reinterpret_cast<f32x4*>(xb + row * XP + c4 * 16) = y;                         // t1 (fp32, residual)
+      uint2 pk;
+      pk.x = (unsigned)f32_to_bf16(y[0]) | ((unsigned)f32_to_bf16(y[1]) << 16);
+      pk.y = (unsigned)f32_to_bf16(y[2]) | ((unsigned)f32_to_bf16(y[3]) << 16);
+      *reinterpret_cast<uint2*>(act + row * ACT_PITCH + c4 * 8) = pk;                 // t1 (bf16, GEMM operand)
+    }
   }
   __syncthreads();
 
+  // query_pos of the last row phase, fetched before the FFN hides the latency
+  f32x4 qp[RPASS][8];
+#pragma unroll
+  for (int ps = 0; ps < RPASS; ++ps)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      qp[ps][i] = (Wn && qpos)
+                      ? *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(ps * 8 * NW + wave * 8 + rgrp, nrow - 1)) * 256 +
+                                                        (part + 8 * i) * 4)
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float bc0 = bc[0], bc1 = bc[1];
+
   if (has_ffn) {
     // ---- FFN (mvp_decoder.py:94-98): Y = sum_c relu(t1 W1_c^T + b1_c) W2[:, c]^T, hidden chunks of 256
-    f32x16 accy[MT][2];
+    f32x16 accy[MT][JN];
     bool all[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) all[mt] = true;
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
-      stage_gemm<MT, 16, BRING>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c);
-      write_act<MT>(hbuf, acc, b1 + c * 256, true, all, tid);                         // private buffer: no hazard with act
+      stage_gemm<MT, 16, BRING, JN>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c);
+      write_act<MT, JN>(hbuf, acc, b1 + c * 256, true, all, tid);                         // private buffer: no hazard with act
       __syncthreads();
-      stage_gemm<MT, 16, BRING>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024);
+      stage_gemm<MT, 16, BRING, JN>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024);
       __syncthreads();                                                               // hbuf free for the next chunk
     }
-    acc_to_x<MT>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
+    acc_to_x<MT, JN>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
     __syncthreads();
   }
 
   // ---- tgt' = LN3(x) (or t1 when the FFN is off) ; class head per row (dq_decoder.py:889-893)
-  for (int row = wave; row < RM; row += NW) {
-    f32x4 y = *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
+#pragma unroll
+  for (int ps = 0; ps < RPASS; ++ps) {
+    const int row = ps * 8 * NW + wave * 8 + rgrp;
+    f32x4 y[8];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      y[i] = *reinterpret_cast<const f32x4*>(xb + row * XP + (part + 8 * i) * 16);
+      sm += y[i][0] + y[i][1] + y[i][2] + y[i][3];
+    }
     if (has_ffn) {
-      const float mean = wsum(y[0] + y[1] + y[2] + y[3]) * (1.f / 256.f);
-      const f32x4 d = y - mean;
-      const float rstd = 1.f / sqrtf(wsum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f) + 1e-5f);
-      y = d * rstd * *reinterpret_cast<const f32x4*>(g3 + lane * 4) + *reinterpret_cast<const f32x4*>(be3 + lane * 4);
+      const float mean = sum8(sm) * (1.f / 256.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        y[i] = y[i] - mean;
+        sq += y[i][0] * y[i][0] + y[i][1] * y[i][1] + y[i][2] * y[i][2] + y[i][3] * y[i][3];
+      }
+      const float rstd = 1.f / sqrtf(sum8(sq) * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c4 = part + 8 * i;
+        y[i] = y[i] * rstd * *reinterpret_cast<const f32x4*>(g3 + c4 * 4) + *reinterpret_cast<const f32x4*>(be3 + c4 * 4);
+      }
     }
-    if (row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + lane * 4) = y;
-    if (Wn) {   // operand of the next layer's query-term GEMM: tgt' + query_pos (bf16), into the now free act tile
-      f32x4 x = y;
-      if (qpos && row < nrow) x += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + row) * 256 + lane * 4);
-      uint2 pk;
-      pk.x = (unsigned)f32_to_bf16(x[0]) | ((unsigned)f32_to_bf16(x[1]) << 16);
-      pk.y = (unsigned)f32_to_bf16(x[2]) | ((unsigned)f32_to_bf16(x[3]) << 16);
-      *reinterpret_cast<uint2*>(act + row * ACT_PITCH + lane * 8) = pk;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = part + 8 * i;
+      if (row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + c4 * 4) = y[i];
+      if (Wn) {   // operand of the next layer's query-term GEMM: tgt' + query_pos (bf16), into the now free act tile
+        const f32x4 x = y[i] + qp[ps][i];
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(x[0]) | ((unsigned)f32_to_bf16(x[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(x[2]) | ((unsigned)f32_to_bf16(x[3]) << 16);
+        *reinterpret_cast<uint2*>(act + row * ACT_PITCH + c4 * 8) = pk;
+      }
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + c4 * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + c4 * 4);
+      a0 += y[i][0] * w0[0] + y[i][1] * w0[1] + y[i][2] * w0[2] + y[i][3] * w0[3];
+      a1 += y[i][0] * w1[0] + y[i][1] * w1[1] + y[i][2] * w1[2] + y[i][3] * w1[3];
     }
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + lane * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + lane * 4);
-    const float a0 = wsum(y[0] * w0[0] + y[1] * w0[1] + y[2] * w0[2] + y[3] * w0[3]) + bc[0];
-    const float a1 = wsum(y[0] * w1[0] + y[1] * w1[1] + y[2] * w1[2] + y[3] * w1[3]) + bc[1];
-    if (lane == 0) {
+    a0 = sum8(a0) + bc0;
+    a1 = sum8(a1) + bc1;
+    if (part == 0) {
       pr[2 * row] = 1.f / (1.f + expf(-a0));
       pr[2 * row + 1] = 1.f / (1.f + expf(-a1));
     }
@@ -427,8 +545,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets/logits Linear
     //      (projattn.py:180-181), computed while the rows are still in LDS (saves a 15 360-row GEMM launch and the
     //      elementwise add per layer).  The barrier above ordered the act writes and the last xb reads.
-    stage_gemm<MT, 16, BRING>(act, Wn, acc, tid, true, rot + 7);
-    acc_to_x<MT>(xb, acc, bn, false, tid);
+    stage_gemm<MT, 16, BRING, JN>(act, Wn, acc, tid, true, rot + 7);
+    acc_to_x<MT, JN>(xb, acc, bn, false, tid);
     __syncthreads();
     for (int row = wave; row < nrow; row += NW)
       if (lane * 4 < n_next)
@@ -439,6 +557,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 
 }  // namespace
 
+int g_chain_ring = 4;     // tuning knob "chain_ring": weight prefetch depth (k-steps) of chain B's stage GEMMs (4 | 8 | 16)
+int g_chain_split = 1;    // tuning knob "chain_split": 1 = column-split wave mapping of chain B (JN = 1), 0 = row-block split
 int g_chain_waves = 8;    // tuning knob "chain_waves": wavefronts per workgroup of chain B (4 | 8); measured 86 -> 69 us
 int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 measured slower: 93 vs 79 us)
 int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128); 128: 65 -> 55 us (half the
@@ -494,21 +614,30 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
   const size_t lds = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512>),
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<8, 512, 1>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<16, 512, 1>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
   const dim3 grid((nq_total + qpt - 1) / qpt);
-#define MVG_CB(R, NTH)                                                                                                  \
-  hipLaunchKernelGGL((chain_b_kernel<R, NTH>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
+#define MVG_CB(R, NTH, JNN)                                                                                                \
+  hipLaunchKernelGGL((chain_b_kernel<R, NTH, JNN>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
                      (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc,     \
                      threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next,  \
                      n_next, rows, J, nq_total, has_ffn)
-  if (g_chain_waves == 8) MVG_CB(4, 512);
-  else MVG_CB(4, 256);
+  if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 16) MVG_CB(16, 512, 1);
+  else if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 8) MVG_CB(8, 512, 1);
+  else if (g_chain_waves == 8 && g_chain_split == 1) MVG_CB(4, 512, 1);
+  else if (g_chain_waves == 8) MVG_CB(4, 512, 2);
+  else MVG_CB(4, 256, 2);
 #undef MVG_CB
   MVG_LAUNCH_CHECK();
   return 0;
