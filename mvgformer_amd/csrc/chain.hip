@@ -143,7 +143,7 @@ __device__ __forceinline__ void write_act(char* __restrict__ act, const f32x16 (
 
 // ------------------------------------------------------------------------------------------
 // chain A
-template <int RM, int NT>   // NT = 256 (4 waves) or 512 (8 waves: two row blocks)
+template <int RM, int NT, int JN>   // NT = 256 (4 waves) | 512 (8 waves: JN = 2 two row blocks, JN = 1 column split)
 __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict__ samp, const uint8_t* __restrict__ inside,
                                                       const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
                                                       const bf16_t* __restrict__ W0, const float* __restrict__ b0,
@@ -152,13 +152,14 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
                                                       bf16_t* __restrict__ attn, float* __restrict__ o,
                                                       const int* __restrict__ order, const float* __restrict__ o_masked,
                                                       int R) {
-  constexpr int MT = RM / 32 / (NT / 256);                  // row tiles per wave
+  constexpr int MT = (JN == 1) ? RM / 32 : RM / 32 / (NT / 256);                  // row tiles per wave
+  static_assert(JN == 2 || NT == 512, "column-split mapping needs 8 wavefronts");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
   int* rid = reinterpret_cast<int*>(smem + RM * ACT_PITCH);  // global row of every tile row (-1: past the end)
   const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
-  const int r0 = blockIdx.x * RM, row0 = (tid >> 8) * MT * 32;
-  const int rot = (blockIdx.x * 7 + ((tid >> 6) & 3) * 3) & 15;   // de-synchronise the weight walk (see stage_gemm)
+  const int r0 = blockIdx.x * RM, row0 = (JN == 1) ? 0 : (tid >> 8) * MT * 32;
+  const int rot = (blockIdx.x * 7 + (JN == 1 ? (tid >> 6) : ((tid >> 6) & 3)) * 3) & 15;   // de-synchronise the weight walk
 
   // Tile row i works on global row order[r0 + i] (the sampler's processing order: rows whose reference point is
   // outside the image come last, mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
       *reinterpret_cast<f32x4*>(act + row * ACT_PITCH + v16 * 16) = (rid[row] >= 0) ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  f32x16 acc[MT][2];
+  f32x16 acc[MT][JN];
   bool keep[MT], all[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -215,9 +216,9 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   }
   __syncthreads();
   // attn = inside * output_proj(samp)
-  stage_gemm<MT, 16>(act, Wp, acc, tid, true, rot);
+  stage_gemm<MT, 16, 4, JN>(act, Wp, acc, tid, true, rot);
   __syncthreads();
-  write_act<MT>(act, acc, bp, false, keep, tid);
+  write_act<MT, JN>(act, acc, bp, false, keep, tid);
   __syncthreads();
 #pragma unroll
   for (int c0 = 0; c0 < RM * 32; c0 += NT) {
@@ -228,13 +229,13 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
           *reinterpret_cast<const f32x4*>(act + row * ACT_PITCH + v16 * 16);
   }
   // pose_embed MLP layers 0, 1 (ReLU)
-  stage_gemm<MT, 16>(act, W0, acc, tid, true, rot + 5);
+  stage_gemm<MT, 16, 4, JN>(act, W0, acc, tid, true, rot + 5);
   __syncthreads();
-  write_act<MT>(act, acc, b0, true, all, tid);
+  write_act<MT, JN>(act, acc, b0, true, all, tid);
   __syncthreads();
-  stage_gemm<MT, 16>(act, W1, acc, tid, true, rot + 10);
+  stage_gemm<MT, 16, 4, JN>(act, W1, acc, tid, true, rot + 10);
   __syncthreads();
-  write_act<MT>(act, acc, b1, true, all, tid);
+  write_act<MT, JN>(act, acc, b1, true, all, tid);
   __syncthreads();
   // last layer (3 outputs): 4 threads per row (RM = 64) / 8 threads per row (RM = 32)
   constexpr int TPR = NT / RM, CPT = 256 / TPR;
@@ -564,19 +565,19 @@ int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 me
 int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128); 128: 65 -> 55 us (half the
                        // weight bytes per row through the L1 miss path, the resource that bounds these kernels)
 
-template <int RM, int NT>
+template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
                           float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
   const size_t lds = RM * ACT_PITCH + RM * sizeof(int);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT, JN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL((chain_a_kernel<RM, NT>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
+  hipLaunchKernelGGL((chain_a_kernel<RM, NT, JN>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
                      (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, order,
                      o_masked, rows);
   MVG_LAUNCH_CHECK();
@@ -590,10 +591,12 @@ extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, cons
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (g_chain_rm == 128 && g_chain_a_waves == 8) return launch_chain_a<128, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_rm == 128) return launch_chain_a<128, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_a_waves == 8) return launch_chain_a<64, 512>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  return launch_chain_a<64, 256>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 128 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<128, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 64 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<64, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 128 && g_chain_a_waves == 8) return launch_chain_a<128, 512, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 128) return launch_chain_a<128, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_a_waves == 8) return launch_chain_a<64, 512, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
 }
 
 extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,
