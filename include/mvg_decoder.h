@@ -122,8 +122,8 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
 /* ---- bf16 fast path of the ProjAttn front end (replaces mvg_gather_ref + 2 x mvg_linear + mvg_msda_fused) ----
  * Bilinear sampling commutes with a Linear: Linear(bilinear(feat,p) + x) = bilinear(feat@W^T, p) + (x@W^T + b).
  *   mvg_value_proj_pairs_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written in the
- *       "pixel-pair" layout vp[img][head 8][1+s][ch 32][2] (word = (value(s)[ch], value(s+1)[ch]); line 0 =
- *       (0, value(0)); bf16, n_img*8*(S+1)*64 elements): the two horizontal corners of a sample are one 128-B line.
+ *       "pixel-pair" layout vp[img][head 8][1+s][ch 32][2] (word = (value(s)[ch], value(s+1)[ch]); line 0 is
+ *       reserved and never read; bf16, n_img*8*(S+1)*64 elements): the two horizontal corners of a sample are one 128-B line.
  *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: [offsets|logits]).
  *   mvg_msda_gsamp          : per (image, query, head): gathers its 24 logits + 48 offsets from G at the reference
  *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b, softmax, locations, samples vp -> samp

@@ -450,9 +450,12 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
       const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
       const float c0 = (hl_ok && wl_ok) ? hh * hw * a : 0.f, c1 = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
       const float c2 = (hh_ok && wl_ok) ? lh * hw * a : 0.f, c3 = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
-      const unsigned my_wt = pack_bf16x2(c0, c1), my_wb = pack_bf16x2(c2, c3);
+      // w_low == -1: the only pixel with weight is column 0 = the LEFT element of pair line 0 of the row
+      const bool wneg = w_low < 0;
+      const unsigned my_wt = wneg ? pack_bf16x2(c1, 0.f) : pack_bf16x2(c0, c1);
+      const unsigned my_wb = wneg ? pack_bf16x2(c3, 0.f) : pack_bf16x2(c2, c3);
       const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-      const int wp = min(max(w_low, -1), W - 1);
+      const int wp = min(max(w_low, 0), W - 1);
       const unsigned lvl_pairs = (unsigned)(1 + lv.start[l]);
       const unsigned my_ot = (lvl_pairs + (unsigned)(hl_c * W + wp)) * 128u;           // byte offset of the top pair line
       const unsigned my_ob = (lvl_pairs + (unsigned)(hh_c * W + wp)) * 128u;

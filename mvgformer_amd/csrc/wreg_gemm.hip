@@ -14,8 +14,8 @@
 // MFMA + epilogue phase later; two workgroups per CU overlap each other.
 //
 // Pixel-pair layout (consumed by msda_gsamp_kernel):  vp[img][head 8][1+s][ch 32][2] bf16, the 32-bit word of
-// channel ch in line 1+s is (value(s)[ch], value(s+1)[ch]); line 0 is (0, value(0)), the right half of the last
-// pixel's line is 0.  Tiles overlap by one row (tile t = rows [31t, 31t+32)) so that every tile owns the
+// channel ch in line 1+s is (value(s)[ch], value(s+1)[ch]); line 0 is reserved (never read: the sampler takes
+// column -1 from the left element of the row's first line), the right half of the last pixel's line is 0.  Tiles overlap by one row (tile t = rows [31t, 31t+32)) so that every tile owns the
 // right-hand neighbour of its last output row.
 #include "common.h"
 
@@ -36,7 +36,13 @@ struct WregParams {
   int rowmajor;           // 0 = pixel-pair layout (N = 256), 1 = row-major bf16 (M, N)
 };
 
+// NCPT: 16-byte output chunks per thread and tile.  0 = pixel-pair layout (N = 256: 4 chunks, 2 stores each),
+// 1..4 = row-major with N = 64 * NCPT columns.  Every thread issues the SAME number of stores for every tile
+// (chunks that fall outside the matrix / on the overlap row are redirected to re-write a valid neighbour's chunk with
+// identical bytes), so the compiler can give the loads of a later tile an exact vmcnt instead of vmcnt(0).
+template <int NCPT>
 __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
+  constexpr bool PAIRS = NCPT == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                   // RM x 256 bf16 A tile
   char* stage0 = smem + RM * ACT_PITCH;               // 2 x (RM x 256 bf16) output tiles (double-buffered)
@@ -56,10 +62,10 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
     }
   }
 
-  const int TS = p.rowmajor ? RM : RM - 1;      // tile stride in rows (pair layout: one row of overlap)
+  constexpr int TS = PAIRS ? RM - 1 : RM;       // tile stride in rows (pair layout: one row of overlap)
   const int ntiles = (p.M + TS - 1) / TS;
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-  // chunk c = i*256 + tid of a tile: row = c >> 5, 16-byte column v16 = c & 31 (NCH chunks per thread)
+  // A chunk c = i*256 + tid of a tile: row = c >> 5, 16-byte column v16 = c & 31 (NCH chunks per thread)
   auto load_chunk = [&](int tile, int i) -> uint4 {
     const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
     const int rr = min(tile, ntiles - 1) * TS;
@@ -68,98 +74,106 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   // global stores of a finished tile from its staging buffer
   auto store_tile = [&](int tile, const char* stage) {
     const int r0 = tile * TS;
+    const int last_row = p.M - 1 - r0;                 // rows past it do not exist (only in the final tile)
+    if (PAIRS) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
-      const int grow = r0 + row;
-      if (grow >= p.M) continue;
-      if (p.rowmajor) {
-        if (v16 * 8 < p.N)
-          *reinterpret_cast<f32x4*>(outp + (long)grow * p.N + v16 * 8) =
-              *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
-      } else if (row < RM - 1) {
+      for (int i = 0; i < NCH; ++i) {
+        const int c = i * 256 + tid, v16 = c & 31;
         // pair line 1+s of (img, head) = 128 bytes = 32 channels x (value(s), value(s+1)); the 4 threads of a
         // head write its two 64-byte halves with one store each: thread q4 covers channels 4*q4.. and 16+4*q4..
-        const int img = grow / p.S_img, s = grow - img * p.S_img;
+        const int row = min(min(c >> 5, RM - 2), last_row);        // overlap row / tail: duplicate a valid line
+        const int grow = r0 + row;
+        const int img = grow / p.S_img, sp = grow - img * p.S_img;
         const int head = v16 >> 2, q4 = v16 & 3;
-        const bool last = s + 1 >= p.S_img;              // no right neighbour across an image boundary
+        const bool last = sp + 1 >= p.S_img;            // no right neighbour across an image boundary
         const char* lrow = stage + row * ACT_PITCH + head * 64 + q4 * 8;
         const uint2 la = *reinterpret_cast<const uint2*>(lrow), lb = *reinterpret_cast<const uint2*>(lrow + 32);
         uint2 ra = *reinterpret_cast<const uint2*>(lrow + ACT_PITCH), rb = *reinterpret_cast<const uint2*>(lrow + ACT_PITCH + 32);
         if (last) ra = rb = uint2{0u, 0u};
-        bf16_t* line = outp + (((long)img * 8 + head) * (p.S_img + 1) + 1 + s) * 64 + q4 * 8;
+        bf16_t* line = outp + (((long)img * 8 + head) * (p.S_img + 1) + 1 + sp) * 64 + q4 * 8;
         *reinterpret_cast<uint4*>(line) =
             uint4{__builtin_amdgcn_perm(ra.x, la.x, 0x05040100u), __builtin_amdgcn_perm(ra.x, la.x, 0x07060302u),
                   __builtin_amdgcn_perm(ra.y, la.y, 0x05040100u), __builtin_amdgcn_perm(ra.y, la.y, 0x07060302u)};
         *reinterpret_cast<uint4*>(line + 32) =
             uint4{__builtin_amdgcn_perm(rb.x, lb.x, 0x05040100u), __builtin_amdgcn_perm(rb.x, lb.x, 0x07060302u),
                   __builtin_amdgcn_perm(rb.y, lb.y, 0x05040100u), __builtin_amdgcn_perm(rb.y, lb.y, 0x07060302u)};
-        if (s == 0) {                                  // line 0 of the plane: (0, value(0)) -- the w_low = -1 column
-          *reinterpret_cast<uint4*>(line - 64) = uint4{la.x << 16, la.x & 0xffff0000u, la.y << 16, la.y & 0xffff0000u};
-          *reinterpret_cast<uint4*>(line - 64 + 32) = uint4{lb.x << 16, lb.x & 0xffff0000u, lb.y << 16, lb.y & 0xffff0000u};
-        }
+      }
+    } else {
+      constexpr int CPR = 8 * (NCPT > 0 ? NCPT : 1);    // 16-byte chunks per output row
+#pragma unroll
+      for (int i = 0; i < NCPT; ++i) {
+        const int c = i * 256 + tid;
+        const int row = min(c / CPR, last_row), ch = c % CPR;
+        *reinterpret_cast<f32x4*>(outp + (long)(r0 + row) * p.N + ch * 8) =
+            *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + ch * 16);
       }
     }
   };
 
-  // Software pipeline.  All global traffic of an iteration is issued at its start -- the stores of the PREVIOUS
-  // tile (from the other staging buffer), then the loads of the NEXT tile -- and is only waited for at the top of
-  // the next iteration, one MFMA + epilogue phase later (gfx9 has a single in-order vmcnt for loads and stores:
-  // a store issued after a load would be waited for together with it).
-  uint4 xp0 = load_chunk(blockIdx.x, 0), xp1 = load_chunk(blockIdx.x, 1), xp2 = load_chunk(blockIdx.x, 2),
-        xp3 = load_chunk(blockIdx.x, 3);
+  // Software pipeline, loads two tiles ahead.  Iteration t: [wait loads(t)] -> A tile to LDS -> barrier ->
+  // stores(t-1) from the other staging buffer -> loads(t+2) into the registers just freed -> MFMA(t) -> epilogue(t)
+  // -> barrier.  gfx9 has ONE in-order vmcnt for loads and stores: loads(t+1) are older than stores(t-1) and
+  // loads(t+2), and because every iteration issues a fixed number of each, the wait at the top of t+1 is an exact
+  // vmcnt(stores + loads), not vmcnt(0) -- a full iteration of latency hiding for every load.
   static_assert(NCH == 4, "prefetch registers are written out for 4 chunks per thread");
+  const int G = gridDim.x;
+  uint4 xa0 = load_chunk(blockIdx.x, 0), xa1 = load_chunk(blockIdx.x, 1), xa2 = load_chunk(blockIdx.x, 2),
+        xa3 = load_chunk(blockIdx.x, 3);
+  uint4 xb0 = load_chunk(blockIdx.x + G, 0), xb1 = load_chunk(blockIdx.x + G, 1), xb2 = load_chunk(blockIdx.x + G, 2),
+        xb3 = load_chunk(blockIdx.x + G, 3);
   int it = 0, prev_tile = -1;
-#pragma unroll 1
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-    {
-      const int row = tid >> 5, v16 = tid & 31;        // chunk i: row + 8*i
-      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = xp0;
-      *reinterpret_cast<uint4*>(act + (row + 8) * ACT_PITCH + v16 * 16) = xp1;
-      *reinterpret_cast<uint4*>(act + (row + 16) * ACT_PITCH + v16 * 16) = xp2;
-      *reinterpret_cast<uint4*>(act + (row + 24) * ACT_PITCH + v16 * 16) = xp3;
-    }
-    __syncthreads();
-    char* stage = stage0 + (it & 1) * RM * ACT_PITCH;
-    if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);
-    xp0 = load_chunk(tile + gridDim.x, 0);
-    xp1 = load_chunk(tile + gridDim.x, 1);
-    xp2 = load_chunk(tile + gridDim.x, 2);
-    xp3 = load_chunk(tile + gridDim.x, 3);
-    __builtin_amdgcn_sched_barrier(0);
 
-    // ---------------- MFMA: acc[j] = A_tile(32 x 256) . W_slice(64 cols)^T, weights from registers
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    if (wave_has_cols) {
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(act + rl * ACT_PITCH + ks * 32 + 16 * h);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks][j]),
-                                                           __builtin_bit_cast(bf16x8, a), acc[j], 0, 0, 0);
-      }
-    }
-
-    // ---------------- epilogue: + bias -> bf16 -> staging tile
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nn);
-        uint2 pk;
-        pk.x = (unsigned)f32_to_bf16(acc[j][4 * g] + bv[0]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 1] + bv[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16(acc[j][4 * g + 2] + bv[2]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 3] + bv[3]) << 16);
-        *reinterpret_cast<uint2*>(stage + rl * ACT_PITCH + nn * 2) = pk;
-      }
-    prev_tile = tile;
-    __syncthreads();      // act may be overwritten, this tile's staging buffer is complete
+#define WREG_ITERATION(X0, X1, X2, X3)                                                                           \
+  {                                                                                                              \
+    {                                                                                                            \
+      const int row = tid >> 5, v16 = tid & 31;                                                                  \
+      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = X0;                                          \
+      *reinterpret_cast<uint4*>(act + (row + 8) * ACT_PITCH + v16 * 16) = X1;                                    \
+      *reinterpret_cast<uint4*>(act + (row + 16) * ACT_PITCH + v16 * 16) = X2;                                   \
+      *reinterpret_cast<uint4*>(act + (row + 24) * ACT_PITCH + v16 * 16) = X3;                                   \
+    }                                                                                                            \
+    __syncthreads();                                                                                             \
+    char* stage = stage0 + (it & 1) * RM * ACT_PITCH;                                                            \
+    if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);                         \
+    X0 = load_chunk(tile + 2 * G, 0);                                                                            \
+    X1 = load_chunk(tile + 2 * G, 1);                                                                            \
+    X2 = load_chunk(tile + 2 * G, 2);                                                                            \
+    X3 = load_chunk(tile + 2 * G, 3);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    f32x16 acc[2];                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;                                            \
+    if (wave_has_cols) {                                                                                         \
+      _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                                        \
+        const f32x4 a = *reinterpret_cast<const f32x4*>(act + rl * ACT_PITCH + ks * 32 + 16 * h);                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks][j]),              \
+                                                           __builtin_bit_cast(bf16x8, a), acc[j], 0, 0, 0);      \
+      }                                                                                                          \
+    }                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
+        const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;                                                         \
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nn);                                           \
+        uint2 pk;                                                                                                \
+        pk.x = (unsigned)f32_to_bf16(acc[j][4 * g] + bv[0]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 1] + bv[1]) << 16);     \
+        pk.y = (unsigned)f32_to_bf16(acc[j][4 * g + 2] + bv[2]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 3] + bv[3]) << 16); \
+        *reinterpret_cast<uint2*>(stage + rl * ACT_PITCH + nn * 2) = pk;                                         \
+      }                                                                                                          \
+    prev_tile = tile;                                                                                            \
+    ++it;                                                                                                        \
+    __syncthreads(); /* act may be overwritten, this tile's staging buffer is complete */                        \
   }
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += 2 * G) {
+    WREG_ITERATION(xa0, xa1, xa2, xa3)
+    tile += G;
+    if (tile >= ntiles) break;
+    WREG_ITERATION(xb0, xb1, xb2, xb3)
+    tile -= G;
+  }
+#undef WREG_ITERATION
   if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);
 }
 
@@ -168,7 +182,15 @@ int launch_wreg(const WregParams& p, hipStream_t st) {
   const int TS = p.rowmajor ? RM : RM - 1;
   const int ntiles = (p.M + TS - 1) / TS;
   const int grid = ntiles < g_wreg_grid ? ntiles : g_wreg_grid;      // persistent: 2 workgroups per CU
-  hipLaunchKernelGGL(wreg_gemm_kernel, dim3(grid), dim3(256), lds, st, p);
+#define WREG_LAUNCH(NC) hipLaunchKernelGGL((wreg_gemm_kernel<NC>), dim3(grid), dim3(256), lds, st, p)
+  if (!p.rowmajor) WREG_LAUNCH(0);
+  else switch (p.N / 64) {
+    case 1: WREG_LAUNCH(1); break;
+    case 2: WREG_LAUNCH(2); break;
+    case 3: WREG_LAUNCH(3); break;
+    default: WREG_LAUNCH(4); break;
+  }
+#undef WREG_LAUNCH
   MVG_LAUNCH_CHECK();
   return 0;
 }
