@@ -124,9 +124,11 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
  *   mvg_value_proj_pairs_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written in the
  *       "pixel-pair" layout vp[img][head 8][1+s][ch 32][2] (word = (value(s)[ch], value(s+1)[ch]); line 0 is
  *       reserved and never read; bf16, n_img*8*(S+1)*64 elements): the two horizontal corners of a sample are one 128-B line.
- *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: [offsets|logits]).
+ *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: the [offsets; logits]
+ *       rows in the order of mvgformer_amd.ops.gsamp_column_order: 8 groups of 16 offset + 8 logit outputs, so that
+ *       with the reference's memory reinterpretation the 72 values a head needs are contiguous in a G row).
  *   mvg_msda_gsamp          : per (image, query, head): gathers its 24 logits + 48 offsets from G at the reference
- *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b, softmax, locations, samples vp -> samp
+ *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b (same column order as G), softmax, locations, samples vp -> samp
  *       (N_img*Lq, 256) bf16.  M=8, D=32, P=8, L<=4.  pair_mask (N_img*Lq) u8 or NULL: rows with mask 0 are
  *       written as zeros without being sampled (the consumer multiplies exactly these rows by the in-image mask,
  *       dq_decoder.py:585-586).  order (N_img*Lq) i32 or NULL: slot i of the launch computes pair order[i].

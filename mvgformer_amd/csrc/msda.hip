@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 //     layer (projattn.py:148-153,180-181), the offsets/logits Linear is applied ONCE to the pyramid
 //     (G = feat @ Woa^T, a (V*S x 192) GEMM independent of the queries) and every (pair, head) gathers its own
 //     24 logits + 48 offsets from G at the reference point (9 chunks of 8 columns, split over the 4 lanes of
-//     the head, parked in LDS) and adds xw = (tgt+query_pos) @ Woa^T + b.  No (rows x 192) fp32 tensor
+//     the head, parked in LDS) and adds xw = (tgt+query_pos) @ Woa^T + b.  The 192 columns of G / xw are ordered
+//     so that a head's chunks are contiguous in a pixel's row (see phase A).  No (rows x 192) fp32 tensor
 //     (177 MB written + read per layer) and no per-(view, query, level) GEMM exist any more.
 // (2) Pixel-pair value layout (written by wreg_gemm.hip):  vp[img][head][1+s][ch 32][2] with the 32-bit word
 //     (value(s)[ch], value(s+1)[ch]): the two horizontal corners of a sample are ONE aligned 128-byte line per
@@ -362,10 +363,14 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
   for (int k = 0; k < (NCHK + 3) / 4; ++k) {
     const int ci = sub + 4 * k;
     if (ci < NCHK) {
-      const bool is_logit = ci < L;
-      const int flat = is_logit ? (m * LP + 8 * ci) : (m * 2 * LP + 8 * (ci - L));
-      const int l = is_logit ? (flat >> 6) : (flat >> 7);                  // level row of the reinterpreted view
-      const int col = is_logit ? (128 + (flat & 63)) : (flat & 127);
+      // G / xw columns are grouped per (16 offsets | 8 logits): group g of a level row = columns [24g, 24g+24) =
+      // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
+      // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
+      const int t = ci / 3, part = ci - 3 * t;
+      const int fg = m * L + t;
+      const int l = fg >> 3;                                               // level row of the reinterpreted view
+      const int col = 24 * (fg & 7) + 8 * part;
+      const bool is_logit = part == 2;
       const int H = lv.H[l], W = lv.W[l];
       const float Wf = (float)W, Hf = (float)H;
       const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
         v[2 * t + 1] = w00 * __uint_as_float(a4[t] & 0xffff0000u) + w10 * __uint_as_float(b4[t] & 0xffff0000u) +
                        w01 * __uint_as_float(c4[t] & 0xffff0000u) + w11 * __uint_as_float(d4[t] & 0xffff0000u);
       }
-      float* dst = sc + (is_logit ? 8 * ci : LP + 8 * (ci - L));
+      float* dst = sc + (is_logit ? 8 * t : LP + 16 * t + 8 * part);
       *reinterpret_cast<f32x4*>(dst) = f32x4{v[0] + xa[0], v[1] + xa[1], v[2] + xa[2], v[3] + xa[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[0], v[5] + xb[1], v[6] + xb[2], v[7] + xb[3]};
     }

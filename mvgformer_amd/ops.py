@@ -227,8 +227,19 @@ def feat_linear_ws(feat, w_frag, N=192):
     return G
 
 
+def gsamp_column_order(device=None):
+    """Row permutation of [sampling_offsets.weight (128); attention_weights.weight (64)] that msda_gsamp expects
+    for G and xw: 8 groups of (16 offset rows | 8 logit rows).  With the reference's memory reinterpretation
+    (projattn.py:180-184) head m of a level row uses whole groups, so its 72 values are contiguous in a G row."""
+    idx = []
+    for g in range(8):
+        idx += list(range(16 * g, 16 * g + 16)) + list(range(128 + 8 * g, 128 + 8 * g + 8))
+    return torch.as_tensor(idx, dtype=torch.long, device=device)
+
+
 def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None):
-    """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h).
+    """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h); the 192
+    columns of G and xw are in gsamp_column_order().
     pair_mask (n_img*Lq) u8: rows with 0 are zero-filled, not sampled; order (n_img*Lq) i32 from bin_pairs."""
     n_img = vp.shape[0]
     Lq = r.shape[1]

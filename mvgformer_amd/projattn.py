@@ -163,12 +163,19 @@ class ProjAttn(nn.Module):
     def query_term_weights(self, dt):
         """operands of xw = (tgt + query_pos) @ [Woff; Wattn]^T + b as the fused chain B of the PREVIOUS layer takes
         them: (weight fragments (256,256) bf16 zero-padded, bias (256,) f32 zero-padded, n = 192)."""
-        pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
-                                              .to(dt))
+        perm = lambda a, b: torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)]
+        pad = lambda a, b: ops.swizzle_weight(torch.cat([perm(a, b), a.new_zeros(64, a.shape[1])], 0).to(dt))
         Wf = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
-        bpad = lambda a, b: torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0])], 0)
+        bpad = lambda a, b: torch.cat([perm(a, b), a.new_zeros(64)], 0)
         bn = self._wc.get("boa_pad", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, bpad)
-        return Wf, bn, self.sampling_offsets.out_features + self.attention_weights.out_features
+        return Wf, bn, 192
+
+    def _fast_query_weights(self, dt):
+        """[offsets; logits] Linear in the column order of the G-sampling kernel (ops.gsamp_column_order)."""
+        perm = lambda a, b: torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)]
+        W = self._wc.get("Woa_perm", (self.sampling_offsets.weight, self.attention_weights.weight), dt, perm)
+        b = self._wc.get("boa_perm", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, perm)
+        return W, b
 
     def native_sample(self, x, r, feat, levels, V, B, pair_mask=None, order=None, xw=None):
         """everything of native_forward up to (not including) output_proj: (V*B*Lq, C) sampled values.
@@ -184,14 +191,13 @@ class ProjAttn(nn.Module):
         if self.uses_fast_path(dt):
             # Linear(bilinear(feat) + x) = bilinear(Linear(feat)) + Linear(x): project the pyramid once (G), compute
             # the query term once per layer (xw), gather offsets/logits inside the sampler (csrc/msda.hip)
-            pad = lambda a, b: ops.swizzle_weight(torch.cat([a, b, a.new_zeros(256 - a.shape[0] - b.shape[0], a.shape[1])], 0)
-                                                  .to(dt))
-            Woa_f = self._wc.get("Woa_frag", (self.sampling_offsets.weight, self.attention_weights.weight), dt, pad)
+            Woa_f = self.query_term_weights(dt)[0]
             # processing order of the pairs: given by the caller (DQDecoderLayer shares it with chain A) or binned here
             if order is None and self.sort_pairs and r.shape[1] <= 65536:
                 order = ops.bin_pairs(r, pair_mask, levels)
             if xw is None:      # else: already computed by the previous layer's fused chain B
-                xw = ops.linear(x.reshape(-1, Cc), Woa, boa, out_dtype=torch.float32)
+                Wq, bq = self._fast_query_weights(dt)
+                xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
             # the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is the
             # freshest resident of the 256-MB Infinity Cache when the sampler starts
             vp = self.project_values(feat) if self._vp_event is None else self._wait_values()

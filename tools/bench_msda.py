@@ -47,9 +47,9 @@ with torch.no_grad():
 
     if dtype == torch.bfloat16:
         vp = pa.project_values(ctx.feat)
-        xw = ops.linear(x.reshape(-1, 256), Woa, boa, out_dtype=torch.float32)
-        Woa_f = pa._wc.get("Woa_frag", (pa.sampling_offsets.weight, pa.attention_weights.weight), dtype,
-                           lambda a_, b_: ops.swizzle_weight(torch.cat([a_, b_, a_.new_zeros(64, 256)], 0).to(dtype)))
+        Wq, bq = pa._fast_query_weights(dtype)
+        xw = ops.linear(x.reshape(-1, 256), Wq, bq, out_dtype=torch.float32)
+        Woa_f = pa.query_term_weights(dtype)[0]
         G = ops.feat_linear_ws(ctx.feat, Woa_f, 192)
         for _ in range(3):
             ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1)
