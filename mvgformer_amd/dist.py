@@ -172,6 +172,11 @@ class GraphedShardedDecoder:
             self.graphs.append(g)
             return res
 
+        # same layer chaining as DQDecoder.forward: layer l's fused chain B also emits layer l+1's query term
+        fuse = getattr(self.dec, "fuse_next_query_term", False)
+        for l, layer in enumerate(layers):
+            layer._next_layer = (layers[l + 1],) if (fuse and l + 1 < len(layers)) else None
+            layer._xw_in = None
         ref = self.ref if self.ref.dim() == 4 else self.ref[:, :, None]
         st = segment(lambda: (self.ctx.pack(self.src), layers[0].forward_features(self.tgt, self.qpos, ref, self.ctx,
                                                                                    self.thr))[1])
@@ -190,6 +195,9 @@ class GraphedShardedDecoder:
             res = segment(body)
             if not last:
                 st = res
+        for layer in layers:
+            layer._next_layer = None
+            layer._xw_in = None
         self.send, self.geo = res
         self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
         self.out = segment(lambda: unpack_outputs(self.recv, self.geo))

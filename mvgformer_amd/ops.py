@@ -231,10 +231,9 @@ def gsamp_column_order(device=None):
     """Row permutation of [sampling_offsets.weight (128); attention_weights.weight (64)] that msda_gsamp expects
     for G and xw: 8 groups of (16 offset rows | 8 logit rows).  With the reference's memory reinterpretation
     (projattn.py:180-184) head m of a level row uses whole groups, so its 72 values are contiguous in a G row."""
-    idx = []
-    for g in range(8):
-        idx += list(range(16 * g, 16 * g + 16)) + list(range(128 + 8 * g, 128 + 8 * g + 8))
-    return torch.as_tensor(idx, dtype=torch.long, device=device)
+    j = torch.arange(192, dtype=torch.long, device=device)       # built on the device: legal during graph capture
+    g, w = j // 24, j % 24
+    return torch.where(w < 16, 16 * g + w, 128 + 8 * g + (w - 16))
 
 
 def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None):
