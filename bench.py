@@ -129,9 +129,21 @@ def main():
             # segments between the collectives are graphs, the RCCL calls stay eager (mvgformer_amd.dist)
             for layer in dec.layers:
                 layer._any_valid_hook = None
-            graph = mdist.GraphedShardedDecoder(dec, tgt, ref, g.src_views, qpos, ctx, thr, NQ)
-            out = graph.replay()
-            torch.cuda.synchronize()
+            ok = 1
+            try:
+                graph = mdist.GraphedShardedDecoder(dec, tgt, ref, src_views, qpos, ctx, thr, NQ)
+            except Exception as e:   # keep the job alive: every rank falls back to the eager sharded forward
+                print("# rank %d: segmented graph capture failed (%s: %s)" % (rank, type(e).__name__, e), file=sys.stderr)
+                ok, graph = 0, None
+                torch.cuda.synchronize()
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                graph = None
+                mdist.install_any_valid_sync(dec, None)
+            else:
+                out = graph.replay()
+                torch.cuda.synchronize()
         elif use_graph:
             try:
                 graph = torch.cuda.CUDAGraph()

@@ -334,6 +334,47 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xf, 0xf, false);
 }
 
+// One lane's sample of gather batch `it` of a (pair, head): sample index it*4 + sub, level (it*4)/8.  Branch-free:
+// packed (left, right) bf16 weights of the top / bottom pair line and the byte offsets of the two lines.
+template <int L>
+__device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
+                                             const float (&refx)[L], const float (&refy)[L], int sub, unsigned& wt,
+                                             unsigned& wb, unsigned& ot, unsigned& ob) {
+  constexpr int P = 8, NB = 4, LP = L * P;
+  const int l = (it * NB) / P;
+  const int H = lv.H[l], W = lv.W[l];
+  const float Wf = (float)W, Hf = (float)H;
+  float rx = refx[0], ry = refy[0];                  // refx[l] / refy[l] without a dynamically indexed register array
+#pragma unroll
+  for (int k = 1; k < L; ++k) {
+    rx = (l == k) ? refx[k] : rx;
+    ry = (l == k) ? refy[k] : ry;
+  }
+  const float lgs = sc[it * NB + sub];
+  const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
+  const float lx = rx + of.x * (1.f / Wf), ly = ry + of.y * (1.f / Hf);               // projattn.py:186-191
+  const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;                           // cuh:295-296
+  const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+  const int h_low = (int)hl_f, w_low = (int)wl_f;
+  const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+  const bool inside = (h_im > -1.f) & (w_im > -1.f) & (h_im < Hf) & (w_im < Wf);      // cuh:298
+  const float e = __expf(lgs - mx);                                                   // <= 1: safe to evaluate always
+  const float a = inside ? e : 0.f;
+  const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+  const float t0 = hh * hw * a, t1 = hh * lw * a, t2 = lh * hw * a, t3 = lh * lw * a;
+  const float c0 = (hl_ok & wl_ok) ? t0 : 0.f, c1 = (hl_ok & wh_ok) ? t1 : 0.f;       // cuh:66-88 zero padding
+  const float c2 = (hh_ok & wl_ok) ? t2 : 0.f, c3 = (hh_ok & wh_ok) ? t3 : 0.f;
+  // w_low == -1: the only pixel with weight is column 0 = the LEFT element of pair line 0 of the row
+  const bool wneg = w_low < 0;
+  wt = pack_bf16x2(wneg ? c1 : c0, wneg ? 0.f : c1);
+  wb = pack_bf16x2(wneg ? c3 : c2, wneg ? 0.f : c3);
+  const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+  const int wp = min(max(w_low, 0), W - 1);
+  const unsigned lvl_pairs = (unsigned)(1 + lv.start[l]);
+  ot = (lvl_pairs + (unsigned)(hl_c * W + wp)) * 128u;           // byte offset of the top pair line
+  ob = (lvl_pairs + (unsigned)(hh_c * W + wp)) * 128u;
+}
+
 template <int L, int NT>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
 __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                             const float* __restrict__ xw, const float* __restrict__ r,
@@ -436,42 +477,28 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
     // byte offset of this lane's 32-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
     const unsigned lane_off = (unsigned)((((long)n * 8 + m) * (S + 1)) * 128 + sub * 32);
     const char* vp_bytes = reinterpret_cast<const char*>(vp);
+    // per-level reference points of the pair, fetched once
+    float refx[L], refy[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float2 rr = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
+      refx[l] = rr.x;
+      refy[l] = rr.y;
+    }
+    // Explicit software pipeline over the LP / NB batches (a real loop: unrolled, hipcc computes all 24 samples
+    // first and spills):   gathers(it) issued  ->  coordinates(it + 1) computed under their latency  ->  blend(it)
+    unsigned cw_t, cw_b, co_t, co_b;                  // this lane's sample of the batch: packed weights / line offsets
+    gsamp_coords<L>(0, sc, mx, lv, refx, refy, sub, cw_t, cw_b, co_t, co_b);
 #pragma unroll 1
     for (int it = 0; it < LP / NB; ++it) {
-      const int l = (it * NB) / P;
-      const int H = lv.H[l], W = lv.W[l];
-      const float Wf = (float)W, Hf = (float)H;
-      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
-      // ---- this lane's sample of the batch: s = sub
-      const float lgs = sc[it * NB + sub];
-      const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
-      const float lx = refx + of.x * (1.f / Wf), ly = refy + of.y * (1.f / Hf);     // projattn.py:186-191
-      const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;                       // cuh:295-296
-      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
-      const int h_low = (int)hl_f, w_low = (int)wl_f;
-      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
-      const float a = inside ? __expf(lgs - mx) : 0.f;
-      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-      const float c0 = (hl_ok && wl_ok) ? hh * hw * a : 0.f, c1 = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
-      const float c2 = (hh_ok && wl_ok) ? lh * hw * a : 0.f, c3 = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
-      // w_low == -1: the only pixel with weight is column 0 = the LEFT element of pair line 0 of the row
-      const bool wneg = w_low < 0;
-      const unsigned my_wt = wneg ? pack_bf16x2(c1, 0.f) : pack_bf16x2(c0, c1);
-      const unsigned my_wb = wneg ? pack_bf16x2(c3, 0.f) : pack_bf16x2(c2, c3);
-      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-      const int wp = min(max(w_low, 0), W - 1);
-      const unsigned lvl_pairs = (unsigned)(1 + lv.start[l]);
-      const unsigned my_ot = (lvl_pairs + (unsigned)(hl_c * W + wp)) * 128u;           // byte offset of the top pair line
-      const unsigned my_ob = (lvl_pairs + (unsigned)(hh_c * W + wp)) * 128u;
       // ---- quad broadcast + 16 gathers in flight
       unsigned wt[NB], wb[NB];
       uint4 raw[NB][4];
 #define MVG_QS(SS)                                                                                      \
       {                                                                                                 \
-        wt[SS] = quad_bcast<SS>(my_wt);                                                                 \
-        wb[SS] = quad_bcast<SS>(my_wb);                                                                 \
-        const unsigned ot = quad_bcast<SS>(my_ot) + lane_off, ob = quad_bcast<SS>(my_ob) + lane_off;    \
+        wt[SS] = quad_bcast<SS>(cw_t);                                                                  \
+        wb[SS] = quad_bcast<SS>(cw_b);                                                                  \
+        const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
         raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
         raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + ot + 16);                               \
         raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
@@ -479,6 +506,9 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
       }
       MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
 #undef MVG_QS
+      __builtin_amdgcn_sched_barrier(0);
+      // next batch's coordinates while the gathers are in flight (the last iteration recomputes batch 0: branch-free)
+      gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, refx, refy, sub, cw_t, cw_b, co_t, co_b);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < NB; ++s)
@@ -494,6 +524,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
             acc[4 + t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, c47[t]), wv, acc[4 + t], false);
           }
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
