@@ -70,6 +70,8 @@ struct LevelTable {
   int H[MVG_MAX_LEVELS];
   int W[MVG_MAX_LEVELS];
   int start[MVG_MAX_LEVELS];
+  float invH[MVG_MAX_LEVELS];   // 1.0f / H, 1.0f / W (IEEE fp32 division on the host: what the kernels used to compute)
+  float invW[MVG_MAX_LEVELS];
   int L;
 };
 
@@ -80,6 +82,8 @@ static inline int mvg_fill_levels(LevelTable* t, const int64_t* shapes_host, con
     t->H[l] = (int)shapes_host[2 * l];
     t->W[l] = (int)shapes_host[2 * l + 1];
     t->start[l] = (int)starts_host[l];
+    t->invH[l] = 1.0f / (float)t->H[l];
+    t->invW[l] = 1.0f / (float)t->W[l];
   }
   return 0;
 }

@@ -352,7 +352,7 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
   }
   const float lgs = sc[it * NB + sub];
   const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
-  const float lx = rx + of.x * (1.f / Wf), ly = ry + of.y * (1.f / Hf);               // projattn.py:186-191
+  const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];               // projattn.py:186-191
   const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;                           // cuh:295-296
   const float hl_f = floorf(h_im), wl_f = floorf(w_im);
   const int h_low = (int)hl_f, w_low = (int)wl_f;
