@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
   int* rid = reinterpret_cast<int*>(smem + RM * ACT_PITCH);  // global row of every tile row (-1: past the end)
+  float* w2s = reinterpret_cast<float*>(smem + RM * ACT_PITCH + RM * sizeof(int));   // last pose layer (3 x 256 f32)
   const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
   const int r0 = blockIdx.x * RM, row0 = (JN == 1) ? 0 : (tid >> 8) * MT * 32;
   const int rot = (blockIdx.x * 7 + (JN == 1 ? (tid >> 6) : ((tid >> 6) & 3)) * 3) & 15;   // de-synchronise the weight walk
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   // outside the image come last, mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
   // and o = the MLP of a zero row for all of its rows: o_masked holds that row's result (computed by this very
   // kernel on one masked row), so such tiles only write their outputs.
+  for (int i = tid; i < 768; i += NT) w2s[i] = W2[i];      // read by every thread in the last stage: LDS, not 96 global loads each
   bool mine = false;
   if (tid < RM) {
     const int slot = r0 + tid;
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(W2 + k * 256 + part * CPT + c);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(W2 + k * 256 + part * CPT + c + 4);
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + part * CPT + c);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + part * CPT + c + 4);
       s[k] += hf[0] * wa[0] + hf[1] * wa[1] + hf[2] * wa[2] + hf[3] * wa[3] + hf[4] * wb[0] + hf[5] * wb[1] +
               hf[6] * wb[2] + hf[7] * wb[3];
     }
@@ -569,7 +571,7 @@ template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
                           float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
-  const size_t lds = RM * ACT_PITCH + RM * sizeof(int);
+  const size_t lds = RM * ACT_PITCH + RM * sizeof(int) + 768 * sizeof(float);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT, JN>),
