@@ -621,3 +621,41 @@ def test_next_layer_query_term_fused_into_chain_b():
         d = dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
                 query_pos=None, threshold=0.1)
     assert float((c[0] - d[0]).abs().max()) < 2e-2 * float(d[0].abs().max())
+
+
+@pytest.mark.parametrize("shapes", [[(24, 40)], [(24, 40), (12, 20)], [(32, 48), (16, 24), (8, 12), (4, 6)], [(5, 7), (3, 3)]])
+def test_bf16_fast_path_other_level_counts(shapes):
+    """The G-sampling kernel's level bookkeeping (flat group -> level row of the reinterpreted Linear outputs, pair
+    line offsets, per-level reference points) for 1, 2 and 4 levels and tiny maps, against the generic bf16 kernels;
+    with and without the processing order / pair mask."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.projattn import ProjAttn
+    torch.manual_seed(7)
+    L_ = len(shapes)
+    n_img, Bq, Lq = 4, 2, 96
+    sp = torch.tensor(shapes, dtype=torch.int64)
+    starts = torch.cat([sp.new_zeros(1), (sp[:, 0] * sp[:, 1]).cumsum(0)[:-1]])
+    levels = ops.Levels(sp, starts)
+    pa = ProjAttn(256, 1, 8, 8, "ablation_not_use_rayconv").to(DEV)
+    with torch.no_grad():
+        pa.sampling_offsets.weight.normal_(0, 0.02)
+        pa.attention_weights.weight.normal_(0, 0.05)
+    pa.compute_dtype = torch.bfloat16
+    feat = torch.randn(n_img, levels.S, 256, device=DEV).to(torch.bfloat16)
+    x = torch.randn(Bq, Lq, 256, device=DEV)
+    r = (torch.rand(n_img, Lq, 1, 2, device=DEV) * 1.3 - 0.15).expand(n_img, Lq, L_, 2).contiguous()
+    mask = (torch.rand(n_img * Lq, device=DEV) < 0.7).to(torch.uint8)
+    with torch.no_grad():
+        pa.use_fast_path = False
+        a = pa.native_sample(x, r, feat, levels, n_img // Bq, Bq).float()
+        pa.use_fast_path = True
+        pa.sort_pairs = False
+        b = pa.native_sample(x, r, feat, levels, n_img // Bq, Bq).float()
+        pa.sort_pairs = "layer"
+        c = pa.native_sample(x, r, feat, levels, n_img // Bq, Bq, pair_mask=mask)
+    scale = float(a.abs().max())
+    assert torch.isfinite(b).all() and scale > 0
+    assert float((a - b).abs().max()) < 0.08 * scale
+    assert float((a - b).abs().mean()) < 5e-3 * scale
+    keep = mask.bool()
+    assert torch.equal(c[keep].float(), b[keep]) and int(c[~keep].float().abs().sum()) == 0
