@@ -134,8 +134,8 @@ __device__ __forceinline__ void write_act(char* __restrict__ act, const f32x16 (
           v[t] = keep[mt] ? x : 0.f;
         }
         uint2 pk;
-        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        pk.x = pack_bf16(v[0], v[1]);
+        pk.y = pack_bf16(v[2], v[3]);
         *reinterpret_cast<uint2*>(act + (row0 + mt * 32 + rl) * ACT_PITCH + n * 2) = pk;
       }
     }
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float a = row < nrow ? s[u][2 * t] * inv : 0.f, b = row < nrow ? s[u][2 * t + 1] * inv : 0.f;
-          op[t] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+          op[t] = pack_bf16(a, b);
         }
         *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = o;
       }
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       const f32x4 y = v[i] * rstd * *reinterpret_cast<const f32x4*>(g2 + c4 * 4) + *reinterpret_cast<const f32x4*>(be2 + c4 * 4);
       *reinterpret_cast<f32x4*>(xb + row * XP + c4 * 16) = y;                         // t1 (fp32, residual)
       uint2 pk;
-      pk.x = (unsigned)f32_to_bf16(y[0]) | ((unsigned)f32_to_bf16(y[1]) << 16);
-      pk.y = (unsigned)f32_to_bf16(y[2]) | ((unsigned)f32_to_bf16(y[3]) << 16);
+      pk.x = pack_bf16(y[0], y[1]);
+      pk.y = pack_bf16(y[2], y[3]);
       *reinterpret_cast<uint2*>(act + row * ACT_PITCH + c4 * 8) = pk;                 // t1 (bf16, GEMM operand)
     }
   }
@@ -513,8 +513,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       if (Wn) {   // operand of the next layer's query-term GEMM: tgt' + query_pos (bf16), into the now free act tile
         const f32x4 x = y[i] + qp[ps][i];
         uint2 pk;
-        pk.x = (unsigned)f32_to_bf16(x[0]) | ((unsigned)f32_to_bf16(x[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16(x[2]) | ((unsigned)f32_to_bf16(x[3]) << 16);
+        pk.x = pack_bf16(x[0], x[1]);
+        pk.y = pack_bf16(x[2], x[3]);
         *reinterpret_cast<uint2*>(act + row * ACT_PITCH + c4 * 8) = pk;
       }
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + c4 * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + c4 * 4);

@@ -19,12 +19,14 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned)v) << 16);
 }
 // round-to-nearest-even, NaN preserved
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction for two values; the integer
+// emulation -- NaN test, rounding add, shift -- was ~5 VALU instructions and a branch per value)
+typedef __bf16 mvg_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  const mvg_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
 
 // ---- 4-channel vector load / store in either storage type (always fp32 in registers)
 template <typename T> struct Vec4;
@@ -40,9 +42,7 @@ template <> struct Vec4<bf16_t> {
     return v;
   }
   static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
-    u16x4 r;
-    r[0] = f32_to_bf16(v[0]); r[1] = f32_to_bf16(v[1]); r[2] = f32_to_bf16(v[2]); r[3] = f32_to_bf16(v[3]);
-    *reinterpret_cast<u16x4*>(p) = r;
+    *reinterpret_cast<uint2*>(p) = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
   }
 };
 
@@ -58,10 +58,7 @@ template <> __device__ __forceinline__ void store_vec4<float>(float* p, float a,
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 template <> __device__ __forceinline__ void store_vec4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  uint2 pk;
-  pk.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
-  pk.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(d) << 16);
-  *reinterpret_cast<uint2*>(p) = pk;
+  *reinterpret_cast<uint2*>(p) = uint2{pack_bf16(a, b), pack_bf16(c, d)};
 }
 
 // Levels are passed by value to kernels (L <= MVG_MAX_LEVELS)

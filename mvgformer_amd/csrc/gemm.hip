@@ -51,10 +51,10 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
   f32x4 v = c.lo;
   if constexpr (BF16 && sizeof(TSRC) == 4) {
     unsigned w[4];
-    w[0] = (unsigned)f32_to_bf16(c.lo[0]) | ((unsigned)f32_to_bf16(c.lo[1]) << 16);
-    w[1] = (unsigned)f32_to_bf16(c.lo[2]) | ((unsigned)f32_to_bf16(c.lo[3]) << 16);
-    w[2] = (unsigned)f32_to_bf16(c.hi[0]) | ((unsigned)f32_to_bf16(c.hi[1]) << 16);
-    w[3] = (unsigned)f32_to_bf16(c.hi[2]) | ((unsigned)f32_to_bf16(c.hi[3]) << 16);
+    w[0] = pack_bf16(c.lo[0], c.lo[1]);
+    w[1] = pack_bf16(c.lo[2], c.lo[3]);
+    w[2] = pack_bf16(c.hi[0], c.hi[1]);
+    w[3] = pack_bf16(c.hi[2], c.hi[3]);
     v[0] = __uint_as_float(w[0]); v[1] = __uint_as_float(w[1]); v[2] = __uint_as_float(w[2]); v[3] = __uint_as_float(w[3]);
   }
   *reinterpret_cast<f32x4*>(lds + row * PITCH + col16 * 16) = v;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
           *reinterpret_cast<f32x4*>(dst) = v;
         } else {
           uint2 pk;
-          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          pk.x = pack_bf16(v[0], v[1]);
+          pk.y = pack_bf16(v[2], v[3]);
           *reinterpret_cast<uint2*>(dst) = pk;
         }
       }

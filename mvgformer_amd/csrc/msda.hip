@@ -183,15 +183,15 @@ __device__ __forceinline__ void store_acc(T* p, const float (&acc)[CPL]) {
     *reinterpret_cast<f32x4*>(p) = f32x4{acc[0], acc[1], acc[2], acc[3]};
   } else if constexpr (CPL == 4) {
     uint2 o;
-    o.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
-    o.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+    o.x = pack_bf16(acc[0], acc[1]);
+    o.y = pack_bf16(acc[2], acc[3]);
     *reinterpret_cast<uint2*>(p) = o;
   } else {
     uint4 o;
-    o.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
-    o.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
-    o.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
-    o.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+    o.x = pack_bf16(acc[0], acc[1]);
+    o.y = pack_bf16(acc[2], acc[3]);
+    o.z = pack_bf16(acc[4], acc[5]);
+    o.w = pack_bf16(acc[6], acc[7]);
     *reinterpret_cast<uint4*>(p) = o;
   }
 }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  return pack_bf16(lo, hi);
 }
 template <int S>   // value of lane S of every quad (v_mov_b32_dpp quad_perm:[S,S,S,S])
 __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
@@ -426,11 +426,13 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
       const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
       const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
       const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
-      const bf16_t* gb = G + ((long)n * S + lv.start[l]) * 192 + col;
-      const uint4 c00 = *reinterpret_cast<const uint4*>(gb + (long)(y0c * W + x0c) * 192);
-      const uint4 c10 = *reinterpret_cast<const uint4*>(gb + (long)(y0c * W + x1c) * 192);
-      const uint4 c01 = *reinterpret_cast<const uint4*>(gb + (long)(y1c * W + x0c) * 192);
-      const uint4 c11 = *reinterpret_cast<const uint4*>(gb + (long)(y1c * W + x1c) * 192);
+      // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
+      const char* g_bytes = reinterpret_cast<const char*>(G);
+      const unsigned gb = ((unsigned)(n * S + lv.start[l]) * 192u + (unsigned)col) * 2u;
+      const uint4 c00 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x0c) * 384u));
+      const uint4 c10 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x1c) * 384u));
+      const uint4 c01 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x0c) * 384u));
+      const uint4 c11 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x1c) * 384u));
       const float* xq = xw + ((long)b * Lq + q) * 192 + col;
       const f32x4 xa = *reinterpret_cast<const f32x4*>(xq), xb = *reinterpret_cast<const f32x4*>(xq + 4);
       const unsigned a4[4] = {c00.x, c00.y, c00.z, c00.w}, b4[4] = {c10.x, c10.y, c10.z, c10.w};
@@ -453,19 +455,26 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- pass 1: softmax denominator of the head's logits
+  // ---- pass 1: softmax denominator of the head's logits; the 4 lanes of the quad split the LP logits and combine
+  //      with DPP (same value in all four: the butterfly adds commute)
   float mx = -INFINITY;
   {
-    f32x4 lg[LP / 4];
+    constexpr int MYC = (LP / 4 + 3) / 4;            // 16-byte chunks per lane
+    f32x4 lg[MYC];
 #pragma unroll
-    for (int i = 0; i < LP / 4; ++i) {
-      lg[i] = *reinterpret_cast<const f32x4*>(sc + 4 * i);
+    for (int i = 0; i < MYC; ++i) {
+      const int c = sub + 4 * i;
+      lg[i] = (c < LP / 4) ? *reinterpret_cast<const f32x4*>(sc + 4 * c) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
     }
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xf, 0xf, false)));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xf, 0xf, false)));
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LP / 4; ++i)
+    for (int i = 0; i < MYC; ++i)     // exp(-inf) = 0 for the padding chunks
       sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
+    sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0xB1, 0xf, 0xf, false));
+    sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x4E, 0xf, 0xf, false));
     mx += __logf(sum);
   }
 
@@ -721,6 +730,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   if (e) return e;
   const long pairs = (long)N_img * Lq;
   if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
+  if ((long)N_img * S * 384 >= 0xffffffffL || (long)N_img * 8 * (S + 1) * 128 >= 0xffffffffL) return MVG_E_BADARG;   // 32-bit byte offsets
   if (pairs == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
 #define MVG_GS(LL, NT)                                                                                            \

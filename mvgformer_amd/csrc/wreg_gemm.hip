@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
         const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;                                                         \
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nn);                                           \
         uint2 pk;                                                                                                \
-        pk.x = (unsigned)f32_to_bf16(acc[j][4 * g] + bv[0]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 1] + bv[1]) << 16);     \
-        pk.y = (unsigned)f32_to_bf16(acc[j][4 * g + 2] + bv[2]) | ((unsigned)f32_to_bf16(acc[j][4 * g + 3] + bv[3]) << 16); \
+        pk.x = pack_bf16(acc[j][4 * g] + bv[0], acc[j][4 * g + 1] + bv[1]);     \
+        pk.y = pack_bf16(acc[j][4 * g + 2] + bv[2], acc[j][4 * g + 3] + bv[3]); \
         *reinterpret_cast<uint2*>(stage + rl * ACT_PITCH + nn * 2) = pk;                                         \
       }                                                                                                          \
     prev_tile = tile;                                                                                            \
