@@ -177,6 +177,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
         self._flag = None      # set by DQDecoder.forward: this layer's zeroed any-valid flag (int32[1])
+        self._geo_out = None   # set by DQDecoder.forward: this layer's slices of the stacked 3D / 2D outputs
         self._next_layer = None   # set by DQDecoder.forward: the layer that consumes this layer's output
         self._xw_in = None        # set by the previous layer: this layer's query term (B*Lq,192) f32
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
@@ -427,7 +428,8 @@ class DQDecoderLayer(MvPDecoderLayer):
     def forward_triangulate(self, st, ctx):
         """step 5: triangulation + scatter (learnable_triangulate, dq_decoder.py:399-461,1013-1029)."""
         V, B, NQ, J = st["dims"]
-        new_ref, ref2d, proj2d = ops.triangulate(st["r"], st["o"], ctx.cams, st["valid"], st["any_valid"], V, B, NQ, J)
+        new_ref, ref2d, proj2d = ops.triangulate(st["r"], st["o"], ctx.cams, st["valid"], st["any_valid"], V, B, NQ, J,
+                                                 out=self._geo_out)
         return st["tgt_update"], new_ref, ref2d, proj2d, st["prob"]
 
 
@@ -519,11 +521,19 @@ class DQDecoder(MvPDecoder):
         if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
             hs_buf = torch.empty((len(self.layers),) + tuple(tgt.shape), dtype=torch.float32, device=tgt.device)
         flags = torch.zeros((len(self.layers),), dtype=torch.int32, device=tgt.device) if tgt.is_cuda else None
+        geo_buf = None
+        if hs_buf is not None:
+            nl, Bq, Lq_ = len(self.layers), tgt.shape[0], tgt.shape[1]
+            Vn = ctx.V
+            geo_buf = (torch.empty((nl, Bq, Lq_, 3), dtype=torch.float32, device=tgt.device),
+                       torch.empty((nl, Bq, Vn, Lq_, 2), dtype=torch.float32, device=tgt.device),
+                       torch.empty((nl, Bq, Vn, Lq_, 2), dtype=torch.float32, device=tgt.device))
         try:
             for lid, layer in enumerate(self.layers):
                 layer._ctx = ctx
                 layer._tgt_out = None if hs_buf is None else hs_buf[lid]
                 layer._flag = None if flags is None else flags[lid:lid + 1]
+                layer._geo_out = None if geo_buf is None else (geo_buf[0][lid], geo_buf[1][lid], geo_buf[2][lid])
                 layer._next_layer = ((self.layers[lid + 1],) if (self.fuse_next_query_term and lid + 1 < len(self.layers))
                                      else None)
                 output, reference_points, ref_points_2d, projs_2d_absolute, outputs_class = layer(
@@ -542,6 +552,7 @@ class DQDecoder(MvPDecoder):
                 layer._ctx = None
                 layer._tgt_out = None
                 layer._flag = None
+                layer._geo_out = None
                 layer._next_layer = None
                 layer._xw_in = None
                 layer.proj_attn._vp_event = None
@@ -551,7 +562,14 @@ class DQDecoder(MvPDecoder):
             in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape
                                                   for i, t in enumerate(inter))
             hs = hs_buf if in_place else torch.stack(inter)
-            return hs, torch.stack(inter_ref), torch.stack(inter_2d), torch.stack(inter_proj), classes
+
+            def stacked(parts, buf):
+                same = buf is not None and all(t.data_ptr() == buf[i].data_ptr() and t.shape == buf[i].shape
+                                               for i, t in enumerate(parts))
+                return buf if same else torch.stack(parts)
+            return (hs, stacked(inter_ref, None if geo_buf is None else geo_buf[0]),
+                    stacked(inter_2d, None if geo_buf is None else geo_buf[1]),
+                    stacked(inter_proj, None if geo_buf is None else geo_buf[2]), classes)
         return output, reference_points, ref_points_2d
 
 

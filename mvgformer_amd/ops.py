@@ -397,12 +397,19 @@ def rowdot3(h, W3, b3):
     return o
 
 
-def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J):
+def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J, out=None):
+    """out: optional caller-owned (new_ref (B,Lq,3), ref2d (B,V,Lq,2), proj2d (B,V,Lq,2)) contiguous f32 destinations
+    (e.g. slices of the stacked per-layer outputs)."""
     Lq = NQ * J
     dev = r.device
-    new_ref = torch.empty((B, Lq, 3), dtype=torch.float32, device=dev)
-    ref2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
-    proj2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
+    if out is not None:
+        new_ref, ref2d, proj2d = out
+        for t, shp in ((new_ref, (B, Lq, 3)), (ref2d, (B, V, Lq, 2)), (proj2d, (B, V, Lq, 2))):
+            assert tuple(t.shape) == shp and t.dtype == torch.float32 and t.is_contiguous()
+    else:
+        new_ref = torch.empty((B, Lq, 3), dtype=torch.float32, device=dev)
+        ref2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
+        proj2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
     with _timed("triangulate"):
       L.check(L.load().mvg_triangulate(L.ptr(r), L.ptr(o), L.ptr(cams), L.ptr(valid), L.ptr(any_valid), L.ptr(new_ref),
                                      L.ptr(ref2d), L.ptr(proj2d), V, B, NQ, J, L.stream_ptr()), "mvg_triangulate")
