@@ -292,119 +292,141 @@ __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][
   }
 }
 
-// 8 lanes per (batch, query, joint) problem: lane `sub` handles views sub, sub+8, ... (un-crop, undistortion, its
-// two DLT rows and their contribution to the 4x4 Gram matrix), the view-softmax and the Gram matrix are reduced
-// over the 8 lanes with wavefront shuffles, then every lane runs the fp64 Jacobi redundantly (no divergence) and
-// lane 0 stores.  (One thread per problem with a serial view loop took 27 us at cfg-2: 240 wavefronts, each a
-// chain of dependent global loads; this form is one load round trip.)
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, mask, 64);
-  hi = __shfl_xor(hi, mask, 64);
-  return __hiloint2double(hi, lo);
+// Two phases per workgroup of 512 threads = 64 (batch, query, joint) problems:
+//   1. 8 lanes per problem: lane `sub` handles views sub, sub+8, ... (view-softmax, un-crop, undistortion, its two
+//      DLT rows and their contribution to the 4x4 Gram matrix) -- one load round trip for the whole problem;
+//      the partial Gram matrices (upper triangle, fp64) go to LDS.
+//   2. one lane per problem (the first wavefront): sums the 8 partials and runs the fp64 Jacobi.
+// (All 8 lanes of a problem running the Jacobi redundantly made the kernel fp64-VALU-bound: 14 of its 22 us at
+// cfg-2; one thread per problem for BOTH phases took 27 us: 240 wavefronts, each a chain of dependent loads.)
+constexpr int TRI_PROBS = 64;           // problems per workgroup
+constexpr int TRI_PAD = 9;              // doubles per (entry, problem) row: 8 partials + 1 pad (bank spread)
+
+__device__ __forceinline__ float max8(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+  return v;
+}
+__device__ __forceinline__ float add8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+  return v;
 }
 
-__global__ __launch_bounds__(256) void triangulate_kernel(const float* __restrict__ r, const float* __restrict__ o,
+__global__ __launch_bounds__(512) void triangulate_kernel(const float* __restrict__ r, const float* __restrict__ o,
                                                           const float* __restrict__ cams,
                                                           const uint8_t* __restrict__ valid,
                                                           const int* __restrict__ any_valid,
                                                           float* __restrict__ new_ref, float* __restrict__ ref2d,
                                                           float* __restrict__ proj2d, int V, int B, int NQ, int J) {
-  const long tidg = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double gram[10][TRI_PROBS][TRI_PAD];
+  const int tid = threadIdx.x, pl = tid >> 3, sub = tid & 7;
   const int Lq = NQ * J;
   const long nprob = (long)B * Lq;
-  long idx = tidg >> 3;
-  const int sub = (int)(tidg & 7);
-  const bool live = idx < nprob;
-  if (!live) idx = nprob - 1;                     // keep the 8-lane groups converged for the shuffles
+  {
+    long idx = (long)blockIdx.x * TRI_PROBS + pl;
+    const bool live = idx < nprob;
+    if (!live) idx = nprob - 1;                     // keep the 8-lane groups converged for the DPP reductions
+    const int q = (int)(idx % Lq), b = (int)(idx / Lq);
+    const int i = q / J;
+    bool ok = valid[b * NQ + i] != 0;
+    if (!ok && any_valid[0] == 0 && b == 0 && i == 0) ok = true;   // dq_decoder.py:620-623
+
+    // softmax over views of the confidence logit (dq_decoder.py:706-707)
+    float mx = -INFINITY;
+    for (int v = sub; v < V; v += 8) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
+    mx = max8(mx);
+    float den = 0.f;
+    for (int v = sub; v < V; v += 8) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
+    den = add8(den);
+
+    double G[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) G[e] = 0.0;
+
+    for (int v = sub; v < V; v += 8) {
+      const long pair = ((long)v * B + b) * Lq + q;
+      const float* cam = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
+      const float imgw = cam[36], imgh = cam[37];
+      const float rx = r[pair * 2], ry = r[pair * 2 + 1];
+      const float dx = o[pair * 3], dy = o[pair * 3 + 1];
+      const float conf = expf(o[pair * 3 + 2] - mx) / den;
+      const float px = rx * imgw, py = ry * imgh;                                   // dq_decoder.py:699
+      const float kx = (rx + dx / imgw) * imgw, ky = (ry + dy / imgh) * imgh;       // :679-685,696
+      if (live) {
+        const long oidx = (((long)b * V + v) * Lq + q) * 2;
+        *reinterpret_cast<float2*>(ref2d + oidx) = ok ? make_float2(kx, ky) : make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(proj2d + oidx) = ok ? make_float2(px, py) : make_float2(0.f, 0.f);
+      }
+      // un-crop (dq_decoder.py:414-420)
+      const float uo = cam[27] * kx + cam[28] * ky + cam[29];
+      const float vo = cam[30] * kx + cam[31] * ky + cam[32];
+      // undistort (dq_decoder.py:119-204)
+      const float fx = cam[12], fy = cam[13], cx = cam[14], cy = cam[15];
+      const float k1 = cam[16], k2 = cam[17], k3 = cam[18], p1 = cam[19], p2 = cam[20];
+      const float x0 = uo * (1.f / fx) + (-cx / fx), y0 = vo * (1.f / fy) + (-cy / fy);
+      float x = x0, y = y0;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const float r2 = x * x + y * y;
+        const float icd = 1.f / (1.f + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const float dX = 2.f * p1 * x * y + p2 * (r2 + 2.f * x * x);
+        const float dY = p1 * (r2 + 2.f * y * y) + 2.f * p2 * x * y;
+        x = (x0 - dX) * icd;
+        y = (y0 - dY) * icd;
+      }
+      const float udx = fx * x + cx, udy = fy * y + cy;
+      // P = K [R | -R T]  (dq_decoder.py:223-246)
+      float RT[3][4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        RT[a][0] = cam[3 * a]; RT[a][1] = cam[3 * a + 1]; RT[a][2] = cam[3 * a + 2];
+        RT[a][3] = -(cam[3 * a] * cam[9] + cam[3 * a + 1] * cam[10] + cam[3 * a + 2] * cam[11]);
+      }
+      float a1[4], a2[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float P0 = fx * RT[0][c] + cx * RT[2][c];
+        const float P1 = fy * RT[1][c] + cy * RT[2][c];
+        const float P2 = RT[2][c];
+        a1[c] = (P2 * udx - P0) * conf;                                             // multiview.py:196-202
+        a2[c] = (P2 * udy - P1) * conf;
+      }
+      int e = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = a; c < 4; ++c, ++e) G[e] += (double)a1[a] * (double)a1[c] + (double)a2[a] * (double)a2[c];
+    }
+#pragma unroll
+    for (int e = 0; e < 10; ++e) gram[e][pl][sub] = G[e];
+  }
+  __syncthreads();
+  if (tid >= TRI_PROBS) return;
+
+  // ---- phase 2: one lane per problem
+  const long idx = (long)blockIdx.x * TRI_PROBS + tid;
+  if (idx >= nprob) return;
   const int q = (int)(idx % Lq), b = (int)(idx / Lq);
   const int i = q / J;
   bool ok = valid[b * NQ + i] != 0;
-  if (!ok && any_valid[0] == 0 && b == 0 && i == 0) ok = true;   // dq_decoder.py:620-623
-
-  // softmax over views of the confidence logit (dq_decoder.py:706-707)
-  float mx = -INFINITY;
-  for (int v = sub; v < V; v += 8) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
-#pragma unroll
-  for (int m_ = 1; m_ < 8; m_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m_, 64));
-  float den = 0.f;
-  for (int v = sub; v < V; v += 8) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
-#pragma unroll
-  for (int m_ = 1; m_ < 8; m_ <<= 1) den += __shfl_xor(den, m_, 64);
-
+  if (!ok && any_valid[0] == 0 && b == 0 && i == 0) ok = true;
   double G[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) G[a][c] = 0.0;
-
-  for (int v = sub; v < V; v += 8) {
-    const long pair = ((long)v * B + b) * Lq + q;
-    const float* cam = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
-    const float imgw = cam[36], imgh = cam[37];
-    const float rx = r[pair * 2], ry = r[pair * 2 + 1];
-    const float dx = o[pair * 3], dy = o[pair * 3 + 1];
-    const float conf = expf(o[pair * 3 + 2] - mx) / den;
-    const float px = rx * imgw, py = ry * imgh;                                   // dq_decoder.py:699
-    const float kx = (rx + dx / imgw) * imgw, ky = (ry + dy / imgh) * imgh;       // :679-685,696
-    if (live) {
-      const long oidx = (((long)b * V + v) * Lq + q) * 2;
-      *reinterpret_cast<float2*>(ref2d + oidx) = ok ? make_float2(kx, ky) : make_float2(0.f, 0.f);
-      *reinterpret_cast<float2*>(proj2d + oidx) = ok ? make_float2(px, py) : make_float2(0.f, 0.f);
-    }
-    // un-crop (dq_decoder.py:414-420)
-    const float uo = cam[27] * kx + cam[28] * ky + cam[29];
-    const float vo = cam[30] * kx + cam[31] * ky + cam[32];
-    // undistort (dq_decoder.py:119-204)
-    const float fx = cam[12], fy = cam[13], cx = cam[14], cy = cam[15];
-    const float k1 = cam[16], k2 = cam[17], k3 = cam[18], p1 = cam[19], p2 = cam[20];
-    const float x0 = uo * (1.f / fx) + (-cx / fx), y0 = vo * (1.f / fy) + (-cy / fy);
-    float x = x0, y = y0;
-#pragma unroll
-    for (int it = 0; it < 5; ++it) {
-      const float r2 = x * x + y * y;
-      const float icd = 1.f / (1.f + ((k3 * r2 + k2) * r2 + k1) * r2);
-      const float dX = 2.f * p1 * x * y + p2 * (r2 + 2.f * x * x);
-      const float dY = p1 * (r2 + 2.f * y * y) + 2.f * p2 * x * y;
-      x = (x0 - dX) * icd;
-      y = (y0 - dY) * icd;
-    }
-    const float udx = fx * x + cx, udy = fy * y + cy;
-    // P = K [R | -R T]  (dq_decoder.py:223-246)
-    float RT[3][4];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      RT[a][0] = cam[3 * a]; RT[a][1] = cam[3 * a + 1]; RT[a][2] = cam[3 * a + 2];
-      RT[a][3] = -(cam[3 * a] * cam[9] + cam[3 * a + 1] * cam[10] + cam[3 * a + 2] * cam[11]);
-    }
-    float a1[4], a2[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float P0 = fx * RT[0][c] + cx * RT[2][c];
-      const float P1 = fy * RT[1][c] + cy * RT[2][c];
-      const float P2 = RT[2][c];
-      a1[c] = (P2 * udx - P0) * conf;                                             // multiview.py:196-202
-      a2[c] = (P2 * udy - P1) * conf;
-    }
+  {
+    int e = 0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int c = a; c < 4; ++c) G[a][c] += (double)a1[a] * (double)a1[c] + (double)a2[a] * (double)a2[c];
+      for (int c = a; c < 4; ++c, ++e) {
+        double g = 0.0;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) g += gram[e][tid][s8];     // Gram matrix over all views
+        G[a][c] = g;
+        G[c][a] = g;
+      }
   }
-  // Gram matrix over all views: butterfly sum across the 8 lanes of the problem (same result on every lane)
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = a; c < 4; ++c) {
-      double g = G[a][c];
-#pragma unroll
-      for (int m_ = 1; m_ < 8; m_ <<= 1) g += shfl_xor_f64(g, m_);
-      G[a][c] = g;
-    }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < a; ++c) G[a][c] = G[c][a];
 
   double Vm[4][4];
 #pragma unroll
@@ -431,12 +453,10 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
       e0 = Vm[0][c]; e1 = Vm[1][c]; e2 = Vm[2][c]; e3 = Vm[3][c];
     }
   }
-  if (live && sub == 0) {
-    float* nr = new_ref + ((long)b * Lq + q) * 3;
-    nr[0] = ok ? (float)(e0 / e3) : 0.f;                                          // multiview.py:220-221
-    nr[1] = ok ? (float)(e1 / e3) : 0.f;
-    nr[2] = ok ? (float)(e2 / e3) : 0.f;
-  }
+  float* nr = new_ref + ((long)b * Lq + q) * 3;
+  nr[0] = ok ? (float)(e0 / e3) : 0.f;                                            // multiview.py:220-221
+  nr[1] = ok ? (float)(e1 / e3) : 0.f;
+  nr[2] = ok ? (float)(e2 / e3) : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -665,9 +685,9 @@ int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, fl
 int mvg_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
                     float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J, void* stream) {
   if (!r || !o || !cams || !valid || !any_valid || !new_ref || !ref2d || !proj2d || V <= 0) return MVG_E_BADARG;
-  const long total = (long)B * NQ * J * 8;       // 8 lanes per (batch, query, joint)
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, r, o, cams,
+  const long nprob = (long)B * NQ * J;            // 64 problems per 512-thread workgroup (8 lanes each in phase 1)
+  if (nprob == 0) return 0;
+  hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(nprob, TRI_PROBS)), dim3(512), 0, (hipStream_t)stream, r, o, cams,
                      valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J);
   MVG_LAUNCH_CHECK();
   return 0;
