@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) void rowdot3_kernel(const T* __restrict__ h, c
 //    smallest eigenvector (= smallest right singular vector of A, torch.linalg.svd's Vh[3]) is
 //    found with cyclic Jacobi rotations in fp64.  Squaring the condition number in fp64
 //    (eps 1.1e-16) leaves far more headroom than an fp32 SVD of A (eps 6e-8) has.
-__device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][4], const int p, const int q) {
+__device__ __forceinline__ void jacobi_angle(const double (&a)[4][4], const int p, const int q, double& c, double& s) {
+  c = 1.0;
+  s = 0.0;
   const double apq = a[p][q];
   if (fabs(apq) < 1e-300) return;
   // The rotation ANGLE only steers convergence, so it is computed in fp32 (one fast division, one sqrt); what
@@ -268,10 +270,15 @@ __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][
   const float tf = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
   const double t = (double)tf;
   const double w = t * t + 1.0;
-  double c = (double)rsqrtf((float)w);
-  c = c * (1.5 - 0.5 * w * c * c);
-  c = c * (1.5 - 0.5 * w * c * c);
-  const double s = t * c;
+  double cc = (double)rsqrtf((float)w);
+  cc = cc * (1.5 - 0.5 * w * cc * cc);
+  cc = cc * (1.5 - 0.5 * w * cc * cc);
+  c = cc;
+  s = t * cc;
+}
+
+__device__ __forceinline__ void jacobi_apply(double (&a)[4][4], double (&v)[4][4], const int p, const int q, const double c,
+                                             const double s) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {   // columns p,q of A
     const double akp = a[k][p], akq = a[k][q];
@@ -290,6 +297,18 @@ __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][
     v[k][p] = c * vkp - s * vkq;
     v[k][q] = s * vkp + c * vkq;
   }
+}
+
+// Two rotations on disjoint index pairs: (p2, q2) does not see what (p1, q1) changes in the entries its angle is
+// computed from, so both angles come from the same matrix -- two independent latency chains instead of one after
+// the other -- and applying them in sequence IS the cyclic order (p1,q1), (p2,q2).
+__device__ __forceinline__ void jacobi_rotate2(double (&a)[4][4], double (&v)[4][4], const int p1, const int q1,
+                                               const int p2, const int q2) {
+  double c1, s1, c2, s2;
+  jacobi_angle(a, p1, q1, c1, s1);
+  jacobi_angle(a, p2, q2, c2, s2);
+  jacobi_apply(a, v, p1, q1, c1, s1);
+  jacobi_apply(a, v, p2, q2, c2, s2);
 }
 
 // Two phases per workgroup of 512 threads = 64 (batch, query, joint) problems:
@@ -437,12 +456,9 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
     const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
     const double lg = fmax(fmax(fabs(G[0][0]), fabs(G[1][1])), fmax(fabs(G[2][2]), fabs(G[3][3])));
     if (off <= 2e-16 * lg) break;     // off-diagonals at the fp64 rounding floor of the matrix: converged
-    jacobi_rotate(G, Vm, 0, 1);
-    jacobi_rotate(G, Vm, 0, 2);
-    jacobi_rotate(G, Vm, 0, 3);
-    jacobi_rotate(G, Vm, 1, 2);
-    jacobi_rotate(G, Vm, 1, 3);
-    jacobi_rotate(G, Vm, 2, 3);
+    jacobi_rotate2(G, Vm, 0, 1, 2, 3);
+    jacobi_rotate2(G, Vm, 0, 2, 1, 3);
+    jacobi_rotate2(G, Vm, 0, 3, 1, 2);
   }
   double best = G[0][0];
   double e0 = Vm[0][0], e1 = Vm[1][0], e2 = Vm[2][0], e3 = Vm[3][0];
