@@ -53,6 +53,10 @@ def main():
                     help="layout the feature pyramid is handed over in (SURVEY 8 f3): nchw = fp32 NCHW maps as the "
                          "reference's backbone emits them (default, the headline configuration); nhwc = channels-last "
                          "maps in the compute dtype; inplace = the producer wrote into DecoderContext.pyramid_buffers()")
+    ap.add_argument("--shard", default="queries", choices=["queries", "samples"],
+                    help="N > 1: queries = ONE sample per step, its person-queries sharded over the ranks + all-gather of "
+                         "the pose set (BASELINE configs[2], strong scaling; default); samples = one sample per rank and "
+                         "step, all-gather of the final pose sets (batch-parallel replicas, weak scaling)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -87,7 +91,9 @@ def main():
     elem = 2 if args.dtype == "bf16" else 4
     thr = 0.1
 
-    case = build_case(args.config, seed=0, valid_fraction=args.valid_fraction)
+    sharded = world > 1 and args.shard == "queries"       # one sample, queries split over the ranks
+    replicas = world > 1 and args.shard == "samples"      # one sample per rank
+    case = build_case(args.config, seed=rank if replicas else 0, valid_fraction=args.valid_fraction)
     NQ, J, V, Ly = case.NQ, 15, case.V, case.layers
     cpu_case = None
     if rank == 0 and args.cpu_baseline and world == 1:
@@ -95,9 +101,10 @@ def main():
         cpu_case = copy.copy(case)      # keeps the host tensors; case_to_device() rebinds `case`'s attributes
     dec = build_decoder_for_case(case, dev, dtype)
     g = case_to_device(case, dev)
-    lo, hi = mdist.shard_bounds(NQ, world, rank)
-    tgt, qpos, ref, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, J, world, rank)
-    if world > 1:
+    lo, hi = mdist.shard_bounds(NQ, world if sharded else 1, rank if sharded else 0)
+    tgt, qpos, ref, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, J, world if sharded else 1,
+                                            rank if sharded else 0)
+    if sharded:
         mdist.install_any_valid_sync(dec, None)
 
     # host-side, per-sample preparation that belongs to data loading (camera records)
@@ -115,9 +122,19 @@ def main():
         ctx.feat = None
         out = dec(tgt, ref, src_views, g.meta, g.spatial_shapes, g.level_start_index, None, query_pos=qpos,
                   threshold=thr, context=ctx)
-        if world > 1:
+        if sharded:
             out = mdist.gather_outputs(out, NQ, J, None, gather_hidden=False)
         return out
+
+    pose_recv = None
+
+    def exchange_poses(o):
+        """replica mode: the final pose sets of all ranks' samples on every rank (one small all-gather per step)"""
+        nonlocal pose_recv
+        send = torch.cat([o[1][-1].reshape(-1), o[4][-1].reshape(-1)])
+        if pose_recv is None:
+            pose_recv = send.new_empty((world * send.numel(),))
+        dist.all_gather_into_tensor(pose_recv, send)
 
     use_graph = True if args.graph < 0 else bool(args.graph)
     graph = None
@@ -125,7 +142,7 @@ def main():
         for _ in range(3):
             out = forward()
         torch.cuda.synchronize()
-        if use_graph and world > 1:
+        if use_graph and sharded:
             # segments between the collectives are graphs, the RCCL calls stay eager (mvgformer_amd.dist)
             for layer in dec.layers:
                 layer._any_valid_hook = None
@@ -157,6 +174,12 @@ def main():
                 graph = None
                 torch.cuda.synchronize()
         step = (lambda: graph.replay()) if graph is not None else forward
+        if replicas:
+            inner = step
+
+            def step():
+                res = inner()
+                exchange_poses(out if graph is not None else res)
 
         for _ in range(args.warmup):
             step()
@@ -177,7 +200,7 @@ def main():
 
         # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
         prof = {}
-        if world > 1:
+        if sharded:
             mdist.install_any_valid_sync(dec, None)
         if args.profile_steps > 0:                 # every rank runs it (the sharded forward contains collectives)
             if rank == 0:
@@ -197,7 +220,7 @@ def main():
     refs = out[1]
     assert torch.isfinite(refs).all(), "non-finite poses"
     ms_per_step = elapsed / args.steps * 1e3
-    value = args.steps / elapsed                          # samples / s (whole job: one sample per step)
+    value = (world if replicas else 1) * args.steps / elapsed   # samples / s of the whole job
 
     # roofline of the dominant kernel: one sampling-kernel launch covers all V views of one layer
     Lq_loc = (hi - lo) * J
@@ -250,14 +273,15 @@ def main():
         else "decoder samples/sec (%s)" % args.config,
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: %d views, %d queries x %d joints, %d decoder layers, maps %s x 256ch, "
                                "all queries valid" % (args.config, V, NQ, J, Ly, case.shapes)
                    if args.valid_fraction is None else
                    "%s: %d views, %d queries x %d joints, %d layers, ~%.0f%% queries valid"
                    % (args.config, V, NQ, J, Ly, 100 * args.valid_fraction),
-                   "parallelism": "queries sharded x%d + all-gather" % world if world > 1 else "single GPU",
+                   "parallelism": ("queries sharded x%d + all-gather" % world if sharded else
+                                   "one sample per GPU x%d + all-gather of the pose sets" % world if replicas else "single GPU"),
                    "pyramid_handoff": {"nchw": "NCHW fp32 (reference producer format), packed per step",
                                        "nhwc": "channels-last %s, copied per step" % args.dtype,
                                        "inplace": "produced in the packed layout (no per-step pack)"}[args.producer],
