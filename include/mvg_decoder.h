@@ -55,8 +55,10 @@ extern "C" {
 int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
 const char* mvg_version(void);
 /* Kernel-variant knobs for A/B measurements (host-only, process-wide; env MVG_TUNE="k=v,..").  Keys:
- *   "fused_cpl_bf16" = 4 | 8, "fused_nb" = 4 | 8 : generic fused sampling kernel variants;
- *   "chain_rm" = 64 | 128, "chain_a_waves" / "chain_waves" = 4 | 8     : fused Linear-chain geometry. */
+ *   "fused_cpl_bf16" = 4 | 8 : channels per lane of the generic fused sampling kernel (bf16);
+ *   "gsamp_threads" = 256 | 512 | 1024 : workgroup size of the G-sampling kernel;
+ *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
+ *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs. */
 int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------

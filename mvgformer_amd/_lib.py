@@ -67,7 +67,7 @@ def load():
     lib.mvg_version.restype = C.c_char_p
     lib.mvg_version.argtypes = []
     _lib = lib
-    # A/B knobs for measurements: MVG_TUNE="chain_rm=128,fused_nb=4"
+    # A/B knobs for measurements: MVG_TUNE="chain_rm=128,gsamp_threads=256"
     for item in filter(None, os.environ.get("MVG_TUNE", "").split(",")):
         k, v = item.split("=")
         check(lib.mvg_set_tuning(k.strip().encode(), int(v)), "mvg_set_tuning(%s)" % item)

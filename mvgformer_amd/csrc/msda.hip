@@ -540,7 +540,6 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
 }
 
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
-static int g_fused_nb = 4;         // tuning knob: samples per gather batch (4 or 8)
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
@@ -562,17 +561,14 @@ static int launch_msda_fused_cpl(const T* value, const float* oa, const float* r
 static int launch_msda_fused(const float* value, const float* oa, const float* r, const LevelTable& lv, float* samp,
                              int n_pairs, int Lq, int S, hipStream_t st) {
   if (n_pairs <= 0) return 0;
-  if (g_fused_nb == 8) return launch_msda_fused_cpl<float, 4, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
   return launch_msda_fused_cpl<float, 4, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
 }
 static int launch_msda_fused(const bf16_t* value, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
                              int n_pairs, int Lq, int S, hipStream_t st) {
   if (n_pairs <= 0) return 0;
   if (g_fused_cpl_bf16 == 4) {
-    if (g_fused_nb == 8) return launch_msda_fused_cpl<bf16_t, 4, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
     return launch_msda_fused_cpl<bf16_t, 4, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
   }
-  if (g_fused_nb == 8) return launch_msda_fused_cpl<bf16_t, 8, 8>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
   return launch_msda_fused_cpl<bf16_t, 8, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
 }
 
@@ -769,7 +765,6 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
-  if (!strcmp(key, "fused_nb") && (value == 4 || value == 8)) { g_fused_nb = value; return 0; }
   return MVG_E_BADARG;
 }
 
