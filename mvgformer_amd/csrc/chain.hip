@@ -160,7 +160,10 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   float* w2s = reinterpret_cast<float*>(smem + RM * ACT_PITCH + RM * sizeof(int));   // last pose layer (3 x 256 f32)
   const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
   const int r0 = blockIdx.x * RM, row0 = (JN == 1) ? 0 : (tid >> 8) * MT * 32;
-  const int rot = (blockIdx.x * 7 + (JN == 1 ? (tid >> 6) : ((tid >> 6) & 3)) * 3) & 15;   // de-synchronise the weight walk
+  // k-step rotation per wavefront only, NOT per tile: which tile a row lands in depends on the processing order
+  // (mvg_bin_pairs: the order inside a bin is whatever the LDS atomics produce), and a row's fp32 accumulation order
+  // -- hence its result, bit for bit -- must not.  (A per-tile rotation was worth 1 us of 39.)
+  const int rot = ((JN == 1 ? (tid >> 6) : ((tid >> 6) & 3)) * 3) & 15;
 
   // Tile row i works on global row order[r0 + i] (the sampler's processing order: rows whose reference point is
   // outside the image come last, mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
