@@ -343,6 +343,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   const int rpt = qpt * J;                               // real rows per tile (60)
   const int q0 = blockIdx.x * qpt, r0 = q0 * J;
   const int nrow = min(rpt, rows - r0);
+  // per tile AND wavefront (worth 5 us of 48 here): tiles are fixed blocks of queries, so results are reproducible;
+  // a query-sharded run numbers its tiles differently and may differ from the unsharded one in the last bf16 bit
   const int rot = (blockIdx.x * 7 + (JN == 1 ? wave : (wave & 3)) * 3) & 15;
 
   // Row phases (LayerNorms, class head): 8 lanes per row, a wavefront works on 8 rows at once; lane (g = lane>>3,
