@@ -262,12 +262,23 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
       const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + part * CPT + c + 4);
       s[k] += hf[0] * wa[0] + hf[1] * wa[1] + hf[2] * wa[2] + hf[3] * wa[3] + hf[4] * wb[0] + hf[5] * wb[1] +
               hf[6] * wb[2] + hf[7] * wb[3];
+      // Keep the three accumulators scalar.  hipcc (ROCm 7.2) pairs s[0], s[1] into v_pk_mul/v_pk_fma_f32 fed by
+      // v_mov/v_pk_mov shuffles of the ds_read_b128 results, and that sequence returned wrong sums in lanes 48-63 of
+      // a wavefront, run-to-run differently, whenever two workgroups shared a CU (found by tools/soak.py; the
+      // packed pair was always the culprit: component 2, computed with scalar FMAs, never differed).
+      asm volatile("" : "+v"(s[k]));
     }
   }
+  // sum over the TPR (2 | 4 | 8) adjacent lanes of a row with DPP (quad_perm xor 1, xor 2, row_half_mirror)
 #pragma unroll
-  for (int off = 1; off < TPR; off <<= 1)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s[k] += __shfl_xor(s[k], off, 64);
+  for (int k = 0; k < 3; ++k) {
+    float v = s[k];
+    if (TPR >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    if (TPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    if (TPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    s[k] = v;
+  }
+  static_assert(TPR == 2 || TPR == 4 || TPR == 8, "threads per row of the last pose layer");
   if (part == 0 && rid[row] >= 0) {
     float* og = o + (long)rid[row] * 3;
     og[0] = s[0] + b2[0];

@@ -749,3 +749,23 @@ def test_bf16_decoder_is_deterministic_and_order_independent():
         assert torch.equal(x, y) and torch.equal(x, z)
     for x, y, z in zip(a[4], b[4], c[4]):
         assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_full_size_bf16_forward_is_bit_reproducible():
+    """cfg-2 at full size (two workgroups per CU in the chain kernels, every kernel at its real occupancy): three eager
+    runs of the bf16 decoder are bit-identical.  (This is the test that a small case cannot replace: a miscompiled
+    packed-fp32 sequence in chain A only misbehaved with two workgroups per CU -- 2 % of the rows, run-to-run
+    different, inside every tolerance.)"""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("cfg2", seed=0)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    run = lambda: dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                      query_pos=gc.query_pos, threshold=0.1)
+    with torch.no_grad():
+        a = [t.clone() for t in run()[:4]]
+        for _ in range(2):
+            b = run()
+            torch.cuda.synchronize()
+            for x, y in zip(a, b[:4]):
+                assert torch.equal(x, y)

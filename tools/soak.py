@@ -1,0 +1,54 @@
+"""Soak test: N graph replays of the cfg-2 bf16 forward; the outputs must stay bit-identical (the processing order of
+the pairs is the only nondeterministic quantity and must not leak into the results).  GPU only."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from mvgformer_amd.decoder import DecoderContext  # noqa: E402
+from mvgformer_amd.factory import build_decoder_for_case, case_to_device  # noqa: E402
+from mvgformer_amd.synthetic import build_case  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+case = build_case("cfg2", seed=0)
+dec = build_decoder_for_case(case, "cuda", torch.bfloat16)
+g = case_to_device(case, "cuda")
+ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, torch.bfloat16, 1, "cuda")
+
+
+def fwd():
+    ctx.feat = None
+    return dec(g.tgt, g.reference_points, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None,
+               query_pos=g.query_pos, threshold=0.1, context=ctx)
+
+
+with torch.no_grad():
+    for _ in range(3):
+        ref = fwd()
+    ref = [t.clone() for t in ref[:4]]
+    again = fwd()
+    names = ("hs", "refs", "refs2d", "projs2d")
+    for nm, a, b in zip(names, again[:4], ref):
+        d = (a.float() - b.float()).abs()
+        print("eager vs eager %-8s identical=%s  max|d|=%.3e  n_diff=%d" % (nm, torch.equal(a, b), float(d.max()), int((d > 0).sum())))
+    for li in range(4):
+        print("  layer %d hs identical: %s  refs identical: %s" % (li, torch.equal(again[0][li], ref[0][li]), torch.equal(again[1][li], ref[1][li])))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd()
+    bad = 0
+    for i in range(n):
+        graph.replay()
+        if i % 250 == 249:
+            torch.cuda.synchronize()
+            same = all(torch.equal(a, b) for a, b in zip(out[:4], ref))
+            if not same and i < 300:
+                for nm, a, b in zip(names, out[:4], ref):
+                    d = (a.float() - b.float()).abs()
+                    print("   graph vs eager %-8s max|d|=%.3e n_diff=%d" % (nm, float(d.max()), int((d > 0).sum())))
+            bad += 0 if same else 1
+            print("replay %5d: %s" % (i + 1, "identical" if same else "DIFFERENT"), flush=True)
+print("soak:", "OK" if bad == 0 else "%d mismatching checkpoints" % bad)
+sys.exit(1 if bad else 0)
