@@ -1,4 +1,4 @@
-"""Soak test: N graph replays of the cfg-2 bf16 forward; the outputs must stay bit-identical (the processing order of
+"""Soak test (python tools/soak.py [replays] [config] [bf16|fp32]): N graph replays of the decoder forward; the outputs must stay bit-identical (the processing order of
 the pairs is the only nondeterministic quantity and must not leak into the results).  GPU only."""
 import os
 import sys
@@ -12,10 +12,12 @@ from mvgformer_amd.factory import build_decoder_for_case, case_to_device  # noqa
 from mvgformer_amd.synthetic import build_case  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-case = build_case("cfg2", seed=0)
-dec = build_decoder_for_case(case, "cuda", torch.bfloat16)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "fp32") else torch.bfloat16
+case = build_case(cfg, seed=0)
+dec = build_decoder_for_case(case, "cuda", dt)
 g = case_to_device(case, "cuda")
-ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, torch.bfloat16, 1, "cuda")
+ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dt, 1, "cuda")
 
 
 def fwd():
