@@ -686,7 +686,7 @@ def test_decoder_full_size_vs_oracle_one_layer(O):
     X64 = torch.where(valid[..., None], X64, torch.zeros(()))
     noise = (w_ref - X64).norm(dim=-1).flatten()
     gc = None
-    for dt, tol_hs, tol_px, tol_mm in ((torch.float32, 2e-4, 5e-3, 0.1), (torch.bfloat16, 6e-2, 0.5, 6.0)):
+    for dt, tol_hs, tol_px, tol_mm in ((torch.float32, 2e-4, 5e-3, 0.1), (torch.bfloat16, 6e-2, 0.05, 6.0)):
         dec = build_decoder_for_case(case, DEV, dtype=dt)
         gc = gc or case_to_device(case, DEV)
         with torch.no_grad():
