@@ -769,3 +769,28 @@ def test_full_size_bf16_forward_is_bit_reproducible():
             torch.cuda.synchronize()
             for x, y in zip(a, b[:4]):
                 assert torch.equal(x, y)
+
+
+def test_fused_chains_match_unfused_path_full_size():
+    """the same comparison at cfg-2 size: the chain kernels run with two workgroups per CU / one tile per CU there,
+    which no small case reaches (a scale-dependent miscompilation hid inside the tolerances of the small test)."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("cfg2", seed=3, layers=1)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    layer = dec.layers[0]
+    outs = []
+    for fused in (False, True):
+        layer.use_fused_chains = fused
+        with torch.no_grad():
+            outs.append(layer(gc.tgt, gc.query_pos, gc.reference_points[:, :, None], gc.src_views, gc.spatial_shapes,
+                              gc.level_start_index, gc.meta, threshold=0.1))
+    a, b = outs
+    d2 = (a[2] - b[2]).abs().flatten()
+    d3 = (a[1] - b[1]).norm(dim=-1).flatten()
+    print("fused vs unfused, full size: hs %.2e  cls %.2e  2D max %.3e px (q99.9 %.3e)  3D max %.3f mm (q99.9 %.3f)"
+          % (float((a[0] - b[0]).abs().max()), float((a[4] - b[4]).abs().max()), float(d2.max()),
+             float(torch.quantile(d2[:2 ** 24], 0.999)), float(d3.max()), float(torch.quantile(d3, 0.999))))
+    assert float((a[4] - b[4]).abs().max()) < 2e-3 and float((a[0] - b[0]).abs().max()) < 3e-2
+    assert torch.equal(a[3], b[3])
+    assert float(d2.max()) < 1e-2 and float(d3.max()) < 1.0      # measured 1.5e-3 px, 0.29 mm
