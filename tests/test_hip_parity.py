@@ -794,3 +794,43 @@ def test_fused_chains_match_unfused_path_full_size():
     assert float((a[4] - b[4]).abs().max()) < 2e-3 and float((a[0] - b[0]).abs().max()) < 3e-2
     assert torch.equal(a[3], b[3])
     assert float(d2.max()) < 1e-2 and float(d3.max()) < 1.0      # measured 1.5e-3 px, 0.29 mm
+
+
+def test_pyramid_gemms_and_binning_full_size():
+    """cfg-2 size (5 x 40 320 pixels, 76 800 pairs): the weight-stationary GEMMs against torch (pixel-pair layout
+    decoded: left element of line 1+s = value(s), right = value(s+1), 0 past the image end; G row-major), and the
+    binning kernel's output is a permutation per image with the masked pairs last."""
+    from mvgformer_amd import ops
+    torch.manual_seed(11)
+    n_img, S = 5, 40320
+    feat = torch.randn(n_img, S, 256, device=DEV).to(torch.bfloat16)
+    W = (torch.randn(256, 256, device=DEV) / 16).to(torch.bfloat16)
+    bias = torch.randn(256, device=DEV) * 0.1
+    vp = torch.empty((n_img, 8, S + 1, 64), dtype=torch.bfloat16, device=DEV)
+    ops.value_proj_pairs_ws(feat, ops.swizzle_weight(W), bias, vp)
+    ref = (feat.float().view(-1, 256) @ W.float().t() + bias).to(torch.bfloat16).view(n_img, S, 8, 32)
+    lines = vp.view(n_img, 8, S + 1, 32, 2)[:, :, 1:]                     # (img, head, s, ch, {left,right})
+    left = lines[..., 0].permute(0, 2, 1, 3)                               # (img, s, head, ch)
+    right = lines[..., 1].permute(0, 2, 1, 3)
+    d = (left.float() - ref.float()).abs()
+    assert float(d.max()) <= 2 ** -7 * float(ref.float().abs().max())      # one bf16 ulp of the largest value
+    assert float((d > 0).float().mean()) < 0.02                            # a different fp32 summation order flips few roundings
+    assert torch.equal(right[:, :-1], left[:, 1:])                         # right element = the next pixel, bit for bit
+    assert int(right[:, -1].float().abs().sum()) == 0                      # nothing past the last pixel of an image
+    Wg = (torch.randn(192, 256, device=DEV) / 16).to(torch.bfloat16)
+    G = ops.feat_linear_ws(feat, ops.swizzle_weight(torch.cat([Wg, Wg.new_zeros(64, 256)], 0)), 192)
+    refg = (feat.float().view(-1, 256) @ Wg.float().t()).to(torch.bfloat16)
+    dg = (G.view(-1, 192).float() - refg.float()).abs()
+    assert float(dg.max()) <= 2 ** -7 * float(refg.float().abs().max()) and float((dg > 0).float().mean()) < 0.02
+    # binning
+    levels = ops.Levels(torch.tensor([[128, 240], [64, 120], [32, 60]]), torch.tensor([0, 30720, 38400]))
+    Lq = 15360
+    r = torch.rand(n_img, Lq, 3, 2, device=DEV)
+    inside = (torch.rand(n_img, Lq, device=DEV) < 0.6).to(torch.uint8)
+    order = ops.bin_pairs(r, inside.view(-1), levels).view(n_img, Lq).long()
+    base = (torch.arange(n_img, device=DEV) * Lq)[:, None]
+    assert torch.equal(torch.sort(order, 1).values, base + torch.arange(Lq, device=DEV)[None])
+    flags = inside.view(-1)[order.view(-1)].view(n_img, Lq)
+    n_in = inside.sum(1)
+    for n in range(n_img):
+        assert int(flags[n, :int(n_in[n])].sum()) == int(n_in[n]) and int(flags[n, int(n_in[n]):].sum()) == 0
