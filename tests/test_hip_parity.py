@@ -834,3 +834,101 @@ def test_pyramid_gemms_and_binning_full_size():
     n_in = inside.sum(1)
     for n in range(n_img):
         assert int(flags[n, :int(n_in[n])].sum()) == int(n_in[n]) and int(flags[n, int(n_in[n]):].sum()) == 0
+
+
+def _emulate_gsamp_one_image(vp, G, xw, ref_lvl, shapes, starts, n, B):
+    """torch restatement of msda_gsamp_kernel's arithmetic for image n (all its queries, 8 heads): bilinear gather of
+    the head's logits / offsets from the bf16 G (+ xw), the reference's memory reinterpretation, softmax, sampling
+    locations, bilinear sampling of the bf16 values with the (corner x attention) weights rounded to bf16."""
+    dev = vp.device
+    L_ = len(shapes)
+    Lq = ref_lvl.shape[1]
+    value = vp.view(vp.shape[0], 8, -1, 32, 2)[n, :, 1:, :, 0].float()   # (8, S, 32): left element of line 1+s
+    Gn = G.view(vp.shape[0], -1, 192)[n].float()                         # (S, 192)
+    xwq = xw.view(B, Lq, 192)[n % B]                                     # (Lq, 192)
+    ref = ref_lvl[n]                                                     # (Lq, L, 2)
+
+    def bilinear_rows(src, H, W, start, px, py):
+        """src rows [start, start+H*W) sampled at pixel coords (px, py) with zero padding -> (..., C) and nothing else"""
+        x0, y0 = torch.floor(px), torch.floor(py)
+        out = 0
+        for dy in (0, 1):
+            for dx in (0, 1):
+                xi, yi = x0 + dx, y0 + dy
+                w = (1 - (px - xi).abs()) * (1 - (py - yi).abs())
+                ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                idx = start + yi.clamp(0, H - 1).long() * W + xi.clamp(0, W - 1).long()
+                out = out + (w * ok)[..., None] * src[idx]
+        return out
+
+    heads = []
+    for m in range(8):
+        logits, offs = [], []
+        for t in range(L_):
+            fg = m * L_ + t
+            l, g = fg >> 3, fg & 7
+            H, W = shapes[l]
+            gx = (ref[:, l, 0] * 2 - 1).clamp(-1.1, 1.1)                    # projattn.py:134 (grid_sample, align_corners=False)
+            gy = (ref[:, l, 1] * 2 - 1).clamp(-1.1, 1.1)
+            px, py = ((gx + 1) * W - 1) * 0.5, ((gy + 1) * H - 1) * 0.5
+            cols = bilinear_rows(Gn[:, 24 * g:24 * g + 24], H, W, starts[l], px, py) + xwq[:, 24 * g:24 * g + 24]
+            offs.append(cols[:, :16])
+            logits.append(cols[:, 16:])
+        logits = torch.cat(logits, 1)                                       # (Lq, 8L)   index = l'*8 + p
+        offs = torch.cat(offs, 1).view(Lq, L_ * 8, 2)
+        a = torch.softmax(logits, 1)
+        acc = torch.zeros((Lq, 32), device=dev)
+        for i in range(L_ * 8):
+            l2 = i // 8
+            H, W = shapes[l2]
+            lx = ref[:, l2, 0] + offs[:, i, 0] / W                          # projattn.py:186-191
+            ly = ref[:, l2, 1] + offs[:, i, 1] / H
+            w_im, h_im = lx * W - 0.5, ly * H - 0.5                         # cuh:295-296
+            inside = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+            x0, y0 = torch.floor(w_im), torch.floor(h_im)
+            ai = torch.where(inside, a[:, i], torch.zeros(()).to(dev))
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    xi, yi = x0 + dx, y0 + dy
+                    w = (1 - (w_im - xi).abs()) * (1 - (h_im - yi).abs()) * ai
+                    ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+                    wq = torch.where(ok, w, torch.zeros(()).to(dev)).to(torch.bfloat16).float()   # kernel: bf16 weights
+                    idx = starts[l2] + yi.clamp(0, H - 1).long() * W + xi.clamp(0, W - 1).long()
+                    acc = acc + wq[:, None] * value[m][idx]
+        heads.append(acc)
+    return torch.cat(heads, 1)                                              # (Lq, 256) fp32
+
+
+def test_gsamp_kernel_vs_torch_emulation_full_size():
+    """The G-sampling kernel at cfg-2 size against an independent torch restatement of ITS arithmetic (same bf16 G / value
+    operands, same bf16 rounding of the blend weights): agreement to bf16 rounding of the output, for two of the five
+    views (one of them through the binned order with masked pairs)."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("cfg2", seed=5, layers=1)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    pa = dec.layers[0].proj_attn
+    with torch.no_grad():
+        ctx = DecoderContext.build(gc.src_views, gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size,
+                                   torch.bfloat16, 1)
+        r, ref_lvl, inside = ops.project(gc.reference_points, ctx.cams, ctx.levels, ctx.V, 1)
+        x = (gc.tgt + gc.query_pos).contiguous()
+        Wq, bq = pa._fast_query_weights(torch.bfloat16)
+        xw = ops.linear(x.reshape(-1, 256), Wq, bq, out_dtype=torch.float32)
+        vp = pa.project_values(ctx.feat)
+        G = ops.feat_linear_ws(ctx.feat, pa.query_term_weights(torch.bfloat16)[0], 192)
+        order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
+        got = ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1, pair_mask=inside.view(-1), order=order).float()
+        shapes = [(int(h), int(w)) for h, w in ctx.levels.shapes]
+        starts = [int(v) for v in ctx.levels.starts]
+        Lq = ref_lvl.shape[1]
+        for n in (0, 3):
+            want = _emulate_gsamp_one_image(vp, G, xw, ref_lvl, shapes, starts, n, 1)
+            keep = inside[n].bool()
+            d = (got[n * Lq:(n + 1) * Lq][keep] - want[keep]).abs()
+            scale = float(want[keep].abs().max())
+            print("gsamp vs emulation, image %d: max %.3e  mean %.3e  (|want| max %.2f)" % (n, float(d.max()), float(d.mean()), scale))
+            assert float(d.max()) < 8e-3 * scale and float(d.mean()) < 4e-4 * scale      # output bf16 rounding (2^-8)
+            assert int(got[n * Lq:(n + 1) * Lq][~keep].abs().sum()) == 0
