@@ -1,6 +1,7 @@
 """GPU test of the query-sharded decoder: 2 ranks (both on cuda:0, gloo for the exchange -- the GPU box
-has one device; RCCL needs one device per rank) must reproduce the single-rank outputs bit for bit, eagerly
-and through the segmented HIP-graph runner, including the global "no query valid -> force (0,0)" rule."""
+has one device; RCCL needs one device per rank) must reproduce the single-rank outputs (fp32 path: bit for bit;
+bf16 path: graphed == eager bit for bit, both within bf16 rounding of the single-rank run), eagerly and through
+the segmented HIP-graph runner, including the global "no query valid -> force (0,0)" rule."""
 import os
 import socket
 
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cname, q):
+def _worker(rank, world, port, cname, q, bf16=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +34,8 @@ def _worker(rank, world, port, cname, q):
         spec = LAYER_CASES[cname]
         case = build_case(spec["config"], B=1, seed=spec["seed"], layers=spec["layers"],
                           valid_fraction=spec.get("valid_fraction"))
-        dec = build_decoder_for_case(case, "cuda:0")
+        dt = torch.bfloat16 if bf16 else torch.float32
+        dec = build_decoder_for_case(case, "cuda:0", dtype=dt)
         g = case_to_device(case, "cuda:0")
         thr = 0.1
         with torch.no_grad():
@@ -41,29 +43,39 @@ def _worker(rank, world, port, cname, q):
                        query_pos=g.query_pos, threshold=thr)
             eager = mdist.sharded_decoder_forward(dec, g.tgt, g.reference_points, g.src_views, g.meta, g.spatial_shapes,
                                                   g.level_start_index, g.query_pos, thr, gather_hidden=True)
-            ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, torch.float32, 1,
-                                         "cuda:0")
+            ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dt, 1, "cuda:0")
             t, p, r, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, 15, world, rank)
             runner = mdist.GraphedShardedDecoder(dec, t, r, g.src_views, p, ctx, thr, case.NQ, gather_hidden=True)
             runner.replay()
             graphed = runner.replay()
             torch.cuda.synchronize()
         ok = True
-        for got in (eager, graphed):
-            ok = ok and all(torch.equal(a, b) for a, b in zip(got[:4], full[:4]))
-            ok = ok and all(torch.equal(a, b) for a, b in zip(got[4], full[4]))
+        if not bf16:
+            for got in (eager, graphed):
+                ok = ok and all(torch.equal(a, b) for a, b in zip(got[:4], full[:4]))
+                ok = ok and all(torch.equal(a, b) for a, b in zip(got[4], full[4]))
+        else:
+            # bf16 path: the segmented graphs replay exactly the eager sharded kernels (bit-identical); against the
+            # single-rank run the fused chain B numbers its tiles differently (k-step rotation per tile): bf16 rounding
+            ok = ok and all(torch.equal(a, b) for a, b in zip(eager[:4], graphed[:4]))
+            ok = ok and all(torch.equal(a, b) for a, b in zip(eager[4], graphed[4]))
+            ok = ok and float((eager[0] - full[0]).abs().max()) < 3e-2
+            ok = ok and float((eager[1] - full[1]).norm(dim=-1).max()) < 1.0
+            ok = ok and float((eager[2] - full[2]).abs().max()) < 5e-2
+            ok = ok and bool(torch.equal(eager[1].abs().sum(-1) > 0, full[1].abs().sum(-1) > 0))
         nvalid = [int((c[..., 1] > thr).sum()) for c in full[4]]
         q.put((rank, bool(ok), nvalid))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("cname", ["mini5_half", "mini5_empty"])
-def test_sharded_equals_single_rank(cname):
+def test_sharded_equals_single_rank(cname, bf16):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, cname, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, cname, q, bf16)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
