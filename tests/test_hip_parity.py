@@ -932,3 +932,27 @@ def test_gsamp_kernel_vs_torch_emulation_full_size():
             print("gsamp vs emulation, image %d: max %.3e  mean %.3e  (|want| max %.2f)" % (n, float(d.max()), float(d.mean()), scale))
             assert float(d.max()) < 8e-3 * scale and float(d.mean()) < 4e-4 * scale      # output bf16 rounding (2^-8)
             assert int(got[n * Lq:(n + 1) * Lq][~keep].abs().sum()) == 0
+
+
+def test_deform_forward_full_size_vs_c_oracle():
+    """The drop-in op (mvg_msda_forward_f32 / _bf16 through Deformable.deform_forward's contract) at the size of one
+    cfg-2 view-layer -- value (2, 40 320, 8, 32), 15 360 queries, 3 levels x 8 points -- against the plain-C
+    restatement of the reference kernel (oracle/msda_ref.c, OpenMP on the host).  Locations reach outside [0,1]."""
+    from mvgformer_amd import ops
+    from oracle import msda_c
+    torch.manual_seed(21)
+    N, M, D, Lq, P = 2, 8, 32, 15360, 8
+    shapes = torch.tensor([[128, 240], [64, 120], [32, 60]], dtype=torch.int64)
+    starts = torch.tensor([0, 30720, 38400], dtype=torch.int64)
+    S = 40320
+    value = torch.randn(N, S, M, D)
+    loc = torch.rand(N, Lq, M, 3, P, 2) * 1.2 - 0.1
+    wgt = torch.softmax(torch.randn(N, Lq, M, 3 * P), -1).view(N, Lq, M, 3, P)
+    want = msda_c.msda_forward(value, shapes, starts, loc, wgt)
+    dv = lambda t: t.to(DEV)
+    got = ops.msda_forward(dv(value), dv(shapes), dv(starts), dv(loc), dv(wgt)).cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-5 * scale
+    got16 = ops.msda_forward(dv(value).to(torch.bfloat16), dv(shapes), dv(starts), dv(loc), dv(wgt)).float().cpu()
+    want16 = msda_c.msda_forward(value.to(torch.bfloat16).float(), shapes, starts, loc, wgt)
+    assert float((got16 - want16).abs().max()) < 6e-3 * scale            # bf16 rounding of the output
