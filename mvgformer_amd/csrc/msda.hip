@@ -381,15 +381,29 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
                                                             LevelTable lv, bf16_t* __restrict__ samp,
                                                             const uint8_t* __restrict__ pair_mask,
                                                             const int* __restrict__ order, int n_pairs,
-                                                            int Lq, int S, int B) {
+                                                            int Lq, int S, int B, int map_ch) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 4;   // SCP: padded scratch row (76 for L=3)
   __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x & 7, sub = lane & 3, pl = lane >> 2;
+  const int sub = lane & 3, pl = lane >> 2;
+  // workgroup -> (head, slot block).  map_ch == 0: head = blockIdx & 7 = the XCD the block is dispatched to (each L2
+  // serves one head plane).  map_ch > 0 (default 4): XCD = blockIdx & 7 works on chunks of map_ch consecutive slot
+  // blocks, the 8 heads of a slot block back to back -- with the pairs in image-space order an L2 then serves a
+  // compact region of all 8 head planes, and the G rows of a pair are fetched into it once for its 8 heads.
+  int m, pblk;
+  if (map_ch == 0) {
+    m = blockIdx.x & 7;
+    pblk = blockIdx.x >> 3;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    m = j & 7;
+    const int t = j >> 3;
+    pblk = ((t / map_ch) * 8 + xcd) * map_ch + t % map_ch;
+  }
   // The 4 lanes of a quad share one (pair, head) and every LDS scratch row is private to its quad, so lanes may
   // leave early (no workgroup barrier below): slots past the end, and pairs the caller masks out (reference
   // points outside the image: the consumer multiplies their rows by 0, dq_decoder.py:585-586) -- zero-filled.
-  const int slot = (blockIdx.x >> 3) * (NT / 4) + wave * 16 + pl;
+  const int slot = pblk * (NT / 4) + wave * 16 + pl;
   if (slot >= n_pairs) return;
   const int pair = order ? order[slot] : slot;
   if (pair_mask && !pair_mask[pair]) {
@@ -540,6 +554,8 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
 }
 
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
+static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
+                                   // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
@@ -730,11 +746,15 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   if (pairs == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
 #define MVG_GS(LL, NT)                                                                                            \
-  hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * (int)((pairs + NT / 4 - 1) / (NT / 4))), dim3(NT), 0, st, \
-                     (const bf16_t*)vp, (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order,       \
-                     (int)pairs, Lq, S, B)
+  {                                                                                                               \
+    int npb = (int)((pairs + NT / 4 - 1) / (NT / 4));                                                             \
+    if (g_gsamp_map > 0) npb = (npb + 8 * g_gsamp_map - 1) / (8 * g_gsamp_map) * (8 * g_gsamp_map);               \
+    hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,            \
+                       (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S, B,  \
+                       g_gsamp_map);                                                                              \
+  }
 #define MVG_GSN(LL)                                                                                               \
-  if (g_gsamp_threads == 1024) MVG_GS(LL, 1024); else if (g_gsamp_threads == 512) MVG_GS(LL, 512); else MVG_GS(LL, 256)
+  if (g_gsamp_threads == 1024) MVG_GS(LL, 1024) else if (g_gsamp_threads == 512) MVG_GS(LL, 512) else MVG_GS(LL, 256)
   switch (L) {
     case 1: MVG_GSN(1); break;
     case 2: MVG_GSN(2); break;
@@ -764,6 +784,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128 || value == 256)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
+  if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }
