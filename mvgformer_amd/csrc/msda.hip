@@ -754,7 +754,8 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
                        g_gsamp_map);                                                                              \
   }
 #define MVG_GSN(LL)                                                                                               \
-  if (g_gsamp_threads == 1024) MVG_GS(LL, 1024) else if (g_gsamp_threads == 512) MVG_GS(LL, 512) else MVG_GS(LL, 256)
+  if (g_gsamp_threads == 1024) MVG_GS(LL, 1024) else if (g_gsamp_threads == 512) MVG_GS(LL, 512)                \
+  else if (g_gsamp_threads == 128) MVG_GS(LL, 128) else MVG_GS(LL, 256)
   switch (L) {
     case 1: MVG_GSN(1); break;
     case 2: MVG_GSN(2); break;
@@ -785,7 +786,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
-  if (!strcmp(key, "gsamp_threads") && (value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
+  if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }
 
