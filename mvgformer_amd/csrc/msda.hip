@@ -338,18 +338,13 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
 // packed (left, right) bf16 weights of the top / bottom pair line and the byte offsets of the two lines.
 template <int L>
 __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
-                                             const float (&refx)[L], const float (&refy)[L], int sub, unsigned& wt,
-                                             unsigned& wb, unsigned& ot, unsigned& ob) {
+                                             int sub, unsigned& wt, unsigned& wb, unsigned& ot, unsigned& ob) {
   constexpr int P = 8, NB = 4, LP = L * P;
   const int l = (it * NB) / P;
   const int H = lv.H[l], W = lv.W[l];
   const float Wf = (float)W, Hf = (float)H;
-  float rx = refx[0], ry = refy[0];                  // refx[l] / refy[l] without a dynamically indexed register array
-#pragma unroll
-  for (int k = 1; k < L; ++k) {
-    rx = (l == k) ? refx[k] : rx;
-    ry = (l == k) ? refy[k] : ry;
-  }
+  const float2 rr = *reinterpret_cast<const float2*>(sc + 3 * LP + 2 * l);   // the pair's reference point at level l
+  const float rx = rr.x, ry = rr.y;
   const float lgs = sc[it * NB + sub];
   const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
   const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];               // projattn.py:186-191
@@ -382,7 +377,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
                                                             const uint8_t* __restrict__ pair_mask,
                                                             const int* __restrict__ order, int n_pairs,
                                                             int Lq, int S, int B, int map_ch) {
-  constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 4;   // SCP: padded scratch row (76 for L=3)
+  constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4, SCP = 3 * LP + 8;   // scratch row: LP logits, 2LP offsets, L refs
   __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane & 3, pl = lane >> 2;
@@ -413,6 +408,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
   float* sc = &scratch[wave][pl][0];
 
+  if (sub < L) *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = *reinterpret_cast<const float2*>(r + ((long)pair * L + sub) * 2);
   // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk
 #pragma unroll
   for (int k = 0; k < (NCHK + 3) / 4; ++k) {
@@ -500,27 +496,16 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
     // byte offset of this lane's 32-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
     const unsigned lane_off = (unsigned)((((long)n * 8 + m) * (S + 1)) * 128 + sub * 32);
     const char* vp_bytes = reinterpret_cast<const char*>(vp);
-    // per-level reference points of the pair, fetched once
-    float refx[L], refy[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const float2 rr = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
-      refx[l] = rr.x;
-      refy[l] = rr.y;
-    }
     // Explicit software pipeline over the LP / NB batches (a real loop: unrolled, hipcc computes all 24 samples
     // first and spills):   gathers(it) issued  ->  coordinates(it + 1) computed under their latency  ->  blend(it)
     unsigned cw_t, cw_b, co_t, co_b;                  // this lane's sample of the batch: packed weights / line offsets
-    gsamp_coords<L>(0, sc, mx, lv, refx, refy, sub, cw_t, cw_b, co_t, co_b);
+    gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b);
 #pragma unroll 1
     for (int it = 0; it < LP / NB; ++it) {
-      // ---- quad broadcast + 16 gathers in flight
-      unsigned wt[NB], wb[NB];
+      // ---- quad broadcast of the line offsets + 16 gathers in flight
       uint4 raw[NB][4];
 #define MVG_QS(SS)                                                                                      \
       {                                                                                                 \
-        wt[SS] = quad_bcast<SS>(cw_t);                                                                  \
-        wb[SS] = quad_bcast<SS>(cw_b);                                                                  \
         const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
         raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
         raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + ot + 16);                               \
@@ -529,10 +514,14 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
       }
       MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
 #undef MVG_QS
+      const unsigned pw_t = cw_t, pw_b = cw_b;        // this batch's weights, broadcast at blend time (fewer live VGPRs)
       __builtin_amdgcn_sched_barrier(0);
       // next batch's coordinates while the gathers are in flight (the last iteration recomputes batch 0: branch-free)
-      gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, refx, refy, sub, cw_t, cw_b, co_t, co_b);
+      gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b);
       __builtin_amdgcn_sched_barrier(0);
+      unsigned wt[NB], wb[NB];
+      wt[0] = quad_bcast<0>(pw_t); wt[1] = quad_bcast<1>(pw_t); wt[2] = quad_bcast<2>(pw_t); wt[3] = quad_bcast<3>(pw_t);
+      wb[0] = quad_bcast<0>(pw_b); wb[1] = quad_bcast<1>(pw_b); wb[2] = quad_bcast<2>(pw_b); wb[3] = quad_bcast<3>(pw_b);
 #pragma unroll
       for (int s = 0; s < NB; ++s)
 #pragma unroll
