@@ -123,9 +123,8 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
 
 /* ---- bf16 fast path of the ProjAttn front end (replaces mvg_gather_ref + 2 x mvg_linear + mvg_msda_fused) ----
  * Bilinear sampling commutes with a Linear: Linear(bilinear(feat,p) + x) = bilinear(feat@W^T, p) + (x@W^T + b).
- *   mvg_value_proj_pairs_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written in the
- *       "pixel-pair" layout vp[img][head 8][1+s][ch 32][2] (word = (value(s)[ch], value(s+1)[ch]); line 0 is
- *       reserved and never read; bf16, n_img*8*(S+1)*64 elements): the two horizontal corners of a sample are one 128-B line.
+ *   mvg_value_proj_planes_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written as head planes
+ *       vh[img][head 8][s][ch 32] (bf16, n_img*8*S*32 elements): the 32 channels of (pixel, head) are 64 contiguous bytes.
  *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: the [offsets; logits]
  *       rows in the order of mvgformer_amd.ops.gsamp_column_order: 8 groups of 16 offset + 8 logit outputs, so that
  *       with the reference's memory reinterpretation the 72 values a head needs are contiguous in a G row).
@@ -136,8 +135,8 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
  *       dq_decoder.py:585-586).  order (N_img*Lq) i32 or NULL: slot i of the launch computes pair order[i].
  * Weights Wf: bf16, zero-padded to 256 rows, MFMA-fragment order [wn 4][ks 16][j 2][lane 64][8]
  * (mvgformer_amd.ops.swizzle_weight); the kernels keep them in registers (weight-stationary, csrc/wreg_gemm.hip). */
-int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
-                            void* stream);
+int mvg_value_proj_planes_ws(const void* feat, const void* Wf, const float* bias, void* vh, int n_img, int S,
+                             void* stream);
 int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
 int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl,
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,

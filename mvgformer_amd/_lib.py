@@ -32,7 +32,7 @@ SIGNATURES = {
     "mvg_msda_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_chain_attn_pose": [_vp] * 14 + [_i, _vp],
     "mvg_chain_update_ffn_class": [_vp, _i] + [_vp] * 13 + [_f] + [_vp] * 9 + [_i] * 5 + [_vp],
-    "mvg_value_proj_pairs_ws": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mvg_value_proj_planes_ws": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_feat_linear_ws": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_msda_gsamp": [_vp] * 9 + [_i] * 5 + [_vp],
     "mvg_bin_pairs": [_vp] * 3 + [_i] + [_vp] + [_i] * 2 + [_vp],

@@ -310,10 +310,12 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 //     the head, parked in LDS) and adds xw = (tgt+query_pos) @ Woa^T + b.  The 192 columns of G / xw are ordered
 //     so that a head's chunks are contiguous in a pixel's row (see phase A).  No (rows x 192) fp32 tensor
 //     (177 MB written + read per layer) and no per-(view, query, level) GEMM exist any more.
-// (2) Pixel-pair value layout (written by wreg_gemm.hip):  vp[img][head][1+s][ch 32][2] with the 32-bit word
-//     (value(s)[ch], value(s+1)[ch]): the two horizontal corners of a sample are ONE aligned 128-byte line per
-//     head (half the gather requests of a pixel-major layout: PMC 45 M -> 23 M L1->L2 requests per launch) and
-//     every word is directly an operand of v_dot2c_f32_bf16 with the packed weights (w_left, w_right).
+// (2) Head-plane value layout (written by wreg_gemm.hip):  vh[img][head][s][ch 32]: a pixel's 32 channels of one head
+//     are 64 contiguous bytes (16 per lane of the head's quad).  The left / right corner pixels of a sample are
+//     interleaved per channel with v_perm_b32 into (left[ch], right[ch]) words = the operand of v_dot2c_f32_bf16 with
+//     the packed weights (w_left, w_right).  (A "pixel-pair" layout that stored this interleaving -- half the
+//     requests, no perm, twice the bytes -- was faster while the pairs were processed in query order; in image-space
+//     order the smaller footprint wins.)
 // (3) Head-per-XCD mapping: block b works on head (b & 7); with gfx950's round-robin dispatch (block b -> XCD
 //     b % 8) each XCD touches one head plane of vp (5 MB per view) instead of all eight, so L1 misses hit in its
 //     4-MB L2 (fabric reads 10.3 M -> 4.5 M requests per launch).  A wavefront = 16 pairs x 1 head x 4 lanes,
@@ -335,10 +337,12 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
 }
 
 // One lane's sample of gather batch `it` of a (pair, head): sample index it*4 + sub, level (it*4)/8.  Branch-free:
-// packed (left, right) bf16 weights of the top / bottom pair line and the byte offsets of the two lines.
+// packed (left, right) bf16 weights of the top / bottom pixel pair, the byte offsets of the top-left / bottom-left
+// pixels inside the head plane and the byte distance to the right-hand pixel (0 at the image border, else 64).
 template <int L>
 __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
-                                             int sub, unsigned& wt, unsigned& wb, unsigned& ot, unsigned& ob) {
+                                             int sub, unsigned& wt, unsigned& wb, unsigned& ot, unsigned& ob,
+                                             unsigned& dx) {
   constexpr int P = 8, NB = 4, LP = L * P;
   const int l = (it * NB) / P;
   const int H = lv.H[l], W = lv.W[l];
@@ -359,15 +363,15 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
   const float t0 = hh * hw * a, t1 = hh * lw * a, t2 = lh * hw * a, t3 = lh * lw * a;
   const float c0 = (hl_ok & wl_ok) ? t0 : 0.f, c1 = (hl_ok & wh_ok) ? t1 : 0.f;       // cuh:66-88 zero padding
   const float c2 = (hh_ok & wl_ok) ? t2 : 0.f, c3 = (hh_ok & wh_ok) ? t3 : 0.f;
-  // w_low == -1: the only pixel with weight is column 0 = the LEFT element of pair line 0 of the row
-  const bool wneg = w_low < 0;
-  wt = pack_bf16x2(wneg ? c1 : c0, wneg ? 0.f : c1);
-  wb = pack_bf16x2(wneg ? c3 : c2, wneg ? 0.f : c3);
+  wt = pack_bf16x2(c0, c1);
+  wb = pack_bf16x2(c2, c3);
+  // clamped pixel indices: a clamped corner always carries weight 0
   const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-  const int wp = min(max(w_low, 0), W - 1);
-  const unsigned lvl_pairs = (unsigned)(1 + lv.start[l]);
-  ot = (lvl_pairs + (unsigned)(hl_c * W + wp)) * 128u;           // byte offset of the top pair line
-  ob = (lvl_pairs + (unsigned)(hh_c * W + wp)) * 128u;
+  const int wl_c = min(max(w_low, 0), W - 1), wr_c = min(max(w_low + 1, 0), W - 1);
+  const unsigned base = (unsigned)lv.start[l];
+  ot = (base + (unsigned)(hl_c * W + wl_c)) * 64u;
+  ob = (base + (unsigned)(hh_c * W + wl_c)) * 64u;
+  dx = (unsigned)(wr_c - wl_c) * 64u;
 }
 
 template <int L, int NT>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
@@ -494,30 +498,31 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
 
   {
     // byte offset of this lane's 32-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
-    const unsigned lane_off = (unsigned)((((long)n * 8 + m) * (S + 1)) * 128 + sub * 32);
+    const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
     const char* vp_bytes = reinterpret_cast<const char*>(vp);
     // Explicit software pipeline over the LP / NB batches (a real loop: unrolled, hipcc computes all 24 samples
     // first and spills):   gathers(it) issued  ->  coordinates(it + 1) computed under their latency  ->  blend(it)
-    unsigned cw_t, cw_b, co_t, co_b;                  // this lane's sample of the batch: packed weights / line offsets
-    gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b);
+    unsigned cw_t, cw_b, co_t, co_b, co_x;            // this lane's sample of the batch: packed weights / pixel offsets
+    gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
 #pragma unroll 1
     for (int it = 0; it < LP / NB; ++it) {
-      // ---- quad broadcast of the line offsets + 16 gathers in flight
+      // ---- quad broadcast of the pixel offsets + 16 gathers in flight: top-left, top-right, bottom-left, bottom-right
       uint4 raw[NB][4];
 #define MVG_QS(SS)                                                                                      \
       {                                                                                                 \
         const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
+        const unsigned dxs = quad_bcast<SS>(co_x);                                                      \
         raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
-        raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + ot + 16);                               \
+        raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs));                            \
         raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
-        raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + ob + 16);                               \
+        raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                            \
       }
       MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
 #undef MVG_QS
       const unsigned pw_t = cw_t, pw_b = cw_b;        // this batch's weights, broadcast at blend time (fewer live VGPRs)
       __builtin_amdgcn_sched_barrier(0);
       // next batch's coordinates while the gathers are in flight (the last iteration recomputes batch 0: branch-free)
-      gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b);
+      gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
       __builtin_amdgcn_sched_barrier(0);
       unsigned wt[NB], wb[NB];
       wt[0] = quad_bcast<0>(pw_t); wt[1] = quad_bcast<1>(pw_t); wt[2] = quad_bcast<2>(pw_t); wt[3] = quad_bcast<3>(pw_t);
@@ -526,14 +531,17 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
       for (int s = 0; s < NB; ++s)
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
-          // every 32-bit word of a pair line is (value(s)[ch], value(s+1)[ch]) = the dot2 operand as stored
+          // left / right pixel (8 channels each) -> per channel the word (left[ch], right[ch]) = the v_dot2c operand for
+          // the packed weights (w_left, w_right): 2 v_perm + 2 v_dot2c per pair of channels
           const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);
-          const unsigned c03[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
-          const unsigned c47[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
+          const unsigned l4[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
+          const unsigned r4[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            acc[t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, c03[t]), wv, acc[t], false);
-            acc[4 + t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, c47[t]), wv, acc[4 + t], false);
+            const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);     // (left[2t],   right[2t])
+            const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);     // (left[2t+1], right[2t+1])
+            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);
+            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false);
           }
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -731,7 +739,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   if (e) return e;
   const long pairs = (long)N_img * Lq;
   if (pairs > 0x7fffffffL / 4) return MVG_E_BADARG;
-  if ((long)N_img * S * 384 >= 0xffffffffL || (long)N_img * 8 * (S + 1) * 128 >= 0xffffffffL) return MVG_E_BADARG;   // 32-bit byte offsets
+  if ((long)N_img * S * 384 >= 0xffffffffL || (long)N_img * 8 * S * 64 >= 0xffffffffL) return MVG_E_BADARG;   // 32-bit byte offsets
   if (pairs == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
 #define MVG_GS(LL, NT)                                                                                            \

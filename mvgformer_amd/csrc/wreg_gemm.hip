@@ -1,6 +1,6 @@
 // Weight-stationary bf16 GEMMs over the feature pyramid (gfx950): out = feat (n_img*S, 256) @ W^T (+ bias)
 //
-//   value projection : vp = pixel-pair layout of feat @ Wv^T + bv            (projattn.py:160-175)
+//   value projection : value = feat @ Wv^T + bv, written as head planes  vh[img][head 8][s][ch 32]   (projattn.py:160-175)
 //   G projection     : G  = feat @ [Woff; Wattn]^T, row-major (n_img*S, 192) (projattn.py:180-181 applied to the
 //                      pyramid itself: bilinear sampling commutes with the Linear, see msda_gsamp_kernel)
 //
@@ -9,14 +9,15 @@
 // 200 000 rows is as much traffic as the activations (measured: 107 us for the value projection = 510 MB, 200 MB
 // of it weights).  Here 512 persistent workgroups load the weight ONCE into registers -- each of the 4
 // wavefronts keeps its 64 output columns x 256 k = 32 KB as 128 VGPRs in MFMA-fragment order -- and stream
-// 32-row tiles through LDS: the k-loop is pure ds_read_b128 + v_mfma_f32_32x32x16_bf16; the loads of the next
-// tile and the stores of the previous one are issued together at the start of an iteration and waited for one
+// 32-row tiles through LDS: the k-loop is pure ds_read_b128 + v_mfma_f32_32x32x16_bf16; the loads of the tile
+// after next and the stores of the previous one are issued together at the start of an iteration and waited for one
 // MFMA + epilogue phase later; two workgroups per CU overlap each other.
 //
-// Pixel-pair layout (consumed by msda_gsamp_kernel):  vp[img][head 8][1+s][ch 32][2] bf16, the 32-bit word of
-// channel ch in line 1+s is (value(s)[ch], value(s+1)[ch]); line 0 is reserved (never read: the sampler takes
-// column -1 from the left element of the row's first line), the right half of the last pixel's line is 0.  Tiles overlap by one row (tile t = rows [31t, 31t+32)) so that every tile owns the
-// right-hand neighbour of its last output row.
+// Head planes (consumed by msda_gsamp_kernel): a pixel's 32 channels of one head are 64 contiguous bytes, two
+// horizontally adjacent pixels one 128-byte line when the left one has an even column -- the bilinear corners of a
+// sample are 2 x (16 + 16) bytes per lane.  (An earlier "pixel-pair" layout stored (value(s), value(s+1)) interleaved:
+// one line per corner pair and perm-free dot2 operands, but twice the bytes -- with the pairs processed in
+// image-space order the smaller footprint wins: sampler 153 -> 145 us, this GEMM 59 -> 40 us.)
 #include "common.h"
 
 int g_wreg_grid = 512;   // tuning knob (mvg_set_tuning "wreg_grid"): persistent workgroups
@@ -33,16 +34,16 @@ struct WregParams {
   const float* bias;      // (256) f32 or nullptr
   void* out;
   int M, N, S_img;
-  int rowmajor;           // 0 = pixel-pair layout (N = 256), 1 = row-major bf16 (M, N)
+  int rowmajor;           // 0 = head planes (N = 256), 1 = row-major bf16 (M, N)
 };
 
-// NCPT: 16-byte output chunks per thread and tile.  0 = pixel-pair layout (N = 256: 4 chunks, 2 stores each),
-// 1..4 = row-major with N = 64 * NCPT columns.  Every thread issues the SAME number of stores for every tile
-// (chunks that fall outside the matrix / on the overlap row are redirected to re-write a valid neighbour's chunk with
-// identical bytes), so the compiler can give the loads of a later tile an exact vmcnt instead of vmcnt(0).
+// NCPT: 16-byte output chunks per thread and tile.  0 = head planes (N = 256: 4 chunks), 1..4 = row-major with
+// N = 64 * NCPT columns.  Every thread issues the SAME number of stores for every tile (chunks of rows past the end
+// of the matrix are redirected to re-write the last valid row's chunk with identical bytes), so the compiler can
+// give the loads of a later tile an exact vmcnt instead of vmcnt(0).
 template <int NCPT>
 __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
-  constexpr bool PAIRS = NCPT == 0;
+  constexpr bool PLANES = NCPT == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                   // RM x 256 bf16 A tile
   char* stage0 = smem + RM * ACT_PITCH;               // 2 x (RM x 256 bf16) output tiles (double-buffered)
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
     }
   }
 
-  constexpr int TS = PAIRS ? RM - 1 : RM;       // tile stride in rows (pair layout: one row of overlap)
+  constexpr int TS = RM;                        // tile stride in rows
   const int ntiles = (p.M + TS - 1) / TS;
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
   // A chunk c = i*256 + tid of a tile: row = c >> 5, 16-byte column v16 = c & 31 (NCH chunks per thread)
@@ -75,28 +76,17 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   auto store_tile = [&](int tile, const char* stage) {
     const int r0 = tile * TS;
     const int last_row = p.M - 1 - r0;                 // rows past it do not exist (only in the final tile)
-    if (PAIRS) {
+    if (PLANES) {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = i * 256 + tid, v16 = c & 31;
-        // pair line 1+s of (img, head) = 128 bytes = 32 channels x (value(s), value(s+1)); the 4 threads of a
-        // head write its two 64-byte halves with one store each: thread q4 covers channels 4*q4.. and 16+4*q4..
-        const int row = min(min(c >> 5, RM - 2), last_row);        // overlap row / tail: duplicate a valid line
+        // the 64 bytes of (pixel, head) are written by 4 threads: thread q4 stores channels 8*q4 .. 8*q4+7
+        const int row = min(c >> 5, last_row);
         const int grow = r0 + row;
         const int img = grow / p.S_img, sp = grow - img * p.S_img;
         const int head = v16 >> 2, q4 = v16 & 3;
-        const bool last = sp + 1 >= p.S_img;            // no right neighbour across an image boundary
-        const char* lrow = stage + row * ACT_PITCH + head * 64 + q4 * 8;
-        const uint2 la = *reinterpret_cast<const uint2*>(lrow), lb = *reinterpret_cast<const uint2*>(lrow + 32);
-        uint2 ra = *reinterpret_cast<const uint2*>(lrow + ACT_PITCH), rb = *reinterpret_cast<const uint2*>(lrow + ACT_PITCH + 32);
-        if (last) ra = rb = uint2{0u, 0u};
-        bf16_t* line = outp + (((long)img * 8 + head) * (p.S_img + 1) + 1 + sp) * 64 + q4 * 8;
-        *reinterpret_cast<uint4*>(line) =
-            uint4{__builtin_amdgcn_perm(ra.x, la.x, 0x05040100u), __builtin_amdgcn_perm(ra.x, la.x, 0x07060302u),
-                  __builtin_amdgcn_perm(ra.y, la.y, 0x05040100u), __builtin_amdgcn_perm(ra.y, la.y, 0x07060302u)};
-        *reinterpret_cast<uint4*>(line + 32) =
-            uint4{__builtin_amdgcn_perm(rb.x, lb.x, 0x05040100u), __builtin_amdgcn_perm(rb.x, lb.x, 0x07060302u),
-                  __builtin_amdgcn_perm(rb.y, lb.y, 0x05040100u), __builtin_amdgcn_perm(rb.y, lb.y, 0x07060302u)};
+        *reinterpret_cast<f32x4*>(outp + (((long)img * 8 + head) * p.S_img + sp) * 32 + q4 * 8) =
+            *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
       }
     } else {
       constexpr int CPR = 8 * (NCPT > 0 ? NCPT : 1);    // 16-byte chunks per output row
@@ -179,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
 
 int launch_wreg(const WregParams& p, hipStream_t st) {
   const size_t lds = 3 * RM * ACT_PITCH + 256 * sizeof(float);
-  const int TS = p.rowmajor ? RM : RM - 1;
+  const int TS = RM;
   const int ntiles = (p.M + TS - 1) / TS;
   const int grid = ntiles < g_wreg_grid ? ntiles : g_wreg_grid;      // persistent: 2 workgroups per CU
 #define WREG_LAUNCH(NC) hipLaunchKernelGGL((wreg_gemm_kernel<NC>), dim3(grid), dim3(256), lds, st, p)
@@ -197,8 +187,8 @@ int launch_wreg(const WregParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mvg_value_proj_pairs_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
-                                       void* stream) {
+extern "C" int mvg_value_proj_planes_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
+                                        void* stream) {
   if (!feat || !Wf || !bias || !vp || n_img <= 0 || S <= 0) return MVG_E_BADARG;
   WregParams p = {};
   p.A = (const bf16_t*)feat; p.Wf = (const bf16_t*)Wf; p.bias = bias; p.out = vp;

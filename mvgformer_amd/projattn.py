@@ -122,7 +122,7 @@ class ProjAttn(nn.Module):
 
     def _pair_buffer(self, n_img, S, device):
         """pixel-pair value buffer (every line is fully rewritten by each projection); kept across calls."""
-        shape = (n_img, 8, S + 1, 64)
+        shape = (n_img, 8, S, 32)
         if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
             self._vp = torch.empty(shape, dtype=torch.bfloat16, device=device)
         return self._vp
@@ -142,7 +142,7 @@ class ProjAttn(nn.Module):
         bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
         Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
         vp = self._pair_buffer(n_img, S, feat.device)
-        ops.value_proj_pairs_ws(feat, Wv_f, bv, vp)
+        ops.value_proj_planes_ws(feat, Wv_f, bv, vp)
         if record_event:
             self._vp_event = torch.cuda.Event()
             self._vp_event.record()

@@ -797,26 +797,22 @@ def test_fused_chains_match_unfused_path_full_size():
 
 
 def test_pyramid_gemms_and_binning_full_size():
-    """cfg-2 size (5 x 40 320 pixels, 76 800 pairs): the weight-stationary GEMMs against torch (pixel-pair layout
-    decoded: left element of line 1+s = value(s), right = value(s+1), 0 past the image end; G row-major), and the
-    binning kernel's output is a permutation per image with the masked pairs last."""
+    """cfg-2 size (5 x 40 320 pixels, 76 800 pairs): the weight-stationary GEMMs against torch (value as head planes
+    vh[img][head][s][32]; G row-major), and the binning kernel's output is a permutation per image with the masked
+    pairs last."""
     from mvgformer_amd import ops
     torch.manual_seed(11)
     n_img, S = 5, 40320
     feat = torch.randn(n_img, S, 256, device=DEV).to(torch.bfloat16)
     W = (torch.randn(256, 256, device=DEV) / 16).to(torch.bfloat16)
     bias = torch.randn(256, device=DEV) * 0.1
-    vp = torch.empty((n_img, 8, S + 1, 64), dtype=torch.bfloat16, device=DEV)
-    ops.value_proj_pairs_ws(feat, ops.swizzle_weight(W), bias, vp)
+    vh = torch.empty((n_img, 8, S, 32), dtype=torch.bfloat16, device=DEV)
+    ops.value_proj_planes_ws(feat, ops.swizzle_weight(W), bias, vh)
     ref = (feat.float().view(-1, 256) @ W.float().t() + bias).to(torch.bfloat16).view(n_img, S, 8, 32)
-    lines = vp.view(n_img, 8, S + 1, 32, 2)[:, :, 1:]                     # (img, head, s, ch, {left,right})
-    left = lines[..., 0].permute(0, 2, 1, 3)                               # (img, s, head, ch)
-    right = lines[..., 1].permute(0, 2, 1, 3)
-    d = (left.float() - ref.float()).abs()
+    got = vh.permute(0, 2, 1, 3)                                          # (img, s, head, ch)
+    d = (got.float() - ref.float()).abs()
     assert float(d.max()) <= 2 ** -7 * float(ref.float().abs().max())      # one bf16 ulp of the largest value
     assert float((d > 0).float().mean()) < 0.02                            # a different fp32 summation order flips few roundings
-    assert torch.equal(right[:, :-1], left[:, 1:])                         # right element = the next pixel, bit for bit
-    assert int(right[:, -1].float().abs().sum()) == 0                      # nothing past the last pixel of an image
     Wg = (torch.randn(192, 256, device=DEV) / 16).to(torch.bfloat16)
     G = ops.feat_linear_ws(feat, ops.swizzle_weight(torch.cat([Wg, Wg.new_zeros(64, 256)], 0)), 192)
     refg = (feat.float().view(-1, 256) @ Wg.float().t()).to(torch.bfloat16)
@@ -843,7 +839,7 @@ def _emulate_gsamp_one_image(vp, G, xw, ref_lvl, shapes, starts, n, B):
     dev = vp.device
     L_ = len(shapes)
     Lq = ref_lvl.shape[1]
-    value = vp.view(vp.shape[0], 8, -1, 32, 2)[n, :, 1:, :, 0].float()   # (8, S, 32): left element of line 1+s
+    value = vp[n].float()                                                # (8, S, 32) head planes
     Gn = G.view(vp.shape[0], -1, 192)[n].float()                         # (S, 192)
     xwq = xw.view(B, Lq, 192)[n % B]                                     # (Lq, 192)
     ref = ref_lvl[n]                                                     # (Lq, L, 2)
