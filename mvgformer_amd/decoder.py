@@ -16,6 +16,7 @@ What differs from the reference by design (MI355X-first, results identical):
 from __future__ import annotations
 
 import copy
+import os
 
 import torch
 import torch.nn.functional as F
@@ -468,9 +469,11 @@ class DQDecoder(MvPDecoder):
 
     def __init__(self, cfg, decoder_layer, num_layers, return_intermediate=False):
         super().__init__(cfg, decoder_layer, num_layers, return_intermediate)
-        # measured on MI355X (cfg-2, bf16): 2.97 ms with the side stream vs 2.91 ms without -- the query-side
-        # kernels already saturate the L2/fabric, so the overlap buys nothing; kept as an option
-        self.overlap_value_projection = False
+        # The pyramid-side GEMMs of every layer (value planes + G, 73 us per layer) depend only on the packed
+        # feature maps: issue all of them on a side stream at the start of the forward (fork/join -> a parallel
+        # branch of the captured HIP graph).  They fill in next to the latency-bound query-side kernels:
+        # cfg-2 bf16 1.43 -> 1.30 ms per sample on MI355X.  MVG_OVERLAP_PYRAMID=0 runs them inline.
+        self.overlap_pyramid = os.environ.get("MVG_OVERLAP_PYRAMID", "1") != "0"
         self._side_stream = None
         # layer l's fused chain B also computes layer l+1's query term xw = (tgt' + query_pos) W^T + b (bf16 path)
         self.fuse_next_query_term = True
@@ -479,6 +482,37 @@ class DQDecoder(MvPDecoder):
         for layer in self.layers:
             layer.set_compute_dtype(dtype)
         return self
+
+    def launch_pyramid_projections(self, ctx):
+        """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
+        by an event its consumer waits on.  Returns the side stream (pass it to join_pyramid_projections before
+        the forward / the captured graph ends) or None when the projections run inline (fp32 / generic path,
+        share_layer_weights -- one buffer for all layers --, training, MVG_OVERLAP_PYRAMID=0)."""
+        layer0 = self.layers[0]
+        distinct = len({id(l.proj_attn) for l in self.layers}) == len(self.layers)
+        if not (self.overlap_pyramid and distinct and ctx.feat is not None and ctx.feat.is_cuda
+                and all(l.proj_attn.uses_fast_path(l.compute_dtype) for l in self.layers)
+                and not torch.is_grad_enabled()):
+            return None
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        ctx.feat.record_stream(side)
+        with torch.cuda.stream(side):
+            for layer in self.layers:
+                layer.proj_attn.project_pyramid(ctx.feat, record_event=True)
+        return side
+
+    def join_pyramid_projections(self, side, keep_results=False):
+        """The current stream waits for the side stream.  keep_results: projections not consumed yet stay valid for
+        the layers that follow on this stream (the segmented graphs of mvgformer_amd.dist); else they are dropped."""
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        for layer in self.layers:
+            pa = layer.proj_attn
+            pa._vp_event = True if (keep_results and pa._vp_event is not None) else None
 
     def forward(self, tgt, reference_points, src_views, meta, src_spatial_shapes, src_level_start_index,
                 src_valid_ratios, query_pos=None, src_padding_mask=None, rgb_views=None, output_dir="./",
@@ -499,23 +533,7 @@ class DQDecoder(MvPDecoder):
         ctx.order = None
         inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
         ref_points_2d = None
-        # The value projections (27 % of the FLOPs) depend only on the pyramid: run all of them on a side
-        # stream, overlapped with the query-side kernels of the earlier layers (fork/join -> parallel
-        # branches of the captured HIP graph).
-        side = None
-        pa0 = layer0.proj_attn
-        distinct = len({id(l.proj_attn) for l in self.layers}) == len(self.layers)   # share_layer_weights -> one buffer
-        if (self.overlap_value_projection and distinct and layer0.compute_dtype == torch.bfloat16
-                and pa0.use_fast_path and not torch.is_grad_enabled()):
-            main = torch.cuda.current_stream()
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-            side = self._side_stream
-            side.wait_stream(main)
-            ctx.feat.record_stream(side)
-            with torch.cuda.stream(side):
-                for layer in self.layers:
-                    layer.proj_attn.project_values(ctx.feat, record_event=True)
+        side = self.launch_pyramid_projections(ctx)
         # the fused chain writes every layer's hidden state straight into its slice of the stacked output
         hs_buf = None
         if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
@@ -555,9 +573,7 @@ class DQDecoder(MvPDecoder):
                 layer._geo_out = None
                 layer._next_layer = None
                 layer._xw_in = None
-                layer.proj_attn._vp_event = None
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
+            self.join_pyramid_projections(side)
         if self.return_intermediate:
             in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape
                                                   for i, t in enumerate(inter))

@@ -178,8 +178,17 @@ class GraphedShardedDecoder:
             layer._next_layer = (layers[l + 1],) if (fuse and l + 1 < len(layers)) else None
             layer._xw_in = None
         ref = self.ref if self.ref.dim() == 4 else self.ref[:, :, None]
-        st = segment(lambda: (self.ctx.pack(self.src), layers[0].forward_features(self.tgt, self.qpos, ref, self.ctx,
-                                                                                   self.thr))[1])
+
+        def first():
+            # every layer's pyramid-side GEMMs (replicated on all ranks: they bound the strong scaling) are issued on
+            # the side stream in this segment, next to layer 0's query-side kernels; the later segments find them done
+            self.ctx.pack(self.src)
+            side = self.dec.launch_pyramid_projections(self.ctx) if hasattr(self.dec, "launch_pyramid_projections") else None
+            st0 = layers[0].forward_features(self.tgt, self.qpos, ref, self.ctx, self.thr)
+            if side is not None:
+                self.dec.join_pyramid_projections(side, keep_results=True)
+            return st0
+        st = segment(first)
         for l, layer in enumerate(layers):
             self.flags.append(st["any_valid"])
             last = l + 1 == len(layers)
@@ -198,6 +207,7 @@ class GraphedShardedDecoder:
         for layer in layers:
             layer._next_layer = None
             layer._xw_in = None
+            layer.proj_attn._vp_event = None
         self.send, self.geo = res
         self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
         self.out = segment(lambda: unpack_outputs(self.recv, self.geo))

@@ -217,10 +217,11 @@ def value_proj_planes_ws(feat, w_frag, bias, vp):
     return vp
 
 
-def feat_linear_ws(feat, w_frag, N=192):
+def feat_linear_ws(feat, w_frag, N=192, out=None):
     """G = feat @ W^T, row-major bf16 (n_img*S, N) (weight-stationary kernel, no bias)."""
     n_img, S, _ = feat.shape
-    G = torch.empty((n_img * S, N), dtype=torch.bfloat16, device=feat.device)
+    G = out if out is not None else torch.empty((n_img * S, N), dtype=torch.bfloat16, device=feat.device)
+    assert G.dtype == torch.bfloat16 and G.is_contiguous() and tuple(G.shape) == (n_img * S, N)
     with _timed("feat_linear_ws"):
       L.check(L.load().mvg_feat_linear_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(G), n_img, S, N, L.stream_ptr()),
               "mvg_feat_linear_ws")

@@ -86,6 +86,7 @@ class ProjAttn(nn.Module):
         self._wc = WeightCache()
         self._vp = None
         self._vp_event = None
+        self._G = None
 
     def _reset_parameters(self):
         constant_(self.sampling_offsets.weight.data, 0.)
@@ -121,31 +122,46 @@ class ProjAttn(nn.Module):
                 wc.get("bp", (self.output_proj.bias,), torch.float32))
 
     def _pair_buffer(self, n_img, S, device):
-        """pixel-pair value buffer (every line is fully rewritten by each projection); kept across calls."""
+        """value planes buffer (every line is fully rewritten by each projection); kept across calls."""
         shape = (n_img, 8, S, 32)
         if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
             self._vp = torch.empty(shape, dtype=torch.bfloat16, device=device)
         return self._vp
 
-    def _wait_values(self):
-        """values were projected ahead of time on a side stream (DQDecoder.overlap_value_projection)."""
-        torch.cuda.current_stream().wait_event(self._vp_event)
+    def _wait_pyramid(self):
+        """both pyramid projections were produced ahead of time on a side stream (DQDecoder.launch_pyramid_projections)."""
+        if self._vp_event is not True:          # True: already joined into this stream (segmented graphs)
+            torch.cuda.current_stream().wait_event(self._vp_event)
         self._vp_event = None
-        return self._vp
+        return self._vp, self._G
 
-    def project_values(self, feat, record_event=False):
-        """value = rayconv(input_flatten) (projattn.py:169) in the bf16 pixel-pair layout.  The projection
-        does not depend on the queries, so DQDecoder can run it for every layer on a side stream
-        (record_event=True: the consumer waits on the event)."""
+    def project_pyramid(self, feat, record_event=False):
+        """The two query-independent GEMMs of a layer: value planes (projattn.py:169) and G = feat @ [Wo; Wa]^T
+        (the pyramid side of projattn.py:180-181).  Neither depends on the queries, so DQDecoder runs them for
+        every layer on a side stream next to the latency-bound query-side kernels (record_event=True: the
+        consumer waits on the event); both land in buffers kept across calls."""
+        dt = feat.dtype
+        n_img, S, _ = feat.shape
+        # the 103-MB value write first, G (gathered at random by the sampler) last: G is then the fresher
+        # resident of the 256-MB Infinity Cache when the sampler starts
+        vp = self.project_values(feat)
+        shape = (n_img * S, 192)
+        if self._G is None or tuple(self._G.shape) != shape or self._G.device != feat.device:
+            self._G = torch.empty(shape, dtype=torch.bfloat16, device=feat.device)
+        ops.feat_linear_ws(feat, self.query_term_weights(dt)[0], 192, out=self._G)
+        if record_event:
+            self._vp_event = torch.cuda.Event()
+            self._vp_event.record()
+        return vp, self._G
+
+    def project_values(self, feat):
+        """value = rayconv(input_flatten) (projattn.py:169) as bf16 head planes vh[img][head][s][32]."""
         dt = feat.dtype
         n_img, S, _ = feat.shape
         bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
         Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
         vp = self._pair_buffer(n_img, S, feat.device)
         ops.value_proj_planes_ws(feat, Wv_f, bv, vp)
-        if record_event:
-            self._vp_event = torch.cuda.Event()
-            self._vp_event.record()
         return vp
 
     def native_forward(self, x, r, feat, levels, V, B, rowmask=None):
@@ -191,17 +207,13 @@ class ProjAttn(nn.Module):
         if self.uses_fast_path(dt):
             # Linear(bilinear(feat) + x) = bilinear(Linear(feat)) + Linear(x): project the pyramid once (G), compute
             # the query term once per layer (xw), gather offsets/logits inside the sampler (csrc/msda.hip)
-            Woa_f = self.query_term_weights(dt)[0]
             # processing order of the pairs: given by the caller (DQDecoderLayer shares it with chain A) or binned here
             if order is None and self.sort_pairs and r.shape[1] <= 65536:
                 order = ops.bin_pairs(r, pair_mask, levels)
             if xw is None:      # else: already computed by the previous layer's fused chain B
                 Wq, bq = self._fast_query_weights(dt)
                 xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
-            # the 206-MB value write first, the 77-MB G (gathered at random by the sampler) last, so that G is the
-            # freshest resident of the 256-MB Infinity Cache when the sampler starts
-            vp = self.project_values(feat) if self._vp_event is None else self._wait_values()
-            G = ops.feat_linear_ws(feat, Woa_f, 192)
+            vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181

@@ -3,7 +3,8 @@ import torch
 from mvgformer_amd import ops
 from mvgformer_amd.factory import build_decoder_for_case, case_to_device
 from mvgformer_amd.synthetic import build_case
-case = build_case("cfg2", seed=0)
+vf = float(sys.argv[1]) if len(sys.argv) > 1 else None
+case = build_case("cfg2", seed=0, valid_fraction=vf)
 dec = build_decoder_for_case(case, "cuda", torch.bfloat16)
 g = case_to_device(case, "cuda")
 orig = ops.project

@@ -1,0 +1,14 @@
+"""Per-kernel timeline of the last forward in a rocprofv3 kernel trace (start/end relative to the step's first
+kernel, stream/queue) -- shows what the side-stream GEMMs overlap with.  tools/timeline.py <trace dir>"""
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# last forward: starts at the last but one pack_level group
+idx = [i for i, r in enumerate(rows) if "pack_level" in r["Kernel_Name"]]
+start = idx[-3]
+t0 = int(rows[start]["Start_Timestamp"])
+for r in rows[start:]:
+    n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:42]
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+    print("%-42s q%-3s %8.1f %8.1f  %6.1f" % (n, r.get("Queue_Id", "?"), s, e, e - s))
