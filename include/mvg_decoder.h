@@ -129,7 +129,7 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
  *       rows in the order of mvgformer_amd.ops.gsamp_column_order: 8 groups of 16 offset + 8 logit outputs, so that
  *       with the reference's memory reinterpretation the 72 values a head needs are contiguous in a G row).
  *   mvg_msda_gsamp          : per (image, query, head): gathers its 24 logits + 48 offsets from G at the reference
- *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b (same column order as G), softmax, locations, samples vp -> samp
+ *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b (same column order as G), softmax, locations, samples vh -> samp
  *       (N_img*Lq, 256) bf16.  M=8, D=32, P=8, L<=4.  pair_mask (N_img*Lq) u8 or NULL: rows with mask 0 are
  *       written as zeros without being sampled (the consumer multiplies exactly these rows by the in-image mask,
  *       dq_decoder.py:585-586).  order (N_img*Lq) i32 or NULL: slot i of the launch computes pair order[i].
@@ -138,7 +138,7 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
 int mvg_value_proj_planes_ws(const void* feat, const void* Wf, const float* bias, void* vh, int n_img, int S,
                              void* stream);
 int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
-int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* ref_lvl,
+int mvg_msda_gsamp(const void* vh, const void* G, const float* xw, const float* ref_lvl,
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,
                    const uint8_t* pair_mask, const int32_t* order,
                    int N_img, int Lq, int L, int S, int B, void* stream);

@@ -483,22 +483,29 @@ class DQDecoder(MvPDecoder):
             layer.set_compute_dtype(dtype)
         return self
 
-    def launch_pyramid_projections(self, ctx):
-        """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
-        by an event its consumer waits on.  Returns the side stream (pass it to join_pyramid_projections before
-        the forward / the captured graph ends) or None when the projections run inline (fp32 / generic path,
-        share_layer_weights -- one buffer for all layers --, training, MVG_OVERLAP_PYRAMID=0)."""
-        layer0 = self.layers[0]
+    def fork_side_stream(self, device):
+        """The side stream of the forward, forked from the current stream -- or None when the query-independent work
+        runs inline (fp32 / generic path, share_layer_weights -- one buffer for all layers --, training, CPU,
+        MVG_OVERLAP_PYRAMID=0)."""
         distinct = len({id(l.proj_attn) for l in self.layers}) == len(self.layers)
-        if not (self.overlap_pyramid and distinct and ctx.feat is not None and ctx.feat.is_cuda
-                and all(l.proj_attn.uses_fast_path(l.compute_dtype) for l in self.layers)
-                and not torch.is_grad_enabled()):
+        if not (self.overlap_pyramid and distinct and device.type == "cuda" and not torch.is_grad_enabled()
+                and all(l.proj_attn.uses_fast_path(l.compute_dtype) and l.use_fused_chains for l in self.layers)):
             return None
-        main = torch.cuda.current_stream()
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
-        side = self._side_stream
-        side.wait_stream(main)
+        self._side_stream.wait_stream(torch.cuda.current_stream())
+        return self._side_stream
+
+    def launch_pyramid_projections(self, ctx, side=None):
+        """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
+        by an event its consumer waits on.  Returns the side stream (pass it to join_pyramid_projections before
+        the forward / the captured graph ends) or None when the projections run inline."""
+        if side is None:
+            side = self.fork_side_stream(ctx.feat.device)
+            if side is None:
+                return None
+        else:
+            side.wait_stream(torch.cuda.current_stream())       # the packed pyramid
         ctx.feat.record_stream(side)
         with torch.cuda.stream(side):
             for layer in self.layers:
@@ -525,28 +532,31 @@ class DQDecoder(MvPDecoder):
         output = tgt
         layer0 = self.layers[0]
         ctx = context
-        if ctx is None:
-            ctx = DecoderContext.build(src_views, src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
-                                       layer0.compute_dtype, tgt.shape[0])
-        elif ctx.feat is None:
-            ctx.pack(src_views)
-        ctx.order = None
-        inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
-        ref_points_2d = None
-        side = self.launch_pyramid_projections(ctx)
-        # the fused chain writes every layer's hidden state straight into its slice of the stacked output
-        hs_buf = None
-        if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
-            hs_buf = torch.empty((len(self.layers),) + tuple(tgt.shape), dtype=torch.float32, device=tgt.device)
-        flags = torch.zeros((len(self.layers),), dtype=torch.int32, device=tgt.device) if tgt.is_cuda else None
-        geo_buf = None
-        if hs_buf is not None:
-            nl, Bq, Lq_ = len(self.layers), tgt.shape[0], tgt.shape[1]
-            Vn = ctx.V
-            geo_buf = (torch.empty((nl, Bq, Lq_, 3), dtype=torch.float32, device=tgt.device),
-                       torch.empty((nl, Bq, Vn, Lq_, 2), dtype=torch.float32, device=tgt.device),
-                       torch.empty((nl, Bq, Vn, Lq_, 2), dtype=torch.float32, device=tgt.device))
+        side = self.fork_side_stream(tgt.device)
+        hs_buf = flags = geo_buf = None
         try:
+            if ctx is None:
+                ctx = DecoderContext.build(src_views, src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
+                                           layer0.compute_dtype, tgt.shape[0])
+            elif ctx.feat is None:
+                ctx.pack(src_views)
+            ctx.order = None
+            inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
+            ref_points_2d = None
+            if side is not None:
+                self.launch_pyramid_projections(ctx, side)
+            # the fused chain writes every layer's hidden state straight into its slice of the stacked output
+            hs_buf = None
+            if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
+                hs_buf = torch.empty((len(self.layers),) + tuple(tgt.shape), dtype=torch.float32, device=tgt.device)
+            flags = torch.zeros((len(self.layers),), dtype=torch.int32, device=tgt.device) if tgt.is_cuda else None
+            geo_buf = None
+            if hs_buf is not None:
+                nl, Bq, Lq_ = len(self.layers), tgt.shape[0], tgt.shape[1]
+                Vn = ctx.V
+                geo_buf = (torch.empty((nl, Bq, Lq_, 3), dtype=torch.float32, device=tgt.device),
+                           torch.empty((nl, Bq, Vn, Lq_, 2), dtype=torch.float32, device=tgt.device),
+                           torch.empty((nl, Bq, Vn, Lq_, 2), dtype=torch.float32, device=tgt.device))
             for lid, layer in enumerate(self.layers):
                 layer._ctx = ctx
                 layer._tgt_out = None if hs_buf is None else hs_buf[lid]

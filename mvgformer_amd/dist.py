@@ -182,8 +182,10 @@ class GraphedShardedDecoder:
         def first():
             # every layer's pyramid-side GEMMs (replicated on all ranks: they bound the strong scaling) are issued on
             # the side stream in this segment, next to layer 0's query-side kernels; the later segments find them done
+            side = self.dec.fork_side_stream(self.tgt.device) if hasattr(self.dec, "fork_side_stream") else None
             self.ctx.pack(self.src)
-            side = self.dec.launch_pyramid_projections(self.ctx) if hasattr(self.dec, "launch_pyramid_projections") else None
+            if side is not None:
+                self.dec.launch_pyramid_projections(self.ctx, side)
             st0 = layers[0].forward_features(self.tgt, self.qpos, ref, self.ctx, self.thr)
             if side is not None:
                 self.dec.join_pyramid_projections(side, keep_results=True)

@@ -209,7 +209,7 @@ def msda_fused(value, oa, r, levels):
 
 
 def value_proj_planes_ws(feat, w_frag, bias, vp):
-    """weight-stationary value projection (bf16 feat, swizzled weight) into the pixel-pair layout."""
+    """weight-stationary value projection (bf16 feat, swizzled weight) into head planes vh[img][head][s][32]."""
     n_img, S, K = feat.shape
     with _timed("value_proj_ws"):
       L.check(L.load().mvg_value_proj_planes_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(bias), L.ptr(vp), n_img, S, L.stream_ptr()),

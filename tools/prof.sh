@@ -8,6 +8,9 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 3 --cpu-baseline 0 --graph 0 --profile-steps 0 $*"
+# per-kernel durations and counters are those of each kernel running alone (as bench.py's roofline pass times them):
+# the pyramid GEMMs are issued inline here; the overlapped schedule is traced separately at the end
+export MVG_OVERLAP_PYRAMID=0
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/trace.log" 2>&1
 for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
@@ -17,4 +20,6 @@ for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_
   rocprofv3 --pmc $PASS --kernel-trace -d "$OUT/pmc_$N" -o pmc --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/pmc_$N.log" 2>&1
 done
 python $ROOT/tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+MVG_OVERLAP_PYRAMID=1 rocprofv3 --kernel-trace -d "$OUT/overlap" -o trace --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/overlap.log" 2>&1
+python $ROOT/tools/timeline.py "$OUT/overlap" > "$OUT/timeline_overlap.txt" 2>&1
 cat "$OUT/summary.txt"

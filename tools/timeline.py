@@ -8,7 +8,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "pack_level" in r["Kernel_Name"]]
 start = idx[-3]
 t0 = int(rows[start]["Start_Timestamp"])
-for r in rows[start:]:
+end = max(i for i, r in enumerate(rows) if "triangulate" in r["Kernel_Name"])
+print("# one forward (eager launches), us relative to the first pack kernel; q = HSA queue (main / side stream)")
+print("%-42s %-4s %8s %8s  %6s" % ("kernel", "q", "start", "end", "dur"))
+for r in rows[start:end + 1]:
     n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:42]
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
     print("%-42s q%-3s %8.1f %8.1f  %6.1f" % (n, r.get("Queue_Id", "?"), s, e, e - s))
