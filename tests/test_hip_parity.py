@@ -771,6 +771,49 @@ def test_full_size_bf16_forward_is_bit_reproducible():
                 assert torch.equal(x, y)
 
 
+def test_side_stream_pyramid_projections_change_nothing():
+    """DQDecoder.launch_pyramid_projections: all layers' value planes and G are produced on a side stream, each layer's
+    sampler waits on its event.  Same kernels, same inputs -> the outputs must equal the inline schedule BIT FOR BIT,
+    eagerly and as a replayed HIP graph with the parallel branch (a missing wait would show up here as a stale or
+    half-written vh / G), and the schedule must really be in use."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("cfg2", seed=1)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    from mvgformer_amd.decoder import DecoderContext
+    ctx = DecoderContext.prepare(gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size, torch.bfloat16, 1, DEV)
+
+    def run():
+        ctx.feat = None      # pack the pyramid inside the forward (and inside the graph)
+        return dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                   query_pos=gc.query_pos, threshold=0.1, context=ctx)
+    with torch.no_grad():
+        dec.overlap_pyramid = False
+        assert dec.fork_side_stream(torch.device(DEV)) is None
+        ref = [t.clone() for t in run()[:4]]
+        dec.overlap_pyramid = True
+        assert dec.fork_side_stream(torch.device(DEV)) is not None
+        torch.cuda.synchronize()
+        for _ in range(3):
+            got = run()
+            torch.cuda.synchronize()
+            for x, y in zip(ref, got[:4]):
+                assert torch.equal(x, y)
+        assert all(l.proj_attn._vp_event is None for l in dec.layers)          # every event consumed / dropped
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = run()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(ref, out[:4]):
+            assert torch.equal(x, y)
+        # a decoder that shares one layer (one set of vh / G buffers) must fall back to the inline schedule
+        shared = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+        shared.layers = torch.nn.ModuleList([shared.layers[0]] * len(shared.layers))
+        assert shared.fork_side_stream(torch.device(DEV)) is None
+
+
 def test_fused_chains_match_unfused_path_full_size():
     """the same comparison at cfg-2 size: the chain kernels run with two workgroups per CU / one tile per CU there,
     which no small case reaches (a scale-dependent miscompilation hid inside the tolerances of the small test)."""
