@@ -59,6 +59,10 @@ def main():
                     help="N > 1: queries = ONE sample per step, its person-queries sharded over the ranks + all-gather of "
                          "the pose set (BASELINE configs[2], strong scaling; default); samples = one sample per rank and "
                          "step, all-gather of the final pose sets (batch-parallel replicas, weak scaling)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="samples in flight per GPU (serving mode, 1 GPU / --shard samples): K independent decoder "
+                         "instances, each forward a HIP graph on its own stream, replayed concurrently; a step is then "
+                         "K samples.  Default 1 = the single-sample forward the headline number is quoted on")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -176,6 +180,43 @@ def main():
                 graph = None
                 torch.cuda.synchronize()
         step = (lambda: graph.replay()) if graph is not None else forward
+        extra = []
+        if args.inflight > 1:
+            if sharded or graph is None or args.producer != "nchw":
+                raise SystemExit("--inflight needs HIP graphs, the default producer and no query sharding")
+            # more samples in flight: own decoder instance (own vh / G buffers), own stream, own graph each; the graphs
+            # hold raw pointers, so `extra` keeps their owners alive
+            for k in range(args.inflight):
+                if k == 0:          # the decoder built above, re-captured on its own stream like the others
+                    case_k, dec_k, g_k, ctx_k = case, dec, g, ctx
+                else:
+                    case_k = build_case(args.config, seed=1000 * k + rank, valid_fraction=args.valid_fraction)
+                    dec_k = build_decoder_for_case(case_k, dev, dtype)
+                    g_k = case_to_device(case_k, dev)
+                    ctx_k = DecoderContext.prepare(g_k.spatial_shapes, g_k.level_start_index, g_k.meta, case_k.img_size,
+                                                   dtype, 1, dev)
+
+                def fwd_k(dec_k=dec_k, g_k=g_k, ctx_k=ctx_k):
+                    ctx_k.feat = None
+                    return dec_k(g_k.tgt, g_k.reference_points, g_k.src_views, g_k.meta, g_k.spatial_shapes,
+                                 g_k.level_start_index, None, query_pos=g_k.query_pos, threshold=thr, context=ctx_k)
+                torch.cuda.synchronize()
+                s_k = torch.cuda.Stream()    # never the NULL stream: it would order the replays one after the other
+                with torch.cuda.stream(s_k):
+                    for _ in range(3):
+                        fwd_k()
+                    s_k.synchronize()
+                    graph_k = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_k, stream=s_k):
+                        out_k = fwd_k()
+                extra.append((s_k, graph_k, out_k, dec_k, g_k, ctx_k, case_k))
+            torch.cuda.synchronize()
+            out = extra[0][2]
+
+            def step():
+                for slot in extra:
+                    with torch.cuda.stream(slot[0]):
+                        slot[1].replay()
         if replicas:
             inner = step
 
@@ -227,7 +268,7 @@ def main():
     refs = out[1]
     assert torch.isfinite(refs).all(), "non-finite poses"
     ms_per_step = elapsed / args.steps * 1e3
-    value = (world if replicas else 1) * args.steps / elapsed   # samples / s of the whole job
+    value = (world if replicas else 1) * args.inflight * args.steps / elapsed   # samples / s of the whole job
 
     # roofline of the dominant kernel: one sampling-kernel launch covers all V views of one layer
     Lq_loc = (hi - lo) * J
@@ -293,6 +334,7 @@ def main():
                    "pyramid_handoff": {"nchw": "NCHW fp32 (reference producer format), packed per step",
                                        "nhwc": "channels-last %s, copied per step" % args.dtype,
                                        "inplace": "produced in the packed layout (no per-step pack)"}[args.producer],
+                   "samples_in_flight": args.inflight,
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
     }
