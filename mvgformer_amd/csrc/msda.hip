@@ -19,6 +19,12 @@
 
 #include "common.h"
 
+// Index-safe copy of an image coordinate: equal to x wherever the sample counts (-1 < x < n), -2 <= . <= n+1 otherwise
+// (v_med3_f32 returns the minimum of the non-NaN operands when x is NaN: -2).  floor, the float->int conversion and
+// the +1 of the lower-right corner are taken from it, so that they can neither overflow nor be undefined for NaN,
+// +-Inf or 1e30 locations; the reference's bounds test (cuh:298) still looks at the original value and rejects those.
+__device__ __forceinline__ float index_safe(float x, float n) { return __builtin_amdgcn_fmed3f(x, -2.f, n + 1.f); }
+
 // ------------------------------------------------------------------------------------------
 // bilinear sample of 4 consecutive channels with the reference's zero padding
 // (cuh:44-94): corners outside [0,H-1]x[0,W-1] contribute 0; the sample is skipped unless
@@ -27,12 +33,14 @@
 template <typename T>
 __device__ __forceinline__ f32x4 bilinear4(const T* __restrict__ lvl_base, int H, int W, long row_stride,
                                            float h_im, float w_im, float scale) {
+  const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+  h_im = index_safe(h_im, (float)H);
+  w_im = index_safe(w_im, (float)W);
   const float hl_f = floorf(h_im), wl_f = floorf(w_im);
   const int h_low = (int)hl_f, w_low = (int)wl_f;
   const int h_high = h_low + 1, w_high = w_low + 1;
   const float lh = h_im - hl_f, lw = w_im - wl_f;
   const float hh = 1.f - lh, hw = 1.f - lw;
-  const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
   const float s = inside ? scale : 0.f;
   const bool hl_ok = h_low >= 0, hh_ok = h_high <= H - 1, wl_ok = w_low >= 0, wh_ok = w_high <= W - 1;
   const float w1 = (hl_ok && wl_ok) ? hh * hw : 0.f;
@@ -52,12 +60,12 @@ __device__ __forceinline__ f32x4 bilinear4(const T* __restrict__ lvl_base, int H
 template <typename T>
 __device__ __forceinline__ float bilinear1(const T* __restrict__ lvl_base, int H, int W, long row_stride,
                                            float h_im, float w_im, float scale) {
+  if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) return 0.f;   // also NaN
   const float hl_f = floorf(h_im), wl_f = floorf(w_im);
   const int h_low = (int)hl_f, w_low = (int)wl_f;
   const int h_high = h_low + 1, w_high = w_low + 1;
   const float lh = h_im - hl_f, lw = w_im - wl_f;
   const float hh = 1.f - lh, hw = 1.f - lw;
-  if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) return 0.f;
   float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
   if (h_low >= 0 && w_low >= 0) v1 = load1<T>(lvl_base + ((long)h_low * W + w_low) * row_stride);
   if (h_low >= 0 && w_high <= W - 1) v2 = load1<T>(lvl_base + ((long)h_low * W + w_high) * row_stride);
@@ -270,12 +278,13 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
     for (int s = 0; s < NB; ++s) {
       const float lx = refx + o4[s >> 1][2 * (s & 1)] * invW;       // projattn.py:186-191
       const float ly = refy + o4[s >> 1][2 * (s & 1) + 1] * invH;
-      const float h_im = ly * Hf - 0.5f;                             // cuh:295-296
-      const float w_im = lx * Wf - 0.5f;
+      const float h_raw = ly * Hf - 0.5f;                            // cuh:295-296
+      const float w_raw = lx * Wf - 0.5f;
+      const bool inside = (h_raw > -1.f) && (w_raw > -1.f) && (h_raw < Hf) && (w_raw < Wf);   // cuh:298
+      const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
       const float hl_f = floorf(h_im), wl_f = floorf(w_im);
       const int h_low = (int)hl_f, w_low = (int)wl_f;
       const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // cuh:298
       const float a = inside ? __expf(lg[s >> 2][s & 3] - mx) : 0.f;   // softmax weight (projattn.py:184)
       const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
       cw[s][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;               // cuh:66-88 zero padding
@@ -352,11 +361,12 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
   const float lgs = sc[it * NB + sub];
   const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
   const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];               // projattn.py:186-191
-  const float h_im = ly * Hf - 0.5f, w_im = lx * Wf - 0.5f;                           // cuh:295-296
+  const float h_raw = ly * Hf - 0.5f, w_raw = lx * Wf - 0.5f;                         // cuh:295-296
+  const bool inside = (h_raw > -1.f) & (w_raw > -1.f) & (h_raw < Hf) & (w_raw < Wf);  // cuh:298
+  const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
   const float hl_f = floorf(h_im), wl_f = floorf(w_im);
   const int h_low = (int)hl_f, w_low = (int)wl_f;
   const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-  const bool inside = (h_im > -1.f) & (w_im > -1.f) & (h_im < Hf) & (w_im < Wf);      // cuh:298
   const float e = __expf(lgs - mx);                                                   // <= 1: safe to evaluate always
   const float a = inside ? e : 0.f;
   const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;

@@ -995,3 +995,75 @@ def test_deform_forward_full_size_vs_c_oracle():
     got16 = ops.msda_forward(dv(value).to(torch.bfloat16), dv(shapes), dv(starts), dv(loc), dv(wgt)).float().cpu()
     want16 = msda_c.msda_forward(value.to(torch.bfloat16).float(), shapes, starts, loc, wgt)
     assert float((got16 - want16).abs().max()) < 6e-3 * scale            # bf16 rounding of the output
+
+
+def test_non_finite_and_far_away_locations_read_nothing():
+    """Sampling locations that are NaN, +-Inf or astronomically far outside the map: the reference kernel's bounds test
+    (ms_deform_im2col_cuda.cuh:298, all four comparisons false for NaN) makes them contribute 0 -- and nothing may be
+    read out of bounds.  Checked for the drop-in op against the C oracle, and for the bf16 sampling kernels of the
+    decoder (a NaN / huge query term, as a diverged training state would produce) for memory safety + finite output
+    on the untouched rows."""
+    from mvgformer_amd import ops
+    from oracle import msda_c
+    torch.manual_seed(33)
+    N, M, D, Lq, P = 1, 8, 32, 512, 8
+    shapes = torch.tensor([[24, 40], [12, 20], [6, 10]], dtype=torch.int64)
+    starts = torch.tensor([0, 960, 1200], dtype=torch.int64)
+    S = 1260
+    value = torch.randn(N, S, M, D)
+    loc = torch.rand(N, Lq, M, 3, P, 2)
+    bad = [float("nan"), float("inf"), float("-inf"), 1e30, -1e30, 3.4e38, -3.4e38, 2 ** 31 + 0.5, -(2 ** 31) - 0.5]
+    flat = loc.view(-1)
+    idx = torch.randperm(flat.numel())[:len(bad) * 200]
+    flat[idx] = torch.tensor(bad).repeat(200)
+    wgt = torch.softmax(torch.randn(N, Lq, M, 3 * P), -1).view(N, Lq, M, 3, P)
+    want = msda_c.msda_forward(value, shapes, starts, loc, wgt)
+    assert torch.isfinite(want).all()
+    dv = lambda t: t.to(DEV)
+    got = ops.msda_forward(dv(value), dv(shapes), dv(starts), dv(loc), dv(wgt)).cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+    # decoder sampling kernels (generic fused + G-sampling): poison part of the query term / reference points
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("mini5", seed=2, layers=1)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    pa = dec.layers[0].proj_attn
+    with torch.no_grad():
+        ctx = DecoderContext.build(gc.src_views, gc.spatial_shapes, gc.level_start_index, gc.meta, case.img_size,
+                                   torch.bfloat16, 1)
+        r, ref_lvl, inside = ops.project(gc.reference_points, ctx.cams, ctx.levels, ctx.V, 1)
+        x = (gc.tgt + gc.query_pos).contiguous()
+        Wq, bq = pa._fast_query_weights(torch.bfloat16)
+        xw = ops.linear(x.reshape(-1, 256), Wq, bq, out_dtype=torch.float32)
+        vp, G = pa.project_pyramid(ctx.feat)
+        clean = ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1, pair_mask=None, order=None).float()
+        Lq2 = ref_lvl.shape[1]
+        poisoned_rows = torch.arange(0, Lq2, 7, device=DEV)
+        xw_bad = xw.clone()
+        vals = torch.tensor(bad, device=DEV)
+        # offsets columns (the first 16 of each 24-column group) of every 7th query
+        for k, row in enumerate(poisoned_rows.tolist()):
+            xw_bad[row, (k % 8) * 24 + (k % 16)] = vals[k % len(bad)]
+        ref_bad = ref_lvl.clone()
+        ref_bad[0, 3::11] = float("nan")
+        ref_bad[1, 5::13] = 1e30
+        for order in (None, ops.bin_pairs(ref_bad, None, ctx.levels)):
+            out = ops.msda_gsamp(vp, G, xw_bad, ref_bad, ctx.levels, 1, pair_mask=None, order=order).float()
+            torch.cuda.synchronize()                       # a wild read would fault here
+            touched = torch.zeros(ctx.V, Lq2, dtype=torch.bool, device=DEV)
+            touched[:, poisoned_rows] = True
+            touched[0, 3::11] = True
+            touched[1, 5::13] = True
+            same = out.view(ctx.V, Lq2, 256)[~touched]
+            assert torch.equal(same, clean.view(ctx.V, Lq2, 256)[~touched])          # other pairs: bit-identical
+        # generic fused kernel (fp32 path): same poison through `oa`
+        L = ctx.levels.L
+        oa = torch.randn(ctx.V * Lq2 * L, 192, device=DEV)
+        oa.view(-1)[torch.randperm(oa.numel(), device=DEV)[:2000]] = vals.repeat(223)[:2000]
+        value32 = torch.randn(ctx.V, ctx.feat.shape[1], 256, device=DEV)
+        y = ops.msda_fused(value32, oa, ref_bad, ctx.levels)
+        torch.cuda.synchronize()
+        assert y.shape == (ctx.V * Lq2, 256)
