@@ -56,7 +56,10 @@ int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
 const char* mvg_version(void);
 /* Kernel-variant knobs for A/B measurements (host-only, process-wide; env MVG_TUNE="k=v,..").  Keys:
  *   "fused_cpl_bf16" = 4 | 8 : channels per lane of the generic fused sampling kernel (bf16);
- *   "gsamp_threads" = 256 | 512 | 1024 : workgroup size of the G-sampling kernel;
+ *   "gsamp_threads" = 128 | 256 | 512 | 1024 : workgroup size of the G-sampling kernel; "gsamp_map" = 0 | n : its
+ *       XCD block mapping (chunks of n slot blocks per XCD, 0 = one head per XCD);
+ *   "auto_small" = 1 | 0 : launches with few queries per image (<= 8192 joint tokens, e.g. a rank's shard of a
+ *       query-sharded run) use 128-thread sampling workgroups and single-block chunks (bit-identical results);
  *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
  *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs. */
 int mvg_set_tuning(const char* key, int value);

@@ -609,6 +609,10 @@ extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, cons
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // NOTE: the tile size is NOT chosen by the row count (64-row tiles are 2 % faster for a rank's shard of a
+  // query-sharded run): the last pose layer's fp32 reduction order differs between the variants in the last bit, and
+  // o_masked (one row, computed by whatever variant this function picks) must equal a masked row computed inside a
+  // mixed tile of the big launch -- which rows those are changes from run to run with the binning order.
   if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 128 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<128, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 64 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<64, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);

@@ -613,7 +613,10 @@ int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* sh
 #define MVG_BIN(K)                                                                                               \
   hipLaunchKernelGGL((bin_pairs_kernel<K>), dim3(N_img), dim3(1024), 0, (hipStream_t)stream, ref_lvl, inside,   \
                      (int*)order, Lq, L, W0, H0, shift)
-  if (Lq <= 16 * 1024) MVG_BIN(16);
+  if (Lq <= 2 * 1024) MVG_BIN(2);                // few queries per image (a rank's shard of a query-sharded run)
+  else if (Lq <= 4 * 1024) MVG_BIN(4);
+  else if (Lq <= 8 * 1024) MVG_BIN(8);
+  else if (Lq <= 16 * 1024) MVG_BIN(16);
   else if (Lq <= 32 * 1024) MVG_BIN(32);
   else if (Lq <= 64 * 1024) MVG_BIN(64);
   else return MVG_E_BADARG;                       // more than 65 536 tokens per image: run the sampler unordered

@@ -561,6 +561,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
 }
 
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
+int g_auto_small = 1;              // tuning knob "auto_small": small launches pick their own workgroup / tile sizes (see mvg_msda_gsamp)
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
@@ -752,17 +753,26 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   if ((long)N_img * S * 384 >= 0xffffffffL || (long)N_img * 8 * S * 64 >= 0xffffffffL) return MVG_E_BADARG;   // 32-bit byte offsets
   if (pairs == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // Few pairs (a rank's shard of a query-sharded run: 128 of 1024 queries at 8 GPUs): the launch is one partial round of
+  // workgroups and its time is a workgroup's latency -- smaller workgroups and single-block XCD chunks spread it over
+  // more CUs (cfg-2 with 128 / 256 queries: 0.83 / 0.90 -> 0.80 / 0.88 ms per forward).  Results do not depend on either
+  // (every (pair, head) is computed independently).
+  int nthreads = g_gsamp_threads, map = g_gsamp_map;
+  if (g_auto_small && Lq <= 8192) {
+    nthreads = 128;
+    map = 1;
+  }
 #define MVG_GS(LL, NT)                                                                                            \
   {                                                                                                               \
     int npb = (int)((pairs + NT / 4 - 1) / (NT / 4));                                                             \
-    if (g_gsamp_map > 0) npb = (npb + 8 * g_gsamp_map - 1) / (8 * g_gsamp_map) * (8 * g_gsamp_map);               \
+    if (map > 0) npb = (npb + 8 * map - 1) / (8 * map) * (8 * map);                                               \
     hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,            \
                        (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S, B,  \
-                       g_gsamp_map);                                                                              \
+                       map);                                                                                      \
   }
 #define MVG_GSN(LL)                                                                                               \
-  if (g_gsamp_threads == 1024) MVG_GS(LL, 1024) else if (g_gsamp_threads == 512) MVG_GS(LL, 512)                \
-  else if (g_gsamp_threads == 128) MVG_GS(LL, 128) else MVG_GS(LL, 256)
+  if (nthreads == 1024) MVG_GS(LL, 1024) else if (nthreads == 512) MVG_GS(LL, 512)                                \
+  else if (nthreads == 128) MVG_GS(LL, 128) else MVG_GS(LL, 256)
   switch (L) {
     case 1: MVG_GSN(1); break;
     case 2: MVG_GSN(2); break;
@@ -792,6 +802,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128 || value == 256)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
+  if (!strcmp(key, "auto_small") && (value == 0 || value == 1)) { g_auto_small = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;

@@ -493,6 +493,8 @@ class DQDecoder(MvPDecoder):
             return None
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
+        for l in self.layers:       # cached operands are built here, on the forking stream, never on the side stream
+            l.proj_attn.prepare_fast_path(l.compute_dtype)
         self._side_stream.wait_stream(torch.cuda.current_stream())
         return self._side_stream
 

@@ -45,6 +45,12 @@ class WeightCache:
         with torch.no_grad():
             t = build(*params) if build is not None else params[0]
             t = t.detach().to(dtype).contiguous()
+        # An entry is built on whatever stream is current and then handed out to every stream (the decoder issues
+        # query-independent work on a side stream): finish the build before anybody can see the entry.  Rare (first
+        # use / parameters changed).  Inside a graph capture a host wait is illegal -- DQDecoder.fork_side_stream
+        # fills the caches on the forking stream first (ProjAttn.prepare_fast_path), so nothing is built after a fork.
+        if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(t.device).synchronize()
         self._store[key] = (stamp, t)
         return t
 
@@ -127,6 +133,15 @@ class ProjAttn(nn.Module):
         if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
             self._vp = torch.empty(shape, dtype=torch.bfloat16, device=device)
         return self._vp
+
+    def prepare_fast_path(self, dtype):
+        """Fill every cached operand of the bf16 fast path on the CURRENT stream (called before work is forked onto
+        a side stream, so that no cache entry is ever produced on one stream and first read on another)."""
+        self.weights(dtype)
+        self._wc.get("bv", (self.rayconv.bias,), torch.float32)
+        self._wc.get("Wv_frag", (self.rayconv.weight,), dtype, lambda w: ops.swizzle_weight(w.to(dtype)))
+        self.query_term_weights(dtype)
+        self._fast_query_weights(dtype)
 
     def _wait_pyramid(self):
         """both pyramid projections were produced ahead of time on a side stream (DQDecoder.launch_pyramid_projections)."""
