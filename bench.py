@@ -292,7 +292,9 @@ def main():
         ach = bytes_launch / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": samp_key + "_kernel", "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-                "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch}
+                "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
+                # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
+                "fused_minimum_bytes_per_launch": V * (S * 256 + Lq_loc * 256) * elem}
     kern = {k: {"launches": n, "avg_us": round(ms * 1e3, 2)} for k, (n, ms) in sorted(prof.items())}
 
     cpu = None
