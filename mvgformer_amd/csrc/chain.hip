@@ -60,10 +60,26 @@ struct WaveMap {
   }
 };
 
-template <int MT, int KSTEPS, int RING = 4, int JN = 2>
+// The first RING weight fragments of a stage.  Issued by the caller BEFORE the previous stage's epilogue and barrier
+// (stage_gemm with PRE = true then starts on fragments that are already in flight): a stage that loads them itself
+// exposes one full L2 round trip before its first MFMA, 10 times per chain-B tile.
+template <int KSTEPS, int RING, int JN, int MT>
+__device__ __forceinline__ void ring_prefetch(const bf16_t* __restrict__ Wf, f32x4 (&ring)[RING][JN], int tid, int rot,
+                                              int wn_stride = KSTEPS * 1024) {
+  const WaveMap<JN> wm(tid, MT * 32);
+  const bf16_t* wp = Wf + (long)wm.wn * wn_stride + wm.j0 * 512 + (tid & 63) * 8;
+#pragma unroll
+  for (int p = 0; p < RING; ++p) {
+    const int kq = (p + rot) & (KSTEPS - 1);
+#pragma unroll
+    for (int j = 0; j < JN; ++j) ring[p][j] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + j * 512);
+  }
+}
+
+template <int MT, int KSTEPS, int RING = 4, int JN = 2, bool PRE = false>
 __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const bf16_t* __restrict__ Wf,
                                            f32x16 (&acc)[MT][JN], int tid, bool zero, int rot,
-                                           int wn_stride = KSTEPS * 1024) {
+                                           int wn_stride = KSTEPS * 1024, f32x4 (*pre)[JN] = nullptr) {
   static_assert((KSTEPS & (KSTEPS - 1)) == 0, "KSTEPS must be a power of two");
   const WaveMap<JN> wm(tid, MT * 32);
   const int lane = tid & 63, rl = lane & 31, h = lane >> 5, row0 = wm.row0;
@@ -81,16 +97,28 @@ __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const b
   for (int p = 0; p < RING; ++p) {
     const int kq = (p + rot) & (KSTEPS - 1);
 #pragma unroll
-    for (int j = 0; j < JN; ++j) ring[p][j] = *reinterpret_cast<const f32x4*>(wp + kq * 1024 + j * 512);
+    for (int j = 0; j < JN; ++j)
+      ring[p][j] = PRE ? pre[p][j] : *reinterpret_cast<const f32x4*>(wp + kq * 1024 + j * 512);
   }
+  // The activation fragments are read from LDS one k-step ahead of their MFMAs (register double buffer): issued in
+  // the same k-step, every step exposed the LDS latency in front of its first MFMA (MFMA pipe ~60 % busy with the
+  // two wavefronts of a SIMD alternating).
+  const char* arow = act + (row0 + rl) * ACT_PITCH + 16 * h;
+  f32x4 a_nxt[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    a_nxt[mt] = *reinterpret_cast<const f32x4*>(arow + mt * 32 * ACT_PITCH + (rot & (KSTEPS - 1)) * 32);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    const int kc = (ks + rot) & (KSTEPS - 1);
     f32x4 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      a[mt] = *reinterpret_cast<const f32x4*>(act + (row0 + mt * 32 + rl) * ACT_PITCH + kc * 32 + 16 * h);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = a_nxt[mt];
+    if (ks + 1 < KSTEPS) {
+      const int kn = (ks + 1 + rot) & (KSTEPS - 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *reinterpret_cast<const f32x4*>(arow + mt * 32 * ACT_PITCH + kn * 32);
+    }
     f32x4 b[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j) b[j] = ring[ks % RING][j];
@@ -132,6 +160,45 @@ __device__ __forceinline__ void write_act(char* __restrict__ act, const f32x16 (
           float x = acc[mt][j][4 * g + t] + bv[t];
           if (relu) x = fmaxf(x, 0.f);
           v[t] = keep[mt] ? x : 0.f;
+        }
+        uint2 pk;
+        pk.x = pack_bf16(v[0], v[1]);
+        pk.y = pack_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2*>(act + (row0 + mt * 32 + rl) * ACT_PITCH + n * 2) = pk;
+      }
+    }
+}
+
+// Same with the bias already in registers (load_bias): lets the caller order  bias loads -> next stage's ring_prefetch
+// -> epilogue, so that the epilogue's wait on the bias (vmcnt counts in order) leaves the prefetch in flight.
+template <int JN>
+__device__ __forceinline__ void load_bias(const float* __restrict__ bias, f32x4 (&bv)[JN][4], int tid, int mt_rows) {
+  const WaveMap<JN> wm(tid, mt_rows);
+  const int h = (tid & 63) >> 5;
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bv[j][g] = *reinterpret_cast<const f32x4*>(bias + wm.wn * 64 + (wm.j0 + j) * 32 + 8 * g + 4 * h);
+}
+
+template <int MT, int JN>
+__device__ __forceinline__ void write_act_pre(char* __restrict__ act, const f32x16 (&acc)[MT][JN], const f32x4 (&bv)[JN][4],
+                                              bool relu, const bool (&keep)[MT], int tid) {
+  const WaveMap<JN> wm(tid, MT * 32);
+  const int lane = tid & 63, rl = lane & 31, h = lane >> 5, row0 = wm.row0;
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = wm.wn * 64 + (wm.j0 + j) * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float x = acc[mt][j][4 * g + t] + bv[j][g][t];
+          v[t] = keep[mt] ? (relu ? fmaxf(x, 0.f) : x) : 0.f;
         }
         uint2 pk;
         pk.x = pack_bf16(v[0], v[1]);
@@ -220,10 +287,15 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
     all[mt] = true;
   }
   __syncthreads();
-  // attn = inside * output_proj(samp)
+  // attn = inside * output_proj(samp).  Every stage's bias and the NEXT stage's first weight fragments are requested
+  // before the barrier + epilogue that follow its k-loop (ring_prefetch).
+  f32x4 pf[4][JN], bvr[JN][4];
   stage_gemm<MT, 16, 4, JN>(act, Wp, acc, tid, true, rot);
+  load_bias<JN>(bp, bvr, tid, MT * 32);
+  ring_prefetch<16, 4, JN, MT>(W0, pf, tid, rot + 5);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  write_act<MT, JN>(act, acc, bp, false, keep, tid);
+  write_act_pre<MT, JN>(act, acc, bvr, false, keep, tid);
   __syncthreads();
 #pragma unroll
   for (int c0 = 0; c0 < RM * 32; c0 += NT) {
@@ -234,11 +306,14 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
           *reinterpret_cast<const f32x4*>(act + row * ACT_PITCH + v16 * 16);
   }
   // pose_embed MLP layers 0, 1 (ReLU)
-  stage_gemm<MT, 16, 4, JN>(act, W0, acc, tid, true, rot + 5);
+  stage_gemm<MT, 16, 4, JN, true>(act, W0, acc, tid, true, rot + 5, 16 * 1024, pf);
+  load_bias<JN>(b0, bvr, tid, MT * 32);
+  ring_prefetch<16, 4, JN, MT>(W1, pf, tid, rot + 10);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  write_act<MT, JN>(act, acc, b0, true, all, tid);
+  write_act_pre<MT, JN>(act, acc, bvr, true, all, tid);
   __syncthreads();
-  stage_gemm<MT, 16, 4, JN>(act, W1, acc, tid, true, rot + 10);
+  stage_gemm<MT, 16, 4, JN, true>(act, W1, acc, tid, true, rot + 10, 16 * 1024, pf);
   __syncthreads();
   write_act<MT, JN>(act, acc, b1, true, all, tid);
   __syncthreads();
@@ -430,7 +505,9 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 
   // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
   f32x16 acc[MT][JN];
+  f32x4 pf[BRING][JN];
   stage_gemm<MT, 16, BRING, JN>(act, Wu, acc, tid, true, rot);
+  if (has_ffn) ring_prefetch<16, BRING, JN, MT>(W1, pf, tid, rot);       // first FFN stage, fetched under LN2
   acc_to_x<MT, JN>(xb, acc, bu, false, tid);
   __syncthreads();
 #pragma unroll
@@ -483,12 +560,19 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     bool all[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) all[mt] = true;
+    // the first fragments of every stage are fetched one stage ahead (before the epilogue and barrier of the
+    // previous one), see ring_prefetch
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
-      stage_gemm<MT, 16, BRING, JN>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c);
-      write_act<MT, JN>(hbuf, acc, b1 + c * 256, true, all, tid);                         // private buffer: no hazard with act
+      stage_gemm<MT, 16, BRING, JN, true>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c, 16 * 1024, pf);
+      f32x4 bv1[JN][4];
+      load_bias<JN>(b1 + c * 256, bv1, tid, MT * 32);
+      ring_prefetch<16, BRING, JN, MT>(W2 + (long)c * 16 * 1024, pf, tid, rot + 3 * c + 1, 64 * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      write_act_pre<MT, JN>(hbuf, acc, bv1, true, all, tid);                                   // private buffer: no hazard with act
       __syncthreads();
-      stage_gemm<MT, 16, BRING, JN>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024);
+      stage_gemm<MT, 16, BRING, JN, true>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024, pf);
+      if (c < 3) ring_prefetch<16, BRING, JN, MT>(W1 + (long)(c + 1) * 256 * 256, pf, tid, rot + 3 * (c + 1));
       __syncthreads();                                                               // hbuf free for the next chunk
     }
     acc_to_x<MT, JN>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
