@@ -1,0 +1,51 @@
+"""bench.py's output contract (the driver parses this line): one JSON line on stdout with the metric of BASELINE.json,
+the `roofline` of the dominant kernel and the `cpu_baseline` timed beside it.  Runs the real script on the GPU with few
+steps; the CPU part only checks that the script refuses to run without a GPU instead of falling back."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_bench_refuses_to_run_without_a_gpu():
+    p = _run(["--steps", "1", "--warmup", "0"], timeout=300)
+    assert p.returncode != 0
+    assert "no CPU path" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields():
+    p = _run(["--steps", "5", "--warmup", "2", "--cpu-baseline", "0"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout"
+    d = json.loads(lines[0])
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert d["metric"] in base["metric"]                       # the metric BASELINE.json names
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "samples/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["hip_graph"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "msda_gsamp_kernel"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # 5 views x 46.20 MB (bf16) per launch
+    assert r["algorithmic_bytes_per_launch"] == 231014400
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_us"] / 1e3) < 1.0
+    assert 0.02 < r["frac"] < 1.0
