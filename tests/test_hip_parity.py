@@ -1067,3 +1067,37 @@ def test_non_finite_and_far_away_locations_read_nothing():
         y = ops.msda_fused(value32, oa, ref_bad, ctx.levels)
         torch.cuda.synchronize()
         assert y.shape == (ctx.V * Lq2, 256)
+
+
+def test_bf16_fast_path_batch_of_two():
+    """B = 2 through the benchmarked bf16 kernels (images = V*B, the query term indexed per batch item, chain-B tiles per
+    item): against the fp32 kernels of the same decoder (themselves pinned to the reference golden for B = 2,
+    mini5_b2), and item by item against single-sample runs (samples are independent units)."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("mini5", B=2, seed=17, NQ=8, layers=2)                    # all queries valid: no threshold flips
+    gc = case_to_device(case, DEV)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        dec = build_decoder_for_case(case, DEV, dtype=dt)
+        with torch.no_grad():
+            outs[dt] = [t.float().clone() for t in dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes,
+                                                       gc.level_start_index, None, query_pos=gc.query_pos, threshold=0.1)[:4]]
+    hs32, ref32, r2d32, p2d32 = outs[torch.float32]
+    hs16, ref16, r2d16, p2d16 = outs[torch.bfloat16]
+    assert hs16.shape[1] == 2 and torch.isfinite(hs16).all()
+    assert float((hs16 - hs32).abs().max()) < 8e-2
+    assert float((r2d16 - r2d32).abs().max()) < 0.6 and float((ref16 - ref32).norm(dim=-1).max()) < 8.0
+    # the two items really differ, and each equals its single-sample run
+    assert float((hs16[:, 0] - hs16[:, 1]).abs().max()) > 1e-2
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    V = case.V
+    for b in range(2):
+        src_b = [s.view(V, 2, *s.shape[1:])[:, b].contiguous() for s in gc.src_views]      # view-major (V*B, C, H, W)
+        meta_b = [{k: ({kk: vv[b:b + 1] for kk, vv in v.items()} if isinstance(v, dict) else v[b:b + 1])
+                   for k, v in m.items()} for m in gc.meta]
+        with torch.no_grad():
+            one = dec(gc.tgt[b:b + 1], gc.reference_points[b:b + 1], src_b, meta_b, gc.spatial_shapes, gc.level_start_index,
+                      None, query_pos=gc.query_pos[b:b + 1], threshold=0.1)
+        assert float((one[0][:, 0].float() - hs16[:, b]).abs().max()) < 2e-2          # tile numbering changes the fp32 sum order
+        assert float((one[1][:, 0].float() - ref16[:, b]).norm(dim=-1).max()) < 1.0
+        assert float((one[2][:, 0].float() - r2d16[:, b]).abs().max()) < 0.1
