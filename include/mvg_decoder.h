@@ -27,6 +27,7 @@
 #ifndef MVG_DECODER_H
 #define MVG_DECODER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -61,7 +62,8 @@ const char* mvg_version(void);
  *   "auto_small" = 1 | 0 : launches with few queries per image (<= 8192 joint tokens, e.g. a rank's shard of a
  *       query-sharded run) use 128-thread sampling workgroups and single-block chunks (bit-identical results);
  *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
- *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs. */
+ *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs;
+ *   "bin_multi" = 1 | 0 : multi-workgroup binning for large Lq (needs the workspace of mvg_bin_pairs). */
 int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
@@ -148,9 +150,12 @@ int mvg_msda_gsamp(const void* vh, const void* G, const float* xw, const float* 
 
 /* Processing order for mvg_msda_gsamp: per image, the Lq (image, query) pairs counting-sorted by the Morton code of
  * the level-0 cell block of their reference point, pairs with inside == 0 last.  order (N_img*Lq) int32 holds
- * global pair indices (n*Lq + q); it changes where a pair is computed, never its result.  inside may be NULL. */
+ * global pair indices (n*Lq + q); it changes where a pair is computed, never its result.  inside may be NULL.
+ * workspace: device scratch of at least mvg_bin_pairs_workspace(N_img, Lq) bytes (0 for small Lq), or NULL: with it,
+ * images with many pairs are sorted by 8 workgroups each (two kernels) instead of one. */
+size_t mvg_bin_pairs_workspace(int N_img, int Lq);
 int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* shapes_host, int L, int32_t* order,
-                  int N_img, int Lq, void* stream);
+                  int N_img, int Lq, void* workspace, size_t workspace_bytes, void* stream);
 
 /* A.4 (dq_decoder.py:770): mean over views of attn (V,B*Lq,C) `dtype` -> (B*Lq,C) `dtype`. */
 int mvg_mean_views(const void* attn, int dtype, void* out, int V, int rows, int C, void* stream);

@@ -35,7 +35,8 @@ SIGNATURES = {
     "mvg_value_proj_planes_ws": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_feat_linear_ws": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_msda_gsamp": [_vp] * 9 + [_i] * 5 + [_vp],
-    "mvg_bin_pairs": [_vp] * 3 + [_i] + [_vp] + [_i] * 2 + [_vp],
+    "mvg_bin_pairs": [_vp] * 3 + [_i] + [_vp] + [_i] * 2 + [_vp, C.c_size_t, _vp],
+    "mvg_bin_pairs_workspace": [_i, _i],
     "mvg_mean_views": [_vp, _i, _vp, _i, _i, _i, _vp],
     "mvg_add_layernorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_class_head": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -65,6 +66,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.mvg_version.restype = C.c_char_p
+    lib.mvg_bin_pairs_workspace.restype = C.c_size_t
     lib.mvg_version.argtypes = []
     _lib = lib
     # A/B knobs for measurements: MVG_TUNE="chain_rm=128,gsamp_threads=256"

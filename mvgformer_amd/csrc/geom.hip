@@ -569,6 +569,119 @@ __global__ __launch_bounds__(1024) void bin_pairs_kernel(const float* __restrict
   }
 }
 
+// ---- the same counting sort spread over BIN_PARTS workgroups per image (large Lq): the single-workgroup kernel is
+// bound by the LDS-atomic throughput of ONE CU (2 x Lq returning atomics on its LDS unit: 16.6 us at Lq = 15 360).
+//   bin_count_kernel  : part p counts the keys of its slice of the pairs in LDS and writes the 4097 counters and its
+//                       16-bit keys to the workspace;
+//   bin_scatter_kernel: every part re-derives the global offsets from all parts' counters (key-major, then part:
+//                       offset(k, p) = sum_{k' < k} total(k') + sum_{p' < p} count(p', k)) and scatters its slice.
+// No workgroup waits for another one: the dependency is the kernel boundary.
+int g_bin_multi = 1;                            // tuning knob "bin_multi": 0 = always the single-workgroup binning kernel
+constexpr int BIN_PARTS = 8;
+constexpr int BIN_MULTI_MIN = 8192;             // pairs per image from which the multi-workgroup variant is used
+constexpr int BIN_CNT_STRIDE = BIN_KEYS + 4;        // counters per (image, part), padded to 16 bytes
+
+template <int KPT>   // keys per thread: slice length <= 1024 * KPT
+__global__ __launch_bounds__(1024) void bin_count_kernel(const float* __restrict__ ref_lvl,
+                                                         const uint8_t* __restrict__ inside, unsigned* __restrict__ cnt,
+                                                         unsigned short* __restrict__ keys_out, int Lq, int Lp, int L,
+                                                         int W0, int H0, int shift) {
+  __shared__ int hist[BIN_KEYS + 4];
+  const int n = blockIdx.x / BIN_PARTS, part = blockIdx.x % BIN_PARTS, tid = threadIdx.x;
+  const int q0 = part * Lp, nq = max(0, min(Lp, Lq - q0));
+  for (int i = tid; i < BIN_KEYS + 4; i += 1024) hist[i] = 0;
+  float rx[KPT], ry[KPT];
+  uint8_t in[KPT];
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const long pair = (long)n * Lq + min(q0 + tid + 1024 * k, Lq - 1);
+    const float2 rr = *reinterpret_cast<const float2*>(ref_lvl + pair * L * 2);
+    rx[k] = rr.x;
+    ry[k] = rr.y;
+    in[k] = inside ? inside[pair] : (uint8_t)1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const int cx = min(max((int)(fminf(fmaxf(rx[k], 0.f), 1.f) * (float)W0), 0), W0 - 1) >> shift;
+    const int cy = min(max((int)(fminf(fmaxf(ry[k], 0.f), 1.f) * (float)H0), 0), H0 - 1) >> shift;
+    const int key = in[k] ? (int)(spread1((unsigned)cx) | (spread1((unsigned)cy) << 1)) : BIN_KEYS;
+    const bool live = tid + 1024 * k < nq;
+    const unsigned long long outm = __ballot(live && key == BIN_KEYS);
+    if (live && key != BIN_KEYS) atomicAdd(&hist[key], 1);
+    if (outm && (tid & 63) == 0) atomicAdd(&hist[BIN_KEYS], __popcll(outm));
+    if (live) keys_out[(long)n * Lq + q0 + tid + 1024 * k] = (unsigned short)key;
+  }
+  __syncthreads();
+  unsigned* dst = cnt + (long)blockIdx.x * BIN_CNT_STRIDE;
+  *reinterpret_cast<uint4*>(dst + 4 * tid) = *reinterpret_cast<const uint4*>(&hist[4 * tid]);
+  if (tid == 0) *reinterpret_cast<uint4*>(dst + BIN_KEYS) = *reinterpret_cast<const uint4*>(&hist[BIN_KEYS]);
+}
+
+template <int KPT>
+__global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __restrict__ cnt,
+                                                           const unsigned short* __restrict__ keys_in,
+                                                           int* __restrict__ order, int Lq, int Lp) {
+  __shared__ int hist[BIN_KEYS + 4];
+  __shared__ int wave_tot[16];
+  const int n = blockIdx.x / BIN_PARTS, part = blockIdx.x % BIN_PARTS, tid = threadIdx.x;
+  const int q0 = part * Lp, nq = max(0, min(Lp, Lq - q0));
+  int key[KPT];
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) key[k] = keys_in[(long)n * Lq + min(q0 + tid + 1024 * k, Lq - 1)];
+  // totals over the parts and this part's offset inside every key, 4 keys per thread
+  const unsigned* c0 = cnt + (long)n * BIN_PARTS * BIN_CNT_STRIDE;
+  int tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+  int out_before = 0;
+#pragma unroll
+  for (int p = 0; p < BIN_PARTS; ++p) {
+    const uint4 c = *reinterpret_cast<const uint4*>(c0 + (long)p * BIN_CNT_STRIDE + 4 * tid);
+    const int cc[4] = {(int)c.x, (int)c.y, (int)c.z, (int)c.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tot[i] += cc[i];
+      before[i] += (p < part) ? cc[i] : 0;
+    }
+    if (tid == 0) out_before += (p < part) ? (int)c0[(long)p * BIN_CNT_STRIDE + BIN_KEYS] : 0;
+  }
+  const int mine = tot[0] + tot[1] + tot[2] + tot[3];
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if ((tid & 63) >= d) incl += up;
+  }
+  if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int t = wave_tot[w];
+    base += (w < (tid >> 6)) ? t : 0;
+    total += t;
+  }
+  const int ex = base + incl - mine;
+  hist[4 * tid] = ex + before[0];
+  hist[4 * tid + 1] = ex + tot[0] + before[1];
+  hist[4 * tid + 2] = ex + tot[0] + tot[1] + before[2];
+  hist[4 * tid + 3] = ex + tot[0] + tot[1] + tot[2] + before[3];
+  if (tid == 0) hist[BIN_KEYS] = total + out_before;          // the "outside" pairs go last
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const bool live = tid + 1024 * k < nq;
+    const bool out = live && key[k] == BIN_KEYS;
+    const unsigned long long outm = __ballot(out);
+    int pos = 0;
+    if (live && !out) pos = atomicAdd(&hist[key[k]], 1);
+    int obase = 0;
+    if (outm && (tid & 63) == 0) obase = atomicAdd(&hist[BIN_KEYS], __popcll(outm));
+    obase = __shfl(obase, 0, 64);
+    if (out) pos = obase + __popcll(outm & ((1ull << (tid & 63)) - 1ull));
+    if (live) order[(long)n * Lq + pos] = n * Lq + q0 + tid + 1024 * k;
+  }
+}
+
 extern "C" {
 
 int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W, int S, int start,
@@ -601,8 +714,13 @@ int mvg_project(const float* X, const float* cams, const int64_t* shapes_host, i
   return 0;
 }
 
+size_t mvg_bin_pairs_workspace(int N_img, int Lq) {
+  if (N_img <= 0 || Lq < BIN_MULTI_MIN) return 0;
+  return (size_t)N_img * BIN_PARTS * BIN_CNT_STRIDE * sizeof(unsigned) + (size_t)N_img * Lq * sizeof(unsigned short);
+}
+
 int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* shapes_host, int L, int32_t* order,
-                  int N_img, int Lq, void* stream) {
+                  int N_img, int Lq, void* workspace, size_t workspace_bytes, void* stream) {
   if (!ref_lvl || !shapes_host || !order || L <= 0 || N_img < 0 || Lq < 0) return MVG_E_BADARG;
   if ((long)N_img * Lq > 0x7fffffffL) return MVG_E_BADARG;
   if (N_img == 0 || Lq == 0) return 0;
@@ -610,16 +728,37 @@ int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* sh
   if (H0 <= 0 || W0 <= 0) return MVG_E_BADARG;
   int shift = 2;                                  // 4 x 4 level-0 cells per bin, coarser for maps wider than 256 cells
   while (((W0 - 1) >> shift) >= (1 << BIN_BITS) || ((H0 - 1) >> shift) >= (1 << BIN_BITS)) ++shift;
+  if (Lq > 64 * 1024) return MVG_E_BADARG;        // more than 65 536 tokens per image: run the sampler unordered
+  hipStream_t st = (hipStream_t)stream;
+  if (g_bin_multi && Lq >= BIN_MULTI_MIN && workspace && workspace_bytes >= mvg_bin_pairs_workspace(N_img, Lq)) {
+    // many pairs per image: BIN_PARTS workgroups per image, two kernels (see bin_count_kernel)
+    unsigned* cnt = reinterpret_cast<unsigned*>(workspace);
+    unsigned short* keys = reinterpret_cast<unsigned short*>(cnt + (size_t)N_img * BIN_PARTS * BIN_CNT_STRIDE);
+    const int Lp = ((Lq + BIN_PARTS - 1) / BIN_PARTS + 63) / 64 * 64;       // slice length, whole wavefronts
+#define MVG_BIN2(K)                                                                                              \
+  {                                                                                                              \
+    hipLaunchKernelGGL((bin_count_kernel<K>), dim3(N_img * BIN_PARTS), dim3(1024), 0, st, ref_lvl, inside, cnt,  \
+                       keys, Lq, Lp, L, W0, H0, shift);                                                          \
+    hipLaunchKernelGGL((bin_scatter_kernel<K>), dim3(N_img * BIN_PARTS), dim3(1024), 0, st, cnt, keys,           \
+                       (int*)order, Lq, Lp);                                                                     \
+  }
+    if (Lp <= 1024) MVG_BIN2(1)
+    else if (Lp <= 2 * 1024) MVG_BIN2(2)
+    else if (Lp <= 4 * 1024) MVG_BIN2(4)
+    else MVG_BIN2(8)
+#undef MVG_BIN2
+    MVG_LAUNCH_CHECK();
+    return 0;
+  }
 #define MVG_BIN(K)                                                                                               \
-  hipLaunchKernelGGL((bin_pairs_kernel<K>), dim3(N_img), dim3(1024), 0, (hipStream_t)stream, ref_lvl, inside,   \
+  hipLaunchKernelGGL((bin_pairs_kernel<K>), dim3(N_img), dim3(1024), 0, st, ref_lvl, inside,                     \
                      (int*)order, Lq, L, W0, H0, shift)
   if (Lq <= 2 * 1024) MVG_BIN(2);                // few queries per image (a rank's shard of a query-sharded run)
   else if (Lq <= 4 * 1024) MVG_BIN(4);
   else if (Lq <= 8 * 1024) MVG_BIN(8);
   else if (Lq <= 16 * 1024) MVG_BIN(16);
   else if (Lq <= 32 * 1024) MVG_BIN(32);
-  else if (Lq <= 64 * 1024) MVG_BIN(64);
-  else return MVG_E_BADARG;                       // more than 65 536 tokens per image: run the sampler unordered
+  else MVG_BIN(64);
 #undef MVG_BIN
   MVG_LAUNCH_CHECK();
   return 0;

@@ -265,9 +265,13 @@ def bin_pairs(r, inside, levels, out=None):
     if out is None:
         out = torch.empty((n_img * Lq,), dtype=torch.int32, device=r.device)
     order = out
+    lib = L.load()
+    ws_bytes = int(lib.mvg_bin_pairs_workspace(n_img, Lq))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=r.device) if ws_bytes else None     # multi-workgroup variant
     with _timed("bin_pairs"):
-      L.check(L.load().mvg_bin_pairs(L.ptr(r), None if inside is None else L.ptr(inside), levels.shapes_c, levels.L,
-                                     L.ptr(order), n_img, Lq, L.stream_ptr()), "mvg_bin_pairs")
+      L.check(lib.mvg_bin_pairs(L.ptr(r), None if inside is None else L.ptr(inside), levels.shapes_c, levels.L,
+                                L.ptr(order), n_img, Lq, None if ws is None else L.ptr(ws), ws_bytes, L.stream_ptr()),
+              "mvg_bin_pairs")
     return order
 
 

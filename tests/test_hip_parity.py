@@ -1101,3 +1101,41 @@ def test_bf16_fast_path_batch_of_two():
         assert float((one[0][:, 0].float() - hs16[:, b]).abs().max()) < 2e-2          # tile numbering changes the fp32 sum order
         assert float((one[1][:, 0].float() - ref16[:, b]).norm(dim=-1).max()) < 1.0
         assert float((one[2][:, 0].float() - r2d16[:, b]).abs().max()) < 0.1
+
+
+@pytest.mark.parametrize("n_img,Lq", [(3, 8192), (2, 8199), (1, 12345), (5, 15360), (2, 30720), (1, 65536), (4, 8191),
+                                      (3, 1), (2, 2049)])
+def test_bin_pairs_all_variants_against_a_stable_sort(n_img, Lq):
+    """mvg_bin_pairs for sizes on both sides of the single- / multi-workgroup switch (8192 pairs per image), ragged
+    slices, the largest supported image (65 536 tokens): every image's slice of `order` is a permutation of its pairs whose
+    keys (Morton code of the 4x4-cell block, 4096 for masked pairs) are non-decreasing -- the multiset of keys equals the
+    one of a torch sort; both variants agree on it."""
+    from mvgformer_amd import _lib, ops
+    torch.manual_seed(n_img * 100003 + Lq)
+    levels = ops.Levels(torch.tensor([[128, 240], [64, 120], [32, 60]]), torch.tensor([0, 30720, 38400]))
+    ref = torch.rand(n_img, Lq, 3, 2, device=DEV) * 1.3 - 0.15          # also outside [0, 1]: clamped keys
+    ref[:, ::17] = ref[:, :1].clone()                                   # a hot key
+    inside = (torch.rand(n_img, Lq, device=DEV) > 0.35).to(torch.uint8)
+    H0, W0 = 128, 240
+    cx = (ref[..., 0, 0].clamp(0, 1) * W0).to(torch.int64).clamp(0, W0 - 1) >> 2
+    cy = (ref[..., 0, 1].clamp(0, 1) * H0).to(torch.int64).clamp(0, H0 - 1) >> 2
+    key = torch.zeros_like(cx)
+    for bit in range(6):
+        key |= ((cx >> bit) & 1) << (2 * bit) | ((cy >> bit) & 1) << (2 * bit + 1)
+    key = torch.where(inside.bool(), key, torch.full_like(key, 4096))
+    lib = _lib.load()
+    got = {}
+    for multi in (0, 1):
+        lib.mvg_set_tuning(b"bin_multi", multi)
+        try:
+            order = ops.bin_pairs(ref, inside.view(-1), levels).view(n_img, Lq).long()
+        finally:
+            lib.mvg_set_tuning(b"bin_multi", 1)
+        base = torch.arange(n_img, device=DEV).view(-1, 1) * Lq
+        local = order - base
+        assert int(local.min()) >= 0 and int(local.max()) < Lq
+        assert torch.equal(local.sort(dim=1).values, torch.arange(Lq, device=DEV).expand(n_img, Lq))   # permutation
+        k = torch.gather(key, 1, local)
+        assert bool((k[:, 1:] >= k[:, :-1]).all())                                                     # sorted by key
+        got[multi] = k
+    assert torch.equal(got[0], got[1]) and torch.equal(got[1], key.sort(dim=1).values)
