@@ -220,6 +220,12 @@ int mvg_triangulate(const float* r, const float* o, const float* cams, const uin
                     const int* any_valid, float* new_ref, float* ref2d, float* proj2d,
                     int V, int B, int NQ, int J, void* stream);
 
+/* Batched eigen-decomposition of n symmetric 4x4 fp64 matrices G (n,4,4): evals (n,4) in no particular order, evecs
+ * (n,4,4) with the eigenvectors as columns (G v_k = evals_k v_k, v_k = evecs[:, :, k]).  fp64 cyclic Jacobi, one lane
+ * per matrix.  Used by the differentiable DLT of the training path (multiview.py:170-228 under autograd): smallest
+ * eigenvector of A^T A in the forward, all pairs in the backward. */
+int mvg_sym4_eigh(const double* G, double* evals, double* evecs, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

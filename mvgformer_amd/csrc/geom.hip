@@ -682,6 +682,38 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __res
   }
 }
 
+// ---- batched eigen-decomposition of symmetric 4x4 matrices (fp64, cyclic Jacobi as in triangulate_kernel): the
+// differentiable DLT of the training path (geometry_torch.dlt) takes the eigenvector of the smallest eigenvalue of the
+// Gram matrix A^T A and needs all four pairs for its backward (rocSOLVER's batched SVD of the (2V, 4) row matrices was
+// 70 % of a training step).  One lane per matrix; evecs holds the eigenvectors as COLUMNS, evals in no particular order.
+__global__ __launch_bounds__(256) void sym4_eigh_kernel(const double* __restrict__ Gin, double* __restrict__ evals,
+                                                        double* __restrict__ evecs, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  double G[4][4], Vm[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      G[a][c] = 0.5 * (Gin[idx * 16 + a * 4 + c] + Gin[idx * 16 + c * 4 + a]);
+      Vm[a][c] = (a == c) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
+    const double lg = fmax(fmax(fabs(G[0][0]), fabs(G[1][1])), fmax(fabs(G[2][2]), fabs(G[3][3])));
+    if (off <= 2e-16 * lg) break;
+    jacobi_rotate2(G, Vm, 0, 1, 2, 3);
+    jacobi_rotate2(G, Vm, 0, 2, 1, 3);
+    jacobi_rotate2(G, Vm, 0, 3, 1, 2);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    evals[idx * 4 + a] = G[a][a];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) evecs[idx * 16 + a * 4 + c] = Vm[a][c];
+  }
+}
+
 extern "C" {
 
 int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W, int S, int start,
@@ -847,6 +879,14 @@ int mvg_triangulate(const float* r, const float* o, const float* cams, const uin
   if (nprob == 0) return 0;
   hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(nprob, TRI_PROBS)), dim3(512), 0, (hipStream_t)stream, r, o, cams,
                      valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_sym4_eigh(const double* G, double* evals, double* evecs, long n, void* stream) {
+  if (!G || !evals || !evecs || n < 0) return MVG_E_BADARG;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sym4_eigh_kernel, dim3((unsigned)mvg_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, G, evals, evecs, n);
   MVG_LAUNCH_CHECK();
   return 0;
 }

@@ -458,3 +458,17 @@ def pack_cameras(meta, img_size, device):
         rec[v, :, 36], rec[v, :, 37] = dw, dh
         wh_all.append(wh)
     return torch.from_numpy(rec.reshape(V * B, L.CAM_STRIDE)).to(device)
+
+
+def sym4_eigh(G):
+    """eigen-decomposition of symmetric 4x4 matrices G (..., 4, 4) fp64 on the GPU: (evals (..., 4), evecs (..., 4, 4),
+    eigenvectors as columns, no particular order)."""
+    if G.dtype != torch.float64 or G.shape[-2:] != (4, 4):
+        raise RuntimeError("mvg_sym4_eigh: (..., 4, 4) float64 expected")
+    Gc = G.contiguous()
+    n = Gc.numel() // 16
+    w = torch.empty(Gc.shape[:-1], dtype=torch.float64, device=G.device)
+    V = torch.empty_like(Gc)
+    L.check(L.load().mvg_sym4_eigh(L.ptr(Gc), L.ptr(w), L.ptr(V), n, L.stream_ptr()), "mvg_sym4_eigh")
+    return w, V
+

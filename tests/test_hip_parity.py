@@ -1139,3 +1139,46 @@ def test_bin_pairs_all_variants_against_a_stable_sort(n_img, Lq):
         assert bool((k[:, 1:] >= k[:, :-1]).all())                                                     # sorted by key
         got[multi] = k
     assert torch.equal(got[0], got[1]) and torch.equal(got[1], key.sort(dim=1).values)
+
+
+def test_differentiable_dlt_matches_svd_autograd():
+    """geometry_torch.dlt on the GPU (Gram matrix + mvg_sym4_eigh + analytic backward) against torch.linalg.svd and
+    its autograd in fp64 on the CPU (what the reference differentiates through, multiview.py:206): points and the
+    gradients w.r.t. 2D points, confidences and projection matrices."""
+    from mvgformer_amd import geometry_torch as G
+    from mvgformer_amd import ops
+    torch.manual_seed(4)
+    B, V, N = 2, 5, 300
+    K = torch.tensor([[1400.0, 0, 960], [0, 1400.0, 540], [0, 0, 1]], dtype=torch.float64)
+    Pm = []
+    for v in range(V):
+        a = 2 * np.pi * v / V
+        R = torch.tensor([[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]], dtype=torch.float64)
+        C = torch.tensor([4000 * np.sin(a), 200.0 * v, -4000 * np.cos(a)], dtype=torch.float64)
+        Pm.append(K @ torch.cat([R, (-R @ C)[:, None]], 1))
+    Pm = torch.stack(Pm)[None].repeat(B, 1, 1, 1)                                    # (B,V,3,4)
+    X = torch.randn(B, N, 3, dtype=torch.float64) * 500.0
+    Xh = torch.cat([X, torch.ones(B, N, 1, dtype=torch.float64)], -1)
+    uvw = torch.einsum("bvij,bnj->bvni", Pm, Xh)
+    pts = uvw[..., :2] / uvw[..., 2:3] + torch.randn(B, V, N, 2, dtype=torch.float64) * 2.0   # noisy observations
+    conf = torch.softmax(torch.randn(B, V, N, dtype=torch.float64), 1)
+    wgt = torch.randn(B, N, 3, dtype=torch.float64)
+    res = {}
+    for dev in ("cpu", DEV):
+        leaves = [t.clone().to(dev).requires_grad_(True) for t in (Pm, pts, conf)]
+        out = G.dlt(*leaves)
+        (out * wgt.to(dev)).sum().backward()
+        res[dev] = [out.detach().cpu()] + [l.grad.cpu() for l in leaves]
+    names = ("X", "dL/dP", "dL/dpts", "dL/dconf")
+    for nm, a, b in zip(names, res["cpu"], res[DEV]):
+        err = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
+        print("dlt %-8s rel err %.2e" % (nm, err))
+        assert err < 1e-6, nm
+    assert float((res[DEV][0] - X).norm(dim=-1).max()) < 60.0                     # sanity: near the true points (mm)
+    # the eigen-solver itself
+    A = torch.randn(1000, 4, 4, dtype=torch.float64, device=DEV)
+    S = A @ A.transpose(-1, -2)
+    w, Vv = ops.sym4_eigh(S)
+    assert float((S @ Vv - Vv * w[:, None, :]).abs().max()) < 1e-12 * float(S.abs().max())
+    assert float((Vv.transpose(-1, -2) @ Vv - torch.eye(4, dtype=torch.float64, device=DEV)).abs().max()) < 1e-13
+    assert torch.allclose(w.sort(-1).values, torch.linalg.eigvalsh(S.cpu()).to(DEV), rtol=1e-12, atol=1e-12 * float(S.abs().max()))
