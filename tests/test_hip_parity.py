@@ -435,7 +435,8 @@ def test_decoder_layer_training_path_matches_inference_and_backprops():
     assert float((out[3] - inf[3]).abs().max()) < 2e-3 and float((out[2] - inf[2]).abs().max()) < 2e-3
     err3d = float((out[1] - inf[1]).norm(dim=-1).max().detach())
     print("training-path 3D vs inference-path: %.3f mm" % err3d)
-    assert err3d < 3.0          # rocSOLVER fp32 SVD vs fp64 normal equations of the same fp32 rows (mm, 4 m scene)
+    assert err3d < 0.05         # both paths: smallest eigenvector of the fp64 Gram matrix of their fp32 rows (mm, 4 m scene;
+                                # 0.001 measured -- it was 1-3 mm while the training path went through rocSOLVER's fp32 SVD)
     loss = out[0].square().mean() + 1e-6 * out[1].square().mean() + out[4].sum() + 1e-4 * out[2].square().mean()
     loss.backward()
     assert tgt.grad is not None and torch.isfinite(tgt.grad).all() and float(tgt.grad.abs().max()) > 0
