@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--queries", type=int, default=None,
                     help="override the configuration's query count (diagnostics: --queries 128 is the per-rank workload "
                          "of the 8-GPU query-sharded run; the metric name then no longer applies)")
+    ap.add_argument("--speculative", type=int, default=1,
+                    help="query-sharded runs: 1 = the whole forward as one graph, assuming every layer has a valid query "
+                         "somewhere, verified after the forward and redone exactly on a miss (dist.SpeculativeShardedDecoder); "
+                         "0 = graph segments with a MAX all-reduce of the flag between the layers")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
@@ -157,7 +161,8 @@ def main():
                 layer._any_valid_hook = None
             ok = 1
             try:
-                graph = mdist.GraphedShardedDecoder(dec, tgt, ref, src_views, qpos, ctx, thr, NQ)
+                runner_cls = mdist.SpeculativeShardedDecoder if args.speculative else mdist.GraphedShardedDecoder
+                graph = runner_cls(dec, tgt, ref, src_views, qpos, ctx, thr, NQ)
             except Exception as e:   # keep the job alive: every rank falls back to the eager sharded forward
                 print("# rank %d: segmented graph capture failed (%s: %s)" % (rank, type(e).__name__, e), file=sys.stderr)
                 ok, graph = 0, None
@@ -334,7 +339,9 @@ def main():
                    if args.valid_fraction is None else
                    "%s: %d views, %d queries x %d joints, %d layers, ~%.0f%% queries valid"
                    % (args.config, V, NQ, J, Ly, 100 * args.valid_fraction),
-                   "parallelism": ("queries sharded x%d + all-gather" % world if sharded else
+                   "parallelism": ("queries sharded x%d + all-gather%s" % (world, " (one graph, speculative any-valid flag)"
+                                                                            if (args.speculative and graph is not None) else "")
+                                   if sharded else
                                    "one sample per GPU x%d + all-gather of the pose sets" % world if replicas else "single GPU"),
                    "pyramid_handoff": {"nchw": "NCHW fp32 (reference producer format), packed per step",
                                        "nhwc": "channels-last %s, copied per step" % args.dtype,

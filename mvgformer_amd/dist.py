@@ -222,3 +222,76 @@ class GraphedShardedDecoder:
         dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         self.graphs[-1].replay()
         return self.out
+
+
+class SpeculativeShardedDecoder:
+    """The query-sharded forward as ONE HIP graph and two collectives per sample.
+
+    The only reason the segmented runner talks between the layers is the reference's "no query valid anywhere -> force
+    query (0,0)" rule (dq_decoder.py:620-623), a 4-byte MAX all-reduce per layer that is true ("some query is valid")
+    in every layer of every sample a trained model sees.  This runner assumes it: every rank runs all layers with the
+    flag set, keeping its LOCAL flags; a MAX all-reduce of the Ly local flags rides with the final all-gather, and only
+    if some layer turns out to have had no valid query on any rank is the sample redone by the exact segmented runner
+    (same static inputs).  Results are identical in both cases; the common case saves Ly collectives, Ly graph
+    launches and Ly points where all ranks wait for the slowest one."""
+
+    def __init__(self, decoder, tgt, reference_points, src_views, query_pos, ctx, threshold, NQ, group=None,
+                 gather_hidden=False):
+        self.exact = GraphedShardedDecoder(decoder, tgt, reference_points, src_views, query_pos, ctx, threshold, NQ,
+                                           group=group, gather_hidden=gather_hidden)
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        dec, layers = decoder, list(decoder.layers)
+        J = layers[0].num_joints
+        self.flags = torch.zeros((len(layers),), dtype=torch.int32, device=tgt.device)
+        self.fallbacks = 0
+        fuse = getattr(dec, "fuse_next_query_term", False)
+        ref = reference_points if reference_points.dim() == 4 else reference_points[:, :, None]
+
+        def body():
+            for l, layer in enumerate(layers):
+                layer._next_layer = (layers[l + 1],) if (fuse and l + 1 < len(layers)) else None
+                layer._xw_in = None
+            side = dec.fork_side_stream(tgt.device) if hasattr(dec, "fork_side_stream") else None
+            ctx.pack(src_views)
+            if side is not None:
+                dec.launch_pyramid_projections(ctx, side)
+            outs = []
+            st = layers[0].forward_features(tgt, query_pos, ref, ctx, threshold)
+            for l, layer in enumerate(layers):
+                self.flags[l:l + 1].copy_(st["any_valid"])          # this rank's own answer, checked after the forward
+                st["any_valid"].fill_(1)                            # the speculation: somebody has a valid query
+                o = layer.forward_triangulate(st, ctx)
+                outs.append(o)
+                if l + 1 < len(layers):
+                    st = layers[l + 1].forward_features(o[0], query_pos, o[1][:, :, None], ctx, threshold)
+            if side is not None:
+                dec.join_pyramid_projections(side)
+            tup = (torch.stack([x[0] for x in outs]), torch.stack([x[1] for x in outs]), torch.stack([x[2] for x in outs]),
+                   torch.stack([x[3] for x in outs]), [x[4] for x in outs])
+            return pack_outputs(tup, NQ, J, self.world, self.rank, gather_hidden)
+
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, pool=self.exact.graphs[0].pool()):
+                self.send, self.geo = body()
+        finally:
+            for layer in layers:
+                layer._next_layer = None
+                layer._xw_in = None
+                layer.proj_attn._vp_event = None
+        self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
+        self.unpack = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.unpack, pool=self.exact.graphs[0].pool()):
+            self.out = unpack_outputs(self.recv, self.geo)
+
+    def replay(self):
+        self.graph.replay()
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        dist.all_reduce(self.flags, op=dist.ReduceOp.MAX, group=self.group)
+        if int(self.flags.min()) == 0:          # some layer had no valid query on any rank: redo the sample exactly
+            self.fallbacks += 1
+            return self.exact.replay()
+        self.unpack.replay()
+        return self.out
+

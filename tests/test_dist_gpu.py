@@ -47,8 +47,16 @@ def _worker(rank, world, port, cname, q, bf16=False):
             t, p, r, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, 15, world, rank)
             runner = mdist.GraphedShardedDecoder(dec, t, r, g.src_views, p, ctx, thr, case.NQ, gather_hidden=True)
             runner.replay()
-            graphed = runner.replay()
+            graphed = [t.clone() if torch.is_tensor(t) else [c.clone() for c in t] for t in runner.replay()]
+            spec = mdist.SpeculativeShardedDecoder(dec, t, r, g.src_views, p, ctx, thr, case.NQ, gather_hidden=True)
+            spec.replay()
+            speculative = [t.clone() if torch.is_tensor(t) else [c.clone() for c in t] for t in spec.replay()]
             torch.cuda.synchronize()
+            # one graph + verification: identical to the segmented runner; the sample with a layer without any valid
+            # query (mini5_empty) must have been redone by the exact runner, the other one must not
+            same = all(torch.equal(a, b) for a, b in zip(speculative[:4], graphed[:4]))
+            same = same and all(torch.equal(a, b) for a, b in zip(speculative[4], graphed[4]))
+            spec_ok = same and (spec.fallbacks == 2) == (cname == "mini5_empty") and spec.fallbacks in (0, 2)
         ok = True
         if not bf16:
             for got in (eager, graphed):
@@ -64,7 +72,7 @@ def _worker(rank, world, port, cname, q, bf16=False):
             ok = ok and float((eager[2] - full[2]).abs().max()) < 5e-2
             ok = ok and bool(torch.equal(eager[1].abs().sum(-1) > 0, full[1].abs().sum(-1) > 0))
         nvalid = [int((c[..., 1] > thr).sum()) for c in full[4]]
-        q.put((rank, bool(ok), nvalid))
+        q.put((rank, bool(ok and spec_ok), nvalid))
     finally:
         dist.destroy_process_group()
 
