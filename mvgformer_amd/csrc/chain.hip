@@ -406,7 +406,7 @@ __device__ __forceinline__ void acc_to_x(char* __restrict__ xb, const f32x16 (&a
     }
 }
 
-template <int BRING, int NT, int JN>
+template <int BRING, int NT, int JN, int RMT = 64>   // RMT rows per tile: 64 (4 persons of 15 joints) | 32 (2 persons: small launches)
 __global__ __launch_bounds__(NT) void chain_b_kernel(
     const bf16_t* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu,
     const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
@@ -416,13 +416,14 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
     const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
     float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
-  constexpr int RM = 64;
+  constexpr int RM = RMT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                       // RM x 256 bf16 : GEMM operand (mean, then t1)
   char* hbuf = smem + RM * ACT_PITCH;     // RM x 256 bf16 : FFN hidden chunk
   char* xb = hbuf + RM * ACT_PITCH;       // RM x 256 fp32 : pre-LN sums / t1 / tgt'
   float* pr = reinterpret_cast<float*>(xb + RM * XP);   // RM x 2 per-row class probabilities
-  constexpr int MT = (JN == 1) ? 2 : 2 / (NT / 256), NW = NT / 64;   // JN = 1: every wave covers both row blocks
+  constexpr int MT = (JN == 1) ? RM / 32 : (RM / 32) / (NT / 256), NW = NT / 64;   // JN = 1: every wave covers all row blocks
+  static_assert(MT >= 1, "tile too small for this wave mapping");
   static_assert(JN == 2 || NT == 512, "column-split mapping needs 8 wavefronts");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qpt = RM / J;                                // queries per tile (4 for J = 15)
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   // part = lane&7) holds the 8 channel quads part, part+8, ..., part+56 of row  wave*8 + g (+ 8*NW per pass), so a
   // row statistic is a 32-value local sum + a 3-step DPP reduction, and no loop over rows serialises memory or
   // cross-lane latencies.  tgt is fetched here, long before its use.
-  constexpr int RPASS = RM / (8 * NW);                  // 1 with 8 wavefronts, 2 with 4
+  constexpr int RPASS = (RM + 8 * NW - 1) / (8 * NW);   // 1 with 8 wavefronts, 2 with 4; RM = 32: wavefronts 4..7 have no rows
   const int rgrp = lane >> 3, part = lane & 7;
   f32x4 tg[RPASS][8];
 #pragma unroll
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < RPASS; ++ps) {
+    if (ps * 8 * NW + wave * 8 >= RM) continue;        // wavefront without rows (RM = 32)
     const int row = ps * 8 * NW + wave * 8 + rgrp;
     f32x4 v[8];
     float sm = 0.f;
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   // ---- tgt' = LN3(x) (or t1 when the FFN is off) ; class head per row (dq_decoder.py:889-893)
 #pragma unroll
   for (int ps = 0; ps < RPASS; ++ps) {
+    if (ps * 8 * NW + wave * 8 >= RM) continue;
     const int row = ps * 8 * NW + wave * 8 + rgrp;
     f32x4 y[8];
     float sm = 0.f;
@@ -664,6 +667,7 @@ int g_chain_ring = 4;     // tuning knob "chain_ring": weight prefetch depth (k-
 int g_chain_split = 1;    // tuning knob "chain_split": 1 = column-split wave mapping of chain B (JN = 1), 0 = row-block split
 int g_chain_waves = 8;    // tuning knob "chain_waves": wavefronts per workgroup of chain B (4 | 8); measured 86 -> 69 us
 int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 measured slower: 93 vs 79 us)
+int g_auto_small_b = 1;   // tuning knob "auto_small_b": chain B with 32-row tiles when that still leaves <= 128 64-row tiles
 int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128); 128: 65 -> 55 us (half the
                        // weight bytes per row through the L1 miss path, the resource that bounds these kernels)
 
@@ -720,30 +724,38 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
   if (W_next && (!b_next || !xw_next || n_next <= 0 || n_next > 256 || n_next % 4 != 0)) return MVG_E_BADARG;
   const int nq_total = B * NQ, rows = nq_total * J;
   if (rows == 0) return 0;
-  const int qpt = 64 / J;
-  const size_t lds = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float);
+  // few rows (a rank's shard of a query-sharded run): 32-row tiles (2 persons) fill twice as many CUs
+  const bool small = g_auto_small_b && g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 4 && J <= 16 &&
+                     (nq_total + (64 / J) - 1) / (64 / J) <= 128;
+  const int RMr = small ? 32 : 64;
+  const int qpt = RMr / J;
+  const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float);
   static bool configured = false;
+  const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float);
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 2>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<8, 512, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<16, 512, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1, 32>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
   const dim3 grid((nq_total + qpt - 1) / qpt);
-#define MVG_CB(R, NTH, JNN)                                                                                                \
-  hipLaunchKernelGGL((chain_b_kernel<R, NTH, JNN>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
+#define MVG_CB(R, NTH, JNN, ...)                                                                                           \
+  hipLaunchKernelGGL((chain_b_kernel<R, NTH, JNN, ##__VA_ARGS__>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
                      (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc,     \
                      threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next,  \
                      n_next, rows, J, nq_total, has_ffn)
-  if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 16) MVG_CB(16, 512, 1);
+  if (small) MVG_CB(4, 512, 1, 32);
+  else if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 16) MVG_CB(16, 512, 1);
   else if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 8) MVG_CB(8, 512, 1);
   else if (g_chain_waves == 8 && g_chain_split == 1) MVG_CB(4, 512, 1);
   else if (g_chain_waves == 8) MVG_CB(4, 512, 2);

@@ -792,6 +792,7 @@ extern int g_chain_a_waves;
 extern int g_chain_split;
 extern int g_chain_ring;
 extern int g_wreg_grid;
+extern int g_auto_small_b;
 extern int g_bin_multi;
 
 int mvg_set_tuning(const char* key, int value) {
@@ -805,6 +806,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
   if (!strcmp(key, "bin_multi") && (value == 0 || value == 1)) { g_bin_multi = value; return 0; }
   if (!strcmp(key, "auto_small") && (value == 0 || value == 1)) { g_auto_small = value; return 0; }
+  if (!strcmp(key, "auto_small_b") && (value == 0 || value == 1)) { g_auto_small_b = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
