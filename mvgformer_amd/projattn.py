@@ -81,7 +81,7 @@ class ProjAttn(nn.Module):
         self._reset_parameters()
         self.projattn_posembed_mode = projattn_posembed_mode
         self.compute_dtype = torch.float32
-        # bf16 inference: weight-stationary pyramid GEMMs + pixel-pair value layout + G-sampling kernel
+        # bf16 inference: weight-stationary pyramid GEMMs + head-plane value layout + G-sampling kernel
         # (False: the generic gather -> linear -> fused-sampling kernels, also the fp32 path)
         self.use_fast_path = True
         # bf16 fast path: sample the pairs in image-space (Morton) order.  "layer"/True: binned per layer; "first":
@@ -127,7 +127,7 @@ class ProjAttn(nn.Module):
                 wc.get("Wp", (self.output_proj.weight,), dtype),
                 wc.get("bp", (self.output_proj.bias,), torch.float32))
 
-    def _pair_buffer(self, n_img, S, device):
+    def _plane_buffer(self, n_img, S, device):
         """value planes buffer (every line is fully rewritten by each projection); kept across calls."""
         shape = (n_img, 8, S, 32)
         if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
@@ -175,7 +175,7 @@ class ProjAttn(nn.Module):
         n_img, S, _ = feat.shape
         bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
         Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
-        vp = self._pair_buffer(n_img, S, feat.device)
+        vp = self._plane_buffer(n_img, S, feat.device)
         ops.value_proj_planes_ws(feat, Wv_f, bv, vp)
         return vp
 
