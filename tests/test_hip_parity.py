@@ -1183,3 +1183,45 @@ def test_differentiable_dlt_matches_svd_autograd():
     assert float((S @ Vv - Vv * w[:, None, :]).abs().max()) < 1e-12 * float(S.abs().max())
     assert float((Vv.transpose(-1, -2) @ Vv - torch.eye(4, dtype=torch.float64, device=DEV)).abs().max()) < 1e-13
     assert torch.allclose(w.sort(-1).values, torch.linalg.eigvalsh(S.cpu()).to(DEV), rtol=1e-12, atol=1e-12 * float(S.abs().max()))
+
+
+_KNOBS = [("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
+          ("gsamp_map", 8, True), ("bin_multi", 0, True), ("auto_small", 0, True), ("wreg_grid", 256, True),
+          ("wreg_grid", 64, True), ("auto_small_b", 0, False), ("chain_rm", 64, False), ("chain_rm", 256, False),
+          ("chain_a_waves", 8, False), ("chain_waves", 4, False), ("chain_split", 0, False), ("chain_ring", 8, False),
+          ("chain_ring", 16, False)]
+_KNOB_DEFAULTS = dict(gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, chain_rm=128,
+                      chain_a_waves=4, chain_waves=8, chain_split=1, chain_ring=4)
+
+
+@pytest.mark.parametrize("key,value,exact", _KNOBS, ids=["%s=%d" % (k, v) for k, v, _ in _KNOBS])
+def test_every_kernel_variant_behind_a_tuning_knob(key, value, exact):
+    """mvg_set_tuning selects kernel variants that the default configuration never runs (other workgroup sizes, block
+    mappings, tile sizes, wave mappings): each of them must still compute the decoder -- bit-identical where the knob only
+    changes WHERE an item is computed (sampler / binning / GEMM grid), to bf16 rounding where it changes the order of an
+    fp32 sum (chain variants).  12 000-row case: large enough for the multi-workgroup binning and the big-tile chains."""
+    from mvgformer_amd import _lib
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    lib = _lib.load()
+    case = build_case("cfg2", seed=11, NQ=160, layers=2)            # Lq = 2400 per image, 12 000 pairs
+    dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
+    gc = case_to_device(case, DEV)
+    run = lambda: [t.float().clone() for t in dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes,
+                                                  gc.level_start_index, None, query_pos=gc.query_pos, threshold=0.1)[:4]]
+    with torch.no_grad():
+        ref = run()
+        assert lib.mvg_set_tuning(key.encode(), value) == 0
+        try:
+            got = run()
+        finally:
+            assert lib.mvg_set_tuning(key.encode(), _KNOB_DEFAULTS[key]) == 0
+        again = run()
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)                                     # the knob was restored
+    if exact:
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), key
+    else:
+        assert float((got[0] - ref[0]).abs().max()) < 4e-2
+        assert float((got[1] - ref[1]).norm(dim=-1).max()) < 6.0 and float((got[2] - ref[2]).abs().max()) < 0.5     # the bf16 bars of section 5
+    assert lib.mvg_set_tuning(b"no_such_knob", 1) != 0 and lib.mvg_set_tuning(key.encode(), -7) != 0
