@@ -92,6 +92,8 @@ def dlt(Pm, pts, conf):
         Ad = A.double()
         Xh = SmallestEigvec4.apply(Ad.transpose(-1, -2) @ Ad).to(A.dtype)
     else:
+        # host tensors: plain torch reference of the same quantity (used by the gradient-parity test as the thing to
+        # compare with; DQDecoderLayer never gets here -- it raises "Not implemented on the CPU" like the reference op)
         _, _, Vh = torch.linalg.svd(A)
         Xh = -Vh[..., 3, :]
     return Xh[..., :3] / Xh[..., 3:4]
