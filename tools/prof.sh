@@ -15,7 +15,9 @@ rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv --
 for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
             "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
-            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_EA0_WRREQ_sum"; do
+            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_EA0_WRREQ_sum" \
+            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA" \
+            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"; do
   N=$(echo $PASS | cut -d' ' -f1)
   rocprofv3 --pmc $PASS --kernel-trace -d "$OUT/pmc_$N" -o pmc --output-format csv -- python $ROOT/bench.py $ARGS > "$OUT/pmc_$N.log" 2>&1
 done

@@ -38,6 +38,26 @@ for k in sorted(acc, key=lambda k: -sum(acc[k].get("GRBM_GUI_ACTIVE", [0]))):
         v = acc[k][c]
         print("    %-34s %16.1f  (n=%d)" % (c, sum(v) / len(v), len(v)))
 
+# ---- MFMA kernels: achieved matrix throughput (counted MFMA ops x 512 FLOP / kernel-trace duration) against the
+# dense bf16 peak, LDS bank-conflict share
+dur = {}
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Name"])] = float(r["AverageNs"]) * 1e-9
+print("\n== MFMA kernels (per launch)")
+print("%-44s %9s %12s %10s %12s" % ("kernel", "avg_us", "MFMA TFLOP/s", "% 2.5 PF", "LDS confl %"))
+for k in sorted(acc, key=lambda k: -dur.get(k, 0)):
+    c = acc[k]
+    if "SQ_INSTS_VALU_MFMA_MOPS_BF16" not in c or k not in dur:
+        continue
+    mean = lambda n: sum(c[n]) / len(c[n]) if n in c and c[n] else float("nan")
+    mops = mean("SQ_INSTS_VALU_MFMA_MOPS_BF16")
+    if not mops > 0:
+        continue
+    tf = mops * 512.0 / dur[k] / 1e12
+    confl = 100.0 * mean("SQ_LDS_BANK_CONFLICT") / max(mean("SQ_LDS_IDX_ACTIVE"), 1.0)      # share of the LDS-active cycles
+    print("%-44s %9.2f %12.1f %10.1f %12.1f" % (k[:44], dur[k] * 1e6, tf, 100.0 * tf / 2500.0, confl))
+
 # ---- machine-readable HBM-side traffic of the dominant kernel (read by bench.py -> roofline.traffic)
 import json
 for k in acc:
