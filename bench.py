@@ -37,6 +37,73 @@ def algorithmic_bytes_per_view_layer(S, C, Lq, M, L, P, elem):
     return S * C * elem + Lq * M * L * P * 2 * elem + Lq * M * L * P * elem + Lq * C * elem
 
 
+SAMPLER_SOURCES = ("mvgformer_amd/csrc/msda.hip", "mvgformer_amd/csrc/common.h")
+
+
+def sampler_source_hash():
+    """sha256 over the sources of the sampling kernel: a committed PMC figure is only quoted for the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in SAMPLER_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measure_traffic_live(argv_tail, kernel_prefix):
+    """HBM-side bytes per launch of the sampling kernel, measured NOW: two rocprofv3 --pmc child passes over a few eager
+    forwards of this very configuration (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, "rocprofv3 PMC
+    slots"), FETCH_SIZE doubled per the guide's gfx950 correction.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="mvg_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "1"] + argv_tail
+            env = dict(os.environ, TMPDIR="/tmp", MVG_OVERLAP_PYRAMID="0")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            got = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"]:
+                            got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, "no %s samples for %s (rc %d: %s)" % (counter, kernel_prefix, p.returncode, p.stderr[-300:])
+            vals[counter] = sum(got) / len(got)
+        except Exception as e:      # profiler trouble must never cost the bench line
+            return None, "%s pass failed: %s: %s" % (counter, type(e).__name__, e)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return int(total), {"FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
+                        "fetch_correction": 2.0}
+
+
+def self_launch(n):
+    """Re-run this command line as n ranks under torch.distributed.run (one process per GPU); returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,28 +137,43 @@ def main():
                     help="query-sharded runs: 1 = the whole forward as one graph, assuming every layer has a valid query "
                          "somewhere, verified after the forward and redone exactly on a miss (dist.SpeculativeShardedDecoder); "
                          "0 = graph segments with a MAX all-reduce of the flag between the layers")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "cached", "off"],
+                    help="roofline.traffic (HBM bytes per launch of the sampling kernel from the PMC counters): cached = the "
+                         "committed profiles/*_pmc_msda.json, only if it was measured on these kernel sources (hash) and this "
+                         "configuration; live = two rocprofv3 --pmc child passes of this command now; auto = cached if "
+                         "valid, else live; off = null")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1),
+        # exactly the way the driver's torch.distributed.run command does; rank 0's JSON line passes through
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
-    ndev = torch.cuda.device_count()
-    torch.cuda.set_device(local_rank % ndev)
-    dev = torch.device("cuda", local_rank % ndev)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or plainly, "
+                         "without RANK/WORLD_SIZE in the environment)" % (args.gpus, world, args.gpus))
+    have_gpu = torch.cuda.is_available()
+    dev = None
+    if have_gpu:
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
+        # bring-up as lib/models/util/misc.py:504-543 (init_process_group('nccl') from RANK / WORLD_SIZE / LOCAL_RANK)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MVG_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm; gloo only for plumbing tests
-        if backend == "nccl":
+        if backend == "nccl" and have_gpu:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        print("# rank %d/%d: process group up (%s)" % (rank, world, dist.get_backend()), file=sys.stderr, flush=True)
+    if not have_gpu:
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
 
     from mvgformer_amd import _lib, ops
     from mvgformer_amd import dist as mdist
@@ -155,6 +237,11 @@ def main():
         for _ in range(3):
             out = forward()
         torch.cuda.synchronize()
+        if args.pmc_child:      # counter-collection child of measure_traffic_live: eager forwards only
+            for _ in range(3):
+                forward()
+            torch.cuda.synchronize()
+            return
         if use_graph and sharded:
             # segments between the collectives are graphs, the RCCL calls stay eager (mvgformer_amd.dist)
             for layer in dec.layers:
@@ -283,24 +370,55 @@ def main():
     S = int(sum(h * w for h, w in case.shapes))
     bytes_launch = V * algorithmic_bytes_per_view_layer(S, 256, Lq_loc, 8, len(case.shapes), 8, elem)
     roof = None
-    # HBM-side bytes of the same kernel from the rocprofv3 PMC passes (tools/prof.sh of this command; FETCH_SIZE
-    # x2 per the gfx950 correction + WRITE_SIZE), committed under profiles/ -- only valid for the profiled config
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_msda.json")
-    if (os.path.exists(pmc_path) and args.config in ("cfg2", "cfg3") and args.dtype == "bf16" and world == 1
-            and args.valid_fraction is None):
-        with open(pmc_path) as f:
-            traffic = int(json.load(f)["traffic_bytes_per_launch"])
+    # HBM-side bytes of the same kernel from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  Either
+    # measured by this run (two rocprofv3 child passes of the same command) or the committed figure of tools/prof.sh --
+    # quoted only for the kernel sources (hash) and configuration it was measured on; the line says which.
+    traffic, traffic_source = None, None
+    samp_name = "msda_gsamp_kernel" if dtype == torch.bfloat16 else "msda_fused_kernel"
+    if world == 1 and args.traffic != "off" and args.inflight == 1:
+        src_hash = sampler_source_hash()
+        want = {"config": args.config, "dtype": args.dtype, "queries": NQ, "valid_fraction": args.valid_fraction,
+                "src_sha256": src_hash}
+        import glob
+        if args.traffic in ("auto", "cached"):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_msda.json")), reverse=True):
+                with open(path) as f:
+                    rec = json.load(f)
+                if all(rec.get(k) == v for k, v in want.items()):
+                    traffic = int(rec["traffic_bytes_per_launch"])
+                    traffic_source = "%s (tools/prof.sh, sources %s)" % (os.path.relpath(path, ROOT), src_hash)
+                    break
+        if traffic is None and args.traffic in ("auto", "live"):
+            tail = ["--config", args.config, "--dtype", args.dtype, "--producer", args.producer, "--cpu-baseline", "0"]
+            if args.queries is not None:
+                tail += ["--queries", str(args.queries)]
+            if args.valid_fraction is not None:
+                tail += ["--valid-fraction", str(args.valid_fraction)]
+            traffic, detail = measure_traffic_live(tail, samp_name)
+            traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, %s" % json.dumps(detail)
+                              if traffic is not None else "unavailable: %s" % detail)
+        elif traffic is None:
+            traffic_source = "no committed PMC profile for these kernel sources (%s) and this configuration" % src_hash
     samp_key = "msda_gsamp" if "msda_gsamp" in prof else "msda_fused"     # bf16 fast path / generic fused kernel
     if samp_key in prof:
         n, ms = prof[samp_key]
         ach = bytes_launch / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": samp_key + "_kernel", "achieved": round(ach, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
                 "fused_minimum_bytes_per_launch": V * (S * 256 + Lq_loc * 256) * elem}
     kern = {k: {"launches": n, "avg_us": round(ms * 1e3, 2)} for k, (n, ms) in sorted(prof.items())}
+    # per-rank time split (kernel time per forward from the eager profile pass, each kernel alone): "fixed" = work that does
+    # not shrink when the queries are sharded (pyramid packing + the query-independent pyramid GEMMs, replicated on every
+    # rank), "variable" = everything proportional to this rank's queries
+    split = None
+    if prof and args.profile_steps > 0:
+        fixed_keys = ("pack_level", "pack_level_nhwc", "value_proj_ws", "feat_linear_ws", "pyramid_all_layers")
+        fx = sum(n * ms for k, (n, ms) in prof.items() if k in fixed_keys) / args.profile_steps
+        var = sum(n * ms for k, (n, ms) in prof.items() if k not in fixed_keys) / args.profile_steps
+        split = {"fixed_us": round(fx * 1e3, 1), "variable_us": round(var * 1e3, 1),
+                 "note": "rank 0, kernels timed one at a time; fixed = replicated query-independent work"}
 
     cpu = None
     if cpu_case is not None:
@@ -348,7 +466,7 @@ def main():
                                        "inplace": "produced in the packed layout (no per-step pack)"}[args.producer],
                    "samples_in_flight": args.inflight,
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kern,
+        "roofline": roof, "cpu_baseline": cpu, "rank_time_split": split, "kernels": kern,
     }
     print(json.dumps(line))
     if world > 1:

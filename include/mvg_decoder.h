@@ -80,6 +80,18 @@ int mvg_msda_forward_bf16(const void* value, const int64_t* spatial_shapes,
                           const int64_t* level_start_index, const float* sampling_loc,
                           const float* attn_weight, void* out,
                           int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+/* f64: every tensor float64 -- the `double` case of AT_DISPATCH_FLOATING_TYPES (deform_cuda.cu:75,145), for gradcheck-style
+ * calls; plain one-thread-per-output-channel kernels, no fast path.  mvg_msda_backward_f64: grad_value must be zero-filled
+ * by the caller like the f32 form; grad_sampling_loc / grad_attn_weight are zeroed and accumulated by the entry point. */
+int mvg_msda_forward_f64(const double* value, const int64_t* spatial_shapes,
+                         const int64_t* level_start_index, const double* sampling_loc,
+                         const double* attn_weight, double* out,
+                         int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+int mvg_msda_backward_f64(const double* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const double* sampling_loc,
+                          const double* attn_weight, const double* grad_output,
+                          double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
+                          int N, int S, int M, int D, int L, int Lq, int P, void* stream);
 /* grad_value (N,S,M,D) must be zero-filled by the caller (at::zeros_like, deform_cuda.cu:132);
  * grad_sampling_loc / grad_attn_weight are fully overwritten.  Deterministic for a fixed
  * launch geometry only up to the atomic-add order in grad_value (as the reference, cuh:135-162). */

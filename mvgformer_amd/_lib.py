@@ -25,6 +25,8 @@ SIGNATURES = {
     "mvg_msda_forward_f32": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_forward_bf16": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_backward_f32": [_vp] * 9 + [_i] * 7 + [_vp],
+    "mvg_msda_forward_f64": [_vp] * 6 + [_i] * 7 + [_vp],
+    "mvg_msda_backward_f64": [_vp] * 9 + [_i] * 7 + [_vp],
     "mvg_pack_level": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvg_project": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_gather_ref": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -103,6 +105,12 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             # same message as the reference's CPU stub (lib/models/ops/src/deform.h:49)
             raise RuntimeError("Not implemented on the CPU")
+        if t is not None and t.device.index != torch.cuda.current_device():
+            # stream_ptr() hands the kernels the CURRENT device's stream: launching on another device's tensors
+            # would run on the wrong GPU.  The module entry points (DQDecoder / DQDecoderLayer / ProjAttn / deformable)
+            # switch to their tensors' device themselves; a direct ops.* caller has to.
+            raise MvgError("tensor on %s but the current device is cuda:%d -- wrap the call in "
+                           "torch.cuda.device(tensor.device)" % (t.device, torch.cuda.current_device()))
 
 
 def device_info():

@@ -676,12 +676,15 @@ static int launch_chain_a(const void* samp, const uint8_t* inside, const void* W
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
                           float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
   const size_t lds = RM * ACT_PITCH + RM * sizeof(int) + 768 * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
+  // the attribute is per DEVICE: a process that drives several GPUs configures the > 64-KB LDS kernels on each of them
+  static bool configured[MVG_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
+  if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT, JN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    configured = true;
+    configured[dev] = true;
   }
   hipLaunchKernelGGL((chain_a_kernel<RM, NT, JN>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
                      (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, order,
@@ -730,9 +733,11 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
   const int RMr = small ? 32 : 64;
   const int qpt = RMr / J;
   const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float);
-  static bool configured = false;
+  static bool configured[MVG_MAX_DEVICES] = {};   // per device, see launch_chain_a
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
   const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float);
-  if (!configured) {
+  if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 2>),
@@ -746,7 +751,7 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1, 32>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e != hipSuccess) return (int)e;
-    configured = true;
+    configured[dev] = true;
   }
   const dim3 grid((nq_total + qpt - 1) / qpt);
 #define MVG_CB(R, NTH, JNN, ...)                                                                                           \

@@ -6,6 +6,7 @@
 #include "../../include/mvg_decoder.h"
 
 #define MVG_WAVE 64
+#define MVG_MAX_DEVICES 64   // per-device one-time kernel configuration flags
 
 typedef unsigned short bf16_t;  // raw bf16 bits
 

@@ -116,6 +116,106 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   }
 }
 
+// fp64 drop-in (the `double` case of AT_DISPATCH_FLOATING_TYPES, deform_cuda.cu:75: gradcheck-style calls): one thread
+// per (n, q, m, channel), everything in double.  No fast path -- nothing on the decoder's inference path is fp64.
+__global__ __launch_bounds__(256) void msda_fwd_f64_kernel(
+    const double* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+    const double* __restrict__ loc, const double* __restrict__ wgt, double* __restrict__ out,
+    int N, int S, int M, int D, int L, int Lq, int P) {
+  const long total = (long)N * Lq * M * D;
+  const long row_stride = (long)M * D;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % D);
+    long t = idx / D;
+    const int m = (int)(t % M);
+    t /= M;
+    const int q = (int)(t % Lq);
+    const int n = (int)(t / Lq);
+    const long qm = ((long)n * Lq + q) * M + m;
+    const double* vb = value + (long)n * S * row_stride + (long)m * D + c;
+    double acc = 0.0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const double* lvl = vb + (long)starts[l] * row_stride;
+      for (int p = 0; p < P; ++p) {
+        const long sidx = qm * L * P + l * P + p;
+        const double h_im = loc[sidx * 2 + 1] * (double)H - 0.5, w_im = loc[sidx * 2] * (double)W - 0.5;   // cuh:295-296
+        if (!(h_im > -1.0 && w_im > -1.0 && h_im < (double)H && w_im < (double)W)) continue;              // cuh:298 (also NaN)
+        const double hl_f = floor(h_im), wl_f = floor(w_im);
+        const int h_low = (int)hl_f, w_low = (int)wl_f, h_high = h_low + 1, w_high = w_low + 1;
+        const double lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.0 - lh, hw = 1.0 - lw;
+        double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+        if (h_low >= 0 && w_low >= 0) v1 = lvl[((long)h_low * W + w_low) * row_stride];
+        if (h_low >= 0 && w_high <= W - 1) v2 = lvl[((long)h_low * W + w_high) * row_stride];
+        if (h_high <= H - 1 && w_low >= 0) v3 = lvl[((long)h_high * W + w_low) * row_stride];
+        if (h_high <= H - 1 && w_high <= W - 1) v4 = lvl[((long)h_high * W + w_high) * row_stride];
+        acc += wgt[sidx] * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
+      }
+    }
+    out[qm * D + c] = acc;
+  }
+}
+
+// fp64 backward: same decomposition as msda_bwd_kernel<0> (atomics on all three gradients, outputs zeroed by the entry point)
+__global__ __launch_bounds__(256) void msda_bwd_f64_kernel(
+    const double* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+    const double* __restrict__ loc, const double* __restrict__ wgt, const double* __restrict__ gout,
+    double* __restrict__ gvalue, double* __restrict__ gloc, double* __restrict__ gwgt,
+    int N, int S, int M, int D, int L, int Lq, int P) {
+  const long total = (long)N * Lq * M * D;
+  const long row_stride = (long)M * D;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % D);
+  long t = idx / D;
+  const int m = (int)(t % M);
+  t /= M;
+  const int q = (int)(t % Lq);
+  const int n = (int)(t / Lq);
+  const long qm = ((long)n * Lq + q) * M + m;
+  const double go = gout[qm * D + c];
+  const double* vb = value + (long)n * S * row_stride + (long)m * D + c;
+  double* gvb = gvalue + (long)n * S * row_stride + (long)m * D + c;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const long lbase = (long)starts[l] * row_stride;
+    for (int p = 0; p < P; ++p) {
+      const long sidx = qm * L * P + l * P + p;
+      const double aw = wgt[sidx];
+      const double h_im = loc[sidx * 2 + 1] * (double)H - 0.5, w_im = loc[sidx * 2] * (double)W - 0.5;
+      if (!(h_im > -1.0 && w_im > -1.0 && h_im < (double)H && w_im < (double)W)) continue;
+      const double hl_f = floor(h_im), wl_f = floor(w_im);
+      const int h_low = (int)hl_f, w_low = (int)wl_f, h_high = h_low + 1, w_high = w_low + 1;
+      const double lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.0 - lh, hw = 1.0 - lw;
+      const double top = go * aw;
+      double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+      if (h_low >= 0 && w_low >= 0) {
+        const long o = lbase + ((long)h_low * W + w_low) * row_stride;
+        v1 = vb[o];
+        atomicAdd(gvb + o, hh * hw * top);
+      }
+      if (h_low >= 0 && w_high <= W - 1) {
+        const long o = lbase + ((long)h_low * W + w_high) * row_stride;
+        v2 = vb[o];
+        atomicAdd(gvb + o, hh * lw * top);
+      }
+      if (h_high <= H - 1 && w_low >= 0) {
+        const long o = lbase + ((long)h_high * W + w_low) * row_stride;
+        v3 = vb[o];
+        atomicAdd(gvb + o, lh * hw * top);
+      }
+      if (h_high <= H - 1 && w_high <= W - 1) {
+        const long o = lbase + ((long)h_high * W + w_high) * row_stride;
+        v4 = vb[o];
+        atomicAdd(gvb + o, lh * lw * top);
+      }
+      atomicAdd(gloc + sidx * 2, (hh * (v2 - v1) + lh * (v4 - v3)) * top * (double)W);     // cuh:128-167
+      atomicAdd(gloc + sidx * 2 + 1, (hw * (v3 - v1) + lw * (v4 - v2)) * top * (double)H);
+      atomicAdd(gwgt + sidx, go * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4));
+    }
+  }
+}
+
 template <typename T>
 static int launch_msda_fwd(const T* value, const int64_t* shapes, const int64_t* starts, const float* loc,
                            const float* wgt, T* out, int N, int S, int M, int D, int L, int Lq, int P,
@@ -694,6 +794,44 @@ int mvg_msda_forward_f32(const float* value, const int64_t* spatial_shapes, cons
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return MVG_E_BADARG;
   return launch_msda_fwd<float>(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, N, S, M, D,
                                 L, Lq, P, (hipStream_t)stream);
+}
+
+int mvg_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const double* sampling_loc, const double* attn_weight, double* out, int N, int S, int M, int D,
+                         int L, int Lq, int P, void* stream) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return MVG_E_BADARG;
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return MVG_E_BADARG;
+  if (Lq == 0) return 0;
+  const long total = (long)N * Lq * M * D;
+  long grid = (total + 255) / 256;
+  if (grid > (1L << 22)) grid = 1L << 22;
+  hipLaunchKernelGGL(msda_fwd_f64_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, value, spatial_shapes,
+                     level_start_index, sampling_loc, attn_weight, out, N, S, M, D, L, Lq, P);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const double* sampling_loc, const double* attn_weight, const double* grad_output,
+                          double* grad_value, double* grad_sampling_loc, double* grad_attn_weight, int N, int S, int M,
+                          int D, int L, int Lq, int P, void* stream) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_output ||
+      !grad_value || !grad_sampling_loc || !grad_attn_weight)
+    return MVG_E_BADARG;
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return MVG_E_BADARG;
+  if (Lq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_sampling_loc, 0, sizeof(double) * (size_t)N * Lq * M * L * P * 2, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(grad_attn_weight, 0, sizeof(double) * (size_t)N * Lq * M * L * P, st);
+  if (e != hipSuccess) return (int)e;
+  const long total = (long)N * Lq * M * D;
+  if (total > 0x7fffffffL * 256L) return MVG_E_BADARG;
+  hipLaunchKernelGGL(msda_bwd_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, value, spatial_shapes,
+                     level_start_index, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc,
+                     grad_attn_weight, N, S, M, D, L, Lq, P);
+  MVG_LAUNCH_CHECK();
+  return 0;
 }
 
 int mvg_msda_forward_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

@@ -222,6 +222,60 @@ class DQDecoderLayer(MvPDecoderLayer):
     def _w(self, key, params, dtype, build=None):
         return self._wc.get(key, params, dtype, build)
 
+    # cached operands of the fused chains (csrc/chain.hip), in the order the ops take them
+    def _chain_a_weights(self, dt):
+        f32 = torch.float32
+        pose_layers = self.pose_embed.MLP.layers
+        sw = lambda w: ops.swizzle_weight(w.to(dt))
+        wts = (self._w("Wp_sw", (self.proj_attn.output_proj.weight,), dt, sw),
+               self._w("bp", (self.proj_attn.output_proj.bias,), f32),
+               self._w("Wpe0_sw", (pose_layers[0].weight,), dt, sw), self._w("bpe0", (pose_layers[0].bias,), f32),
+               self._w("Wpe1_sw", (pose_layers[1].weight,), dt, sw), self._w("bpe1", (pose_layers[1].bias,), f32),
+               self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
+        pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
+        o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
+        return wts, o_masked
+
+    def _chain_b_weights(self, dt):
+        f32 = torch.float32
+        sw = lambda w: ops.swizzle_weight(w.to(dt))
+        ffn = self.open_forward_ffn
+        return (self._w("Wu_sw", (self.feature_update_mlp.weight,), dt, sw), self._w("bu", (self.feature_update_mlp.bias,), f32),
+                self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
+                self._w("W1_sw", (self.linear1.weight,), dt, sw) if ffn else None,
+                self._w("b1", (self.linear1.bias,), f32) if ffn else None,
+                self._w("W2_sw", (self.linear2.weight,), dt, sw) if ffn else None,
+                self._w("bb2", (self.linear2.bias,), f32) if ffn else None,
+                self._w("g3", (self.norm3.weight,), f32) if ffn else None,
+                self._w("b3", (self.norm3.bias,), f32) if ffn else None,
+                self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
+
+    def _fuses_chains(self, dt):
+        """(chain A, chain B) run as the fused LDS-resident kernels for this configuration."""
+        pose_layers = self.pose_embed.MLP.layers
+        fuse_a = (dt == torch.bfloat16 and self.use_fused_chains and len(pose_layers) == 3 and
+                  pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256)
+        fuse_b = (dt == torch.bfloat16 and self.use_fused_chains and self.d_model == 256 and self.num_joints <= 64 and
+                  (not self.open_forward_ffn or self.linear1.out_features == 1024))
+        return fuse_a, fuse_b
+
+    def prepare_caches(self, dtype=None):
+        """Build every cached operand of the inference path on the CURRENT stream, outside any graph capture (one of
+        them, o_masked, launches a kernel).  An entry created inside a capture would live in the graph's private pool
+        and stay unwritten until the first replay -- WeightCache.get refuses to do that.  DQDecoder calls this before
+        it forks its side stream, the sharded runners (mvgformer_amd.dist) before they capture."""
+        dt = dtype or self.compute_dtype
+        if self.proj_attn.uses_fast_path(dt):
+            self.proj_attn.prepare_fast_path(dt)
+        else:
+            self.proj_attn.weights(dt)
+        fuse_a, fuse_b = self._fuses_chains(dt)
+        if fuse_a:
+            self._chain_a_weights(dt)
+        if fuse_b:
+            self._chain_b_weights(dt)
+        return self
+
     # ----------------------------------------------------------------------------- forward
     def forward(self, tgt, query_pos, reference_points, src_views, src_spatial_shapes, level_start_index, meta,
                 src_padding_mask=None, rgb_views=None, output_dir="./", frame_id=None, indices=None,
@@ -234,7 +288,17 @@ class DQDecoderLayer(MvPDecoderLayer):
         if not tgt.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
         self._check_supported()
-        if torch.is_grad_enabled() and (tgt.requires_grad or any(p.requires_grad for p in self.parameters())):
+        with torch.cuda.device(tgt.device):     # kernels go to the current stream of the TENSORS' device
+            return self._forward(tgt, query_pos, reference_points, src_views, src_spatial_shapes, level_start_index, meta,
+                                 indices, threshold)
+
+    def _forward(self, tgt, query_pos, reference_points, src_views, src_spatial_shapes, level_start_index, meta, indices,
+                 threshold):
+        # The native path has no dropout: it is the eval()-mode layer.  Under autograd, and in train() mode with active
+        # dropout (validation inside a training loop without .eval(), MC-dropout), the differentiable torch path runs,
+        # which applies dropout2/3/4 like the reference (dq_decoder.py:776, mvp_decoder.py:94-98).
+        dropping = self.training and max(self.dropout2.p, self.dropout3.p, self.dropout4.p) > 0
+        if dropping or (torch.is_grad_enabled() and (tgt.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.forward_autograd(tgt, query_pos, reference_points, src_views, src_spatial_shapes,
                                          level_start_index, meta, indices, threshold)
         ctx = self._ctx
@@ -302,9 +366,13 @@ class DQDecoderLayer(MvPDecoderLayer):
                for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
         Ainv = torch.stack([meta[v]["inv_affine_trans"][:, :2, :].to(dev) for v in range(V)], 1).float()   # (B,V,2,3)
         uo = torch.matmul(torch.cat([ref2d, torch.ones_like(ref2d[..., :1])], -1), Ainv.transpose(2, 3))
-        X3 = G.dlt(G.proj_matrices(cam), G.undistort(uo, cam), conf)           # (B,Lq,3)
-        vm = valid.view(B, NQ, 1, 1)
-        new_ref = torch.where(vm, X3.view(B, NQ, J, 3), torch.zeros((), device=dev)).reshape(B, Lq, 3)
+        # Only the matched queries are triangulated, like the reference (dq_decoder.py:929-967): an unmatched query
+        # with a degenerate DLT (homogeneous w == 0, an Inf 2D point) would otherwise put 0 * inf = NaN into the
+        # gradients of the parameters all queries share.
+        ud, Pm = G.undistort(uo, cam), G.proj_matrices(cam)
+        bi, ti = valid.view(B, NQ, 1).expand(B, NQ, J).reshape(B, Lq).nonzero(as_tuple=True)
+        Xv = G.dlt(Pm[bi], ud[bi, :, ti].unsqueeze(2), conf[bi, :, ti].unsqueeze(2))[:, 0]     # (n_valid_tokens, 3)
+        new_ref = torch.zeros((B, Lq, 3), dtype=Xv.dtype, device=dev).index_put((bi, ti), Xv)
         vm2 = valid.view(B, 1, NQ, 1, 1)
         zero = torch.zeros((), device=dev)
         ref2d_o = torch.where(vm2, ref2d.view(B, V, NQ, J, 2), zero).reshape(B, V, Lq, 2)
@@ -331,8 +399,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             xw_in = None
         f32 = torch.float32
         pose_layers = self.pose_embed.MLP.layers
-        fuse_a = (dt == torch.bfloat16 and self.use_fused_chains and len(pose_layers) == 3 and
-                  pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256)
+        fuse_a, fuse_b = self._fuses_chains(dt)
         o = None
         if fuse_a:
             # processing order of the (image, query) pairs: image-space (Morton) order, pairs outside the image last
@@ -348,14 +415,7 @@ class DQDecoderLayer(MvPDecoderLayer):
                 order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
                                                 order=order, xw=xw_in)
-            sw = lambda w: ops.swizzle_weight(w.to(dt))
-            wts = (self._w("Wp_sw", (self.proj_attn.output_proj.weight,), dt, sw),
-                   self._w("bp", (self.proj_attn.output_proj.bias,), f32),
-                   self._w("Wpe0_sw", (pose_layers[0].weight,), dt, sw), self._w("bpe0", (pose_layers[0].bias,), f32),
-                   self._w("Wpe1_sw", (pose_layers[1].weight,), dt, sw), self._w("bpe1", (pose_layers[1].bias,), f32),
-                   self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
-            pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
-            o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
+            wts, o_masked = self._chain_a_weights(dt)
             attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
             attn = self.proj_attn.native_forward(x(), ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
@@ -370,10 +430,8 @@ class DQDecoderLayer(MvPDecoderLayer):
             for b, q in enumerate(indices):
                 forced[b, torch.as_tensor(q, dtype=torch.long, device=tgt.device)] = 1
         tgt32 = tgt.float().reshape(B * Lq, C).contiguous()
-        fuse_b = (dt == torch.bfloat16 and self.use_fused_chains and C == 256 and J <= 64 and
-                  (not self.open_forward_ffn or self.linear1.out_features == 1024))
+        fuse_b = fuse_b and C == 256 and J <= 64
         if fuse_b:
-            sw = lambda w: ops.swizzle_weight(w.to(dt))
             ffn = self.open_forward_ffn
             # the next layer's query term xw = (tgt' + query_pos) W^T + b rides on this chain (its rows are in LDS)
             nxt = self._next_layer[0] if self._next_layer else None     # (kept in a tuple: not a sub-module)
@@ -384,17 +442,8 @@ class DQDecoderLayer(MvPDecoderLayer):
                 qp = None if query_pos is None else query_pos.float().reshape(B * Lq, C).contiguous()
                 next_proj = (qp, Wn, bn, n_next)
             res = ops.chain_update_ffn_class(
-                attn, V, tgt32,
-                self._w("Wu_sw", (self.feature_update_mlp.weight,), dt, sw), self._w("bu", (self.feature_update_mlp.bias,), f32),
-                self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
-                self._w("W1_sw", (self.linear1.weight,), dt, sw) if ffn else None,
-                self._w("b1", (self.linear1.bias,), f32) if ffn else None,
-                self._w("W2_sw", (self.linear2.weight,), dt, sw) if ffn else None,
-                self._w("bb2", (self.linear2.bias,), f32) if ffn else None,
-                self._w("g3", (self.norm3.weight,), f32) if ffn else None,
-                self._w("b3", (self.norm3.bias,), f32) if ffn else None,
-                self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32),
-                threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
+                attn, V, tgt32, *self._chain_b_weights(dt), threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out,
+                any_valid=self._flag, next_query_proj=next_proj)
             tgt_update, prob, valid, any_valid = res[:4]
             if next_proj is not None:
                 nxt._xw_in = res[4]
@@ -493,8 +542,9 @@ class DQDecoder(MvPDecoder):
             return None
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
-        for l in self.layers:       # cached operands are built here, on the forking stream, never on the side stream
-            l.proj_attn.prepare_fast_path(l.compute_dtype)
+        if not torch.cuda.is_current_stream_capturing():
+            for l in self.layers:   # cached operands are built here, on the forking stream, never on the side stream
+                l.prepare_caches()
         self._side_stream.wait_stream(torch.cuda.current_stream())
         return self._side_stream
 
@@ -531,6 +581,11 @@ class DQDecoder(MvPDecoder):
         else (output, reference_points, ref_points_2d).  ``context`` (optional, beyond the reference
         signature): a DecoderContext.prepare(...)d context, so the host-side camera packing is
         hoisted out of a captured HIP graph."""
+        if tgt.is_cuda and tgt.device.index != torch.cuda.current_device():
+            with torch.cuda.device(tgt.device):     # kernels go to the current stream of the TENSORS' device
+                return self.forward(tgt, reference_points, src_views, meta, src_spatial_shapes, src_level_start_index,
+                                    src_valid_ratios, query_pos, src_padding_mask, rgb_views, output_dir, frame_id, indices,
+                                    threshold, indices_all, context)
         output = tgt
         layer0 = self.layers[0]
         ctx = context
@@ -540,8 +595,12 @@ class DQDecoder(MvPDecoder):
             if ctx is None:
                 ctx = DecoderContext.build(src_views, src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
                                            layer0.compute_dtype, tgt.shape[0])
-            elif ctx.feat is None:
+            elif src_views is not None:
+                # a prepared context is reused across frames (static cameras): the pyramid is re-packed from THIS
+                # call's src_views every time (a no-op for levels produced in place in ctx.pyramid_buffers())
                 ctx.pack(src_views)
+            elif ctx.feat is None:
+                raise RuntimeError("DQDecoder.forward: context without a packed pyramid and no src_views")
             ctx.order = None
             inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
             ref_points_2d = None

@@ -150,6 +150,8 @@ class GraphedShardedDecoder:
         self.J = decoder.layers[0].num_joints
         self.gather_hidden = gather_hidden
         self.graphs, self.flags = [], []
+        for layer in decoder.layers:        # cached operands are never built inside a capture (WeightCache.get)
+            layer.prepare_caches()
         self._capture()
 
     def _sync_flag(self, any_valid):

@@ -84,12 +84,17 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
             raise RuntimeError("sampling_loc / attn_weight must be float32")
         rc = lib.mvg_msda_forward_f32(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index), L.ptr(sampling_loc),
                                       L.ptr(attn_weight), L.ptr(out), N, S, M, D, nl, Lq, P, L.stream_ptr())
+    elif value.dtype == torch.float64:      # AT_DISPATCH_FLOATING_TYPES' double case (deform_cuda.cu:75)
+        if sampling_loc.dtype != torch.float64 or attn_weight.dtype != torch.float64:
+            raise RuntimeError("sampling_loc / attn_weight must be float64")
+        rc = lib.mvg_msda_forward_f64(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index), L.ptr(sampling_loc),
+                                      L.ptr(attn_weight), L.ptr(out), N, S, M, D, nl, Lq, P, L.stream_ptr())
     elif value.dtype == torch.bfloat16:
         rc = lib.mvg_msda_forward_bf16(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index),
                                        L.ptr(sampling_loc.float().contiguous()), L.ptr(attn_weight.float().contiguous()),
                                        L.ptr(out), N, S, M, D, nl, Lq, P, L.stream_ptr())
     else:
-        raise RuntimeError("deform_forward: float32 / bfloat16 only (got %s)" % value.dtype)
+        raise RuntimeError("deform_forward: float32 / float64 / bfloat16 only (got %s)" % value.dtype)
     L.check(rc, "mvg_msda_forward")
     return out
 
@@ -97,18 +102,22 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
 def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
     """Deformable.deform_backward (lib/models/ops/src/deform.h:53-72)."""
     L.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
-    if value.dtype != torch.float32:
-        raise RuntimeError("deform_backward: float32 only")
+    if value.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("deform_backward: float32 / float64 only")        # AT_DISPATCH_FLOATING_TYPES, deform_cuda.cu:145
+    for t in (sampling_loc, attn_weight, grad_output):
+        if t.dtype != value.dtype:
+            raise RuntimeError("deform_backward: all floating tensors must have value's dtype (%s)" % value.dtype)
     grad_output = grad_output.contiguous()
     N, S, M, D = value.shape
     _, Lq, _, nl, P, _ = sampling_loc.shape
     gv = torch.zeros_like(value)                                             # deform_cuda.cu:132-134
     gl = torch.empty_like(sampling_loc)
     ga = torch.empty_like(attn_weight)
-    rc = L.load().mvg_msda_backward_f32(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index),
+    fn = L.load().mvg_msda_backward_f32 if value.dtype == torch.float32 else L.load().mvg_msda_backward_f64
+    rc = fn(L.ptr(value), L.ptr(spatial_shapes), L.ptr(level_start_index),
                                         L.ptr(sampling_loc), L.ptr(attn_weight), L.ptr(grad_output), L.ptr(gv), L.ptr(gl),
                                         L.ptr(ga), N, S, M, D, nl, Lq, P, L.stream_ptr())
-    L.check(rc, "mvg_msda_backward_f32")
+    L.check(rc, "mvg_msda_backward")
     return gv, gl, ga
 
 

@@ -42,14 +42,20 @@ class WeightCache:
         hit = self._store.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
+        if any(p.is_cuda for p in params) and torch.cuda.is_current_stream_capturing():
+            # An entry built inside a capture would sit in the graph's private pool, stamped valid but unwritten until
+            # the first replay: an eager forward before that replay (or after the parameters were restored) would read
+            # garbage without any error.  Operands are built ahead of a capture: DQDecoderLayer.prepare_caches().
+            raise RuntimeError("WeightCache: %r is not cached for the current parameters and a HIP-graph capture is in "
+                               "progress; call DQDecoderLayer.prepare_caches() (or run one eager forward with the same "
+                               "dtype and weights) before capturing" % key)
         with torch.no_grad():
             t = build(*params) if build is not None else params[0]
             t = t.detach().to(dtype).contiguous()
         # An entry is built on whatever stream is current and then handed out to every stream (the decoder issues
         # query-independent work on a side stream): finish the build before anybody can see the entry.  Rare (first
-        # use / parameters changed).  Inside a graph capture a host wait is illegal -- DQDecoder.fork_side_stream
-        # fills the caches on the forking stream first (ProjAttn.prepare_fast_path), so nothing is built after a fork.
-        if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        # use / parameters changed).
+        if t.is_cuda:
             torch.cuda.current_stream(t.device).synchronize()
         self._store[key] = (stamp, t)
         return t
@@ -242,6 +248,10 @@ class ProjAttn(nn.Module):
         (n_views, Lq, n_levels, 2) already rescaled per level; src_views list of (n_views,C,H,W)."""
         if not query.is_cuda:
             raise RuntimeError("Not implemented on the CPU")                  # deform.h:49
+        if query.device.index != torch.cuda.current_device():
+            with torch.cuda.device(query.device):   # kernels go to the current stream of the TENSORS' device
+                return self.forward(query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,
+                                    input_level_start_index, input_padding_mask)
         n_views, Len_q, c = query.shape
         feat_lvls = len(src_views)
         if self.projattn_posembed_mode != "ablation_not_use_rayconv":

@@ -49,3 +49,20 @@ def test_bench_line_has_the_contract_fields():
     assert r["algorithmic_bytes_per_launch"] == 231014400
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_us"] / 1e3) < 1.0
     assert 0.02 < r["frac"] < 1.0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_plain_multi_gpu_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed.run in front, the shape of the driver's 1-GPU command) starts two
+    ranks itself and both reach init_process_group (gloo override: no GPU / RCCL in this container); then every rank
+    stops because there is no GPU -- not because the launch was refused."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MVG_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out = p.stderr + p.stdout
+    assert p.returncode != 0
+    assert "rank 0/2: process group up (gloo)" in out and "rank 1/2: process group up (gloo)" in out, out[-3000:]
+    assert "no CPU path" in out
+    assert "launch with torch.distributed.run" not in out

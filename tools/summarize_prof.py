@@ -64,7 +64,13 @@ for k in acc:
     if k.startswith("msda_gsamp_kernel") and "FETCH_SIZE" in acc[k]:
         fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
         write_kb = sum(acc[k].get("WRITE_SIZE", [0])) / max(len(acc[k].get("WRITE_SIZE", [0])), 1)
-        rec = {"kernel": k, "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from bench import sampler_source_hash
+        # what the figure was measured on: bench.py quotes it only for the same kernel sources and configuration
+        rec = {"kernel": k, "config": os.environ.get("MVG_PROF_CONFIG", "cfg2"), "dtype": os.environ.get("MVG_PROF_DTYPE", "bf16"),
+               "queries": int(os.environ.get("MVG_PROF_QUERIES", "1024")), "valid_fraction": None,
+               "src_sha256": sampler_source_hash(),
+               "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
                "fetch_correction": 2.0,
                "note": "gfx950 rocprofv3: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B "
                        "(MI355X_MICROARCH.md, HBM section); calibrated in the same run on kernels with a known read "
