@@ -76,10 +76,15 @@ __device__ __forceinline__ void ring_prefetch(const bf16_t* __restrict__ Wf, f32
   }
 }
 
-template <int MT, int KSTEPS, int RING = 4, int JN = 2, bool PRE = false>
+// SPLIT: the first KSTEPS/2 k-steps (in rotated order) accumulate into `acc`, the last KSTEPS/2 into `acc2`; the caller adds
+// the two.  Because that final fp32 addition commutes, rot and rot + KSTEPS/2 give BIT-IDENTICAL results: a kernel can run
+// its tiles in two phases that are half a weight apart (L2-channel decorrelation) without a row's result depending on
+// the tile it happens to be in (chain B).
+template <int MT, int KSTEPS, int RING = 4, int JN = 2, bool PRE = false, bool SPLIT = false>
 __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const bf16_t* __restrict__ Wf,
                                            f32x16 (&acc)[MT][JN], int tid, bool zero, int rot,
-                                           int wn_stride = KSTEPS * 1024, f32x4 (*pre)[JN] = nullptr) {
+                                           int wn_stride = KSTEPS * 1024, f32x4 (*pre)[JN] = nullptr,
+                                           f32x16 (*acc2)[JN] = nullptr) {
   static_assert((KSTEPS & (KSTEPS - 1)) == 0, "KSTEPS must be a power of two");
   const WaveMap<JN> wm(tid, MT * 32);
   const int lane = tid & 63, rl = lane & 31, h = lane >> 5, row0 = wm.row0;
@@ -89,7 +94,10 @@ __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const b
 #pragma unroll
       for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mt][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+          acc[mt][j][e] = 0.f;
+          if (SPLIT) acc2[mt][j][e] = 0.f;
+        }
   }
   const bf16_t* wp = Wf + (long)wm.wn * wn_stride + wm.j0 * 512 + lane * 8;   // wn_stride: elements between the wave slices
   f32x4 ring[RING][JN];
@@ -130,13 +138,26 @@ __device__ __forceinline__ void stage_gemm(const char* __restrict__ act, const b
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < JN; ++j)
-        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[mt]),
-                                                            acc[mt][j], 0, 0, 0);
+      for (int j = 0; j < JN; ++j) {
+        if (SPLIT && ks >= KSTEPS / 2)
+          acc2[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[mt]),
+                                                               acc2[mt][j], 0, 0, 0);
+        else
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[mt]),
+                                                              acc[mt][j], 0, 0, 0);
+      }
     // pin the k-step: without this hipcc sinks the ring refills down to their uses (issue -> vmcnt(0)
     // -> MFMA in the same step, i.e. no prefetch distance at all; measured MFMA utilisation 13 %)
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+template <int MT, int JN>
+__device__ __forceinline__ void merge_acc(f32x16 (&acc)[MT][JN], const f32x16 (&acc2)[MT][JN]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[mt][j] += acc2[mt][j];
 }
 
 // acc (+bias, relu, row keep-mask) -> bf16 activation tile in LDS, IN PLACE: the caller puts a
@@ -430,9 +451,13 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   const int rpt = qpt * J;                               // real rows per tile (60)
   const int q0 = blockIdx.x * qpt, r0 = q0 * J;
   const int nrow = min(rpt, rows - r0);
-  // per tile AND wavefront (worth 5 us of 48 here): tiles are fixed blocks of queries, so results are reproducible;
-  // a query-sharded run numbers its tiles differently and may differ from the unsharded one in the last bf16 bit
-  const int rot = (blockIdx.x * 7 + (JN == 1 ? wave : (wave & 3)) * 3) & 15;
+  // All tiles walk the SAME weights; in lock-step the 32 tiles of an XCD would hit the same L2 channel at the same time
+  // (stage_gemm).  The k-step order is rotated per wavefront (= per column group) and, per TILE, by half a weight: tiles
+  // (blockIdx >> 3) even / odd -- neighbours on one XCD, whose L2 they share -- start 8 k-steps apart.  The stage GEMMs
+  // accumulate the two halves of the k range separately (SPLIT) and add them, so both phases give bit-identical rows: a
+  // row's result does not depend on the tile it sits in, and query-sharded, permuted and single-rank runs agree bit for
+  // bit.  (A free per-tile rotation of one accumulator was as fast but made the last bf16 bit depend on the tile.)
+  const int rot = (((JN == 1 ? wave : (wave & 3)) * 3) + ((blockIdx.x >> 3) & 1) * 8) & 15;
 
   // Row phases (LayerNorms, class head): 8 lanes per row, a wavefront works on 8 rows at once; lane (g = lane>>3,
   // part = lane&7) holds the 8 channel quads part, part+8, ..., part+56 of row  wave*8 + g (+ 8*NW per pass), so a
@@ -505,10 +530,11 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   __syncthreads();
 
   // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
-  f32x16 acc[MT][JN];
+  f32x16 acc[MT][JN], acc2[MT][JN];
   f32x4 pf[BRING][JN];
-  stage_gemm<MT, 16, BRING, JN>(act, Wu, acc, tid, true, rot);
+  stage_gemm<MT, 16, BRING, JN, false, true>(act, Wu, acc, tid, true, rot, 16 * 1024, nullptr, acc2);
   if (has_ffn) ring_prefetch<16, BRING, JN, MT>(W1, pf, tid, rot);       // first FFN stage, fetched under LN2
+  merge_acc<MT, JN>(acc, acc2);
   acc_to_x<MT, JN>(xb, acc, bu, false, tid);
   __syncthreads();
 #pragma unroll
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 
   if (has_ffn) {
     // ---- FFN (mvp_decoder.py:94-98): Y = sum_c relu(t1 W1_c^T + b1_c) W2[:, c]^T, hidden chunks of 256
-    f32x16 accy[MT][JN];
+    f32x16 accy[MT][JN], accy2[MT][JN];
     bool all[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) all[mt] = true;
@@ -566,17 +592,19 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     // previous one), see ring_prefetch
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
-      stage_gemm<MT, 16, BRING, JN, true>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c, 16 * 1024, pf);
+      stage_gemm<MT, 16, BRING, JN, true, true>(act, W1 + (long)c * 256 * 256, acc, tid, true, rot + 3 * c, 16 * 1024, pf, acc2);
+      merge_acc<MT, JN>(acc, acc2);
       f32x4 bv1[JN][4];
       load_bias<JN>(b1 + c * 256, bv1, tid, MT * 32);
       ring_prefetch<16, BRING, JN, MT>(W2 + (long)c * 16 * 1024, pf, tid, rot + 3 * c + 1, 64 * 1024);
       __builtin_amdgcn_sched_barrier(0);
       write_act_pre<MT, JN>(hbuf, acc, bv1, true, all, tid);                                   // private buffer: no hazard with act
       __syncthreads();
-      stage_gemm<MT, 16, BRING, JN, true>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024, pf);
+      stage_gemm<MT, 16, BRING, JN, true, true>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024, pf, accy2);
       if (c < 3) ring_prefetch<16, BRING, JN, MT>(W1 + (long)(c + 1) * 256 * 256, pf, tid, rot + 3 * (c + 1));
       __syncthreads();                                                               // hbuf free for the next chunk
     }
+    merge_acc<MT, JN>(accy, accy2);
     acc_to_x<MT, JN>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
     __syncthreads();
   }
@@ -651,7 +679,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets/logits Linear
     //      (projattn.py:180-181), computed while the rows are still in LDS (saves a 15 360-row GEMM launch and the
     //      elementwise add per layer).  The barrier above ordered the act writes and the last xb reads.
-    stage_gemm<MT, 16, BRING, JN>(act, Wn, acc, tid, true, rot + 7);
+    stage_gemm<MT, 16, BRING, JN, false, true>(act, Wn, acc, tid, true, rot + 7, 16 * 1024, nullptr, acc2);
+    merge_acc<MT, JN>(acc, acc2);
     acc_to_x<MT, JN>(xb, acc, bn, false, tid);
     __syncthreads();
     for (int row = wave; row < nrow; row += NW)

@@ -1,6 +1,5 @@
 """GPU test of the query-sharded decoder: 2 ranks (both on cuda:0, gloo for the exchange -- the GPU box
-has one device; RCCL needs one device per rank) must reproduce the single-rank outputs (fp32 path: bit for bit;
-bf16 path: graphed == eager bit for bit, both within bf16 rounding of the single-rank run), eagerly and through
+has one device; RCCL needs one device per rank) must reproduce the single-rank outputs BIT FOR BIT (fp32 and bf16 paths), eagerly and through
 the segmented HIP-graph runner, including the global "no query valid -> force (0,0)" rule."""
 import os
 import socket
@@ -63,14 +62,11 @@ def _worker(rank, world, port, cname, q, bf16=False):
                 ok = ok and all(torch.equal(a, b) for a, b in zip(got[:4], full[:4]))
                 ok = ok and all(torch.equal(a, b) for a, b in zip(got[4], full[4]))
         else:
-            # bf16 path: the segmented graphs replay exactly the eager sharded kernels (bit-identical); against the
-            # single-rank run the fused chain B numbers its tiles differently (k-step rotation per tile): bf16 rounding
-            ok = ok and all(torch.equal(a, b) for a, b in zip(eager[:4], graphed[:4]))
-            ok = ok and all(torch.equal(a, b) for a, b in zip(eager[4], graphed[4]))
-            ok = ok and float((eager[0] - full[0]).abs().max()) < 3e-2
-            ok = ok and float((eager[1] - full[1]).norm(dim=-1).max()) < 1.0
-            ok = ok and float((eager[2] - full[2]).abs().max()) < 5e-2
-            ok = ok and bool(torch.equal(eager[1].abs().sum(-1) > 0, full[1].abs().sum(-1) > 0))
+            # bf16 path: sharded (eager and segmented graphs) == single rank bit for bit as well -- no kernel's rounding
+            # depends on a query's position in the launch (chain B rotates wavefront -> column group, not the k order)
+            for got in (eager, graphed):
+                ok = ok and all(torch.equal(a, b) for a, b in zip(got[:4], full[:4]))
+                ok = ok and all(torch.equal(a, b) for a, b in zip(got[4], full[4]))
         nvalid = [int((c[..., 1] > thr).sum()) for c in full[4]]
         q.put((rank, bool(ok and spec_ok), nvalid))
     finally:
