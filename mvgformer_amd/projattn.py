@@ -153,7 +153,7 @@ class ProjAttn(nn.Module):
         """both pyramid projections were produced ahead of time on a side stream (DQDecoder.launch_pyramid_projections)."""
         if self._vp_event is not True:          # True: already joined into this stream (segmented graphs)
             torch.cuda.current_stream().wait_event(self._vp_event)
-        self._vp_event = None
+        # the event stays armed until the end of the forward (DQDecoder.join_pyramid_projections clears it)
         return self._vp, self._G
 
     def project_pyramid(self, feat, record_event=False):
