@@ -374,7 +374,12 @@ def main():
     # measured by this run (two rocprofv3 child passes of the same command) or the committed figure of tools/prof.sh --
     # quoted only for the kernel sources (hash) and configuration it was measured on; the line says which.
     traffic, traffic_source = None, None
-    samp_name = "msda_gsamp_kernel" if dtype == torch.bfloat16 else "msda_fused_kernel"
+    # the dominant kernel: the fused sampler + chain A (bf16 default), the plain G-sampling kernel (MVG_FUSE_SAMPLER=0) or
+    # the generic fused sampling kernel (fp32); its algorithmic bytes are SURVEY 8(d)'s sampling figure in all three cases
+    # (the chain-A half of the fused kernel adds no bytes to the numerator)
+    kernel_names = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel", "msda_fused": "msda_fused_kernel"}
+    samp_key = next((k for k in kernel_names if k in prof), "msda_fused")
+    samp_name = kernel_names[samp_key]
     if world == 1 and args.traffic != "off" and args.inflight == 1:
         src_hash = sampler_source_hash()
         want = {"config": args.config, "dtype": args.dtype, "queries": NQ, "valid_fraction": args.valid_fraction,
@@ -399,11 +404,10 @@ def main():
                               if traffic is not None else "unavailable: %s" % detail)
         elif traffic is None:
             traffic_source = "no committed PMC profile for these kernel sources (%s) and this configuration" % src_hash
-    samp_key = "msda_gsamp" if "msda_gsamp" in prof else "msda_fused"     # bf16 fast path / generic fused kernel
     if samp_key in prof:
         n, ms = prof[samp_key]
         ach = bytes_launch / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": samp_key + "_kernel", "achieved": round(ach, 1), "peak": 8000.0,
+        roof = {"bound": "hbm", "kernel": samp_name, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)

@@ -1,0 +1,207 @@
+// Device building blocks of the G-sampling kernel (csrc/msda.hip: msda_gsamp_kernel) -- shared with the fused sampler +
+// chain A kernel (csrc/sampchain.hip).  See msda.hip for the design notes.
+#pragma once
+#include "common.h"
+
+// Index-safe copy of an image coordinate: equal to x wherever the sample counts (-1 < x < n), -2 <= . <= n+1 otherwise
+// (v_med3_f32 returns the minimum of the non-NaN operands when x is NaN: -2).  floor, the float->int conversion and
+// the +1 of the lower-right corner are taken from it, so that they can neither overflow nor be undefined for NaN,
+// +-Inf or 1e30 locations; the reference's bounds test (cuh:298) still looks at the original value and rejects those.
+__device__ __forceinline__ float index_safe(float x, float n) { return __builtin_amdgcn_fmed3f(x, -2.f, n + 1.f); }
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return pack_bf16(lo, hi);
+}
+template <int S>   // value of lane S of every quad (v_mov_b32_dpp quad_perm:[S,S,S,S])
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xf, 0xf, false);
+}
+
+// One lane's sample of gather batch `it` of a (pair, head): sample index it*4 + sub, level (it*4)/8.  Branch-free:
+// packed (left, right) bf16 weights of the top / bottom pixel pair, the byte offsets of the top-left / bottom-left
+// pixels inside the head plane and the byte distance to the right-hand pixel (0 at the image border, else 64).
+template <int L>
+__device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
+                                             int sub, unsigned& wt, unsigned& wb, unsigned& ot, unsigned& ob,
+                                             unsigned& dx) {
+  constexpr int P = 8, NB = 4, LP = L * P;
+  const int l = (it * NB) / P;
+  const int H = lv.H[l], W = lv.W[l];
+  const float Wf = (float)W, Hf = (float)H;
+  const float2 rr = *reinterpret_cast<const float2*>(sc + 3 * LP + 2 * l);   // the pair's reference point at level l
+  const float rx = rr.x, ry = rr.y;
+  const float lgs = sc[it * NB + sub];
+  const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
+  const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];               // projattn.py:186-191
+  const float h_raw = ly * Hf - 0.5f, w_raw = lx * Wf - 0.5f;                         // cuh:295-296
+  const bool inside = (h_raw > -1.f) & (w_raw > -1.f) & (h_raw < Hf) & (w_raw < Wf);  // cuh:298
+  const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
+  const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+  const int h_low = (int)hl_f, w_low = (int)wl_f;
+  const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+  const float e = __expf(lgs - mx);                                                   // <= 1: safe to evaluate always
+  const float a = inside ? e : 0.f;
+  const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+  const float t0 = hh * hw * a, t1 = hh * lw * a, t2 = lh * hw * a, t3 = lh * lw * a;
+  const float c0 = (hl_ok & wl_ok) ? t0 : 0.f, c1 = (hl_ok & wh_ok) ? t1 : 0.f;       // cuh:66-88 zero padding
+  const float c2 = (hh_ok & wl_ok) ? t2 : 0.f, c3 = (hh_ok & wh_ok) ? t3 : 0.f;
+  wt = pack_bf16x2(c0, c1);
+  wb = pack_bf16x2(c2, c3);
+  // clamped pixel indices: a clamped corner always carries weight 0
+  const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+  const int wl_c = min(max(w_low, 0), W - 1), wr_c = min(max(w_low + 1, 0), W - 1);
+  const unsigned base = (unsigned)lv.start[l];
+  ot = (base + (unsigned)(hl_c * W + wl_c)) * 64u;
+  ob = (base + (unsigned)(hh_c * W + wl_c)) * 64u;
+  dx = (unsigned)(wr_c - wl_c) * 64u;
+}
+
+// One (image-query pair, head) of the G-sampling kernel, computed by the 4 lanes of a quad (lane `sub` owns channels
+// [8 sub, 8 sub + 8) of the head): phase A gathers the head's L*P logits + 2*L*P offsets = bilinear(G) + xw into the
+// quad-private LDS row `sc` (3*L*P + 8 floats), pass 1 takes the softmax denominator, pass 2 samples the head plane.
+// No workgroup barrier inside: the quads of a wavefront are independent, inactive quads may skip the call.
+template <int L>
+__device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                           const float* __restrict__ xw, const float* __restrict__ r,
+                                           const LevelTable& lv, float* __restrict__ sc, int pair, int m, int sub,
+                                           int Lq, int S, int B, float (&acc)[8]) {
+  constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4;
+  const int n = pair / Lq, q = pair - n * Lq, b = n % B;
+
+  if (sub < L) *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = *reinterpret_cast<const float2*>(r + ((long)pair * L + sub) * 2);
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk
+#pragma unroll
+  for (int k = 0; k < (NCHK + 3) / 4; ++k) {
+    const int ci = sub + 4 * k;
+    if (ci < NCHK) {
+      // G / xw columns are grouped per (16 offsets | 8 logits): group g of a level row = columns [24g, 24g+24) =
+      // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
+      // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
+      const int t = ci / 3, part = ci - 3 * t;
+      const int fg = m * L + t;
+      const int l = fg >> 3;                                               // level row of the reinterpreted view
+      const int col = 24 * (fg & 7) + 8 * part;
+      const bool is_logit = part == 2;
+      const int H = lv.H[l], W = lv.W[l];
+      const float Wf = (float)W, Hf = (float)H;
+      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+      const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
+      const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+      const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
+      const float x0f = floorf(ix), y0f = floorf(iy);
+      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      const float tx = ix - x0f, ty = iy - y0f;
+      const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+      const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f, w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+      const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
+      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+      // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
+      const char* g_bytes = reinterpret_cast<const char*>(G);
+      const unsigned gb = ((unsigned)(n * S + lv.start[l]) * 192u + (unsigned)col) * 2u;
+      const uint4 c00 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x0c) * 384u));
+      const uint4 c10 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x1c) * 384u));
+      const uint4 c01 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x0c) * 384u));
+      const uint4 c11 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x1c) * 384u));
+      const float* xq = xw + ((long)b * Lq + q) * 192 + col;
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(xq), xb = *reinterpret_cast<const f32x4*>(xq + 4);
+      const unsigned a4[4] = {c00.x, c00.y, c00.z, c00.w}, b4[4] = {c10.x, c10.y, c10.z, c10.w};
+      const unsigned c4[4] = {c01.x, c01.y, c01.z, c01.w}, d4[4] = {c11.x, c11.y, c11.z, c11.w};
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v[2 * t] = w00 * __uint_as_float(a4[t] << 16) + w10 * __uint_as_float(b4[t] << 16) +
+                   w01 * __uint_as_float(c4[t] << 16) + w11 * __uint_as_float(d4[t] << 16);
+        v[2 * t + 1] = w00 * __uint_as_float(a4[t] & 0xffff0000u) + w10 * __uint_as_float(b4[t] & 0xffff0000u) +
+                       w01 * __uint_as_float(c4[t] & 0xffff0000u) + w11 * __uint_as_float(d4[t] & 0xffff0000u);
+      }
+      float* dst = sc + (is_logit ? 8 * t : LP + 16 * t + 8 * part);
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0] + xa[0], v[1] + xa[1], v[2] + xa[2], v[3] + xa[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[0], v[5] + xb[1], v[6] + xb[2], v[7] + xb[3]};
+    }
+  }
+  // quad-private scratch: LDS operations of one wavefront execute in order, only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- pass 1: softmax denominator of the head's logits; the 4 lanes of the quad split the LP logits and combine
+  //      with DPP (same value in all four: the butterfly adds commute)
+  float mx = -INFINITY;
+  {
+    constexpr int MYC = (LP / 4 + 3) / 4;            // 16-byte chunks per lane
+    f32x4 lg[MYC];
+#pragma unroll
+    for (int i = 0; i < MYC; ++i) {
+      const int c = sub + 4 * i;
+      lg[i] = (c < LP / 4) ? *reinterpret_cast<const f32x4*>(sc + 4 * c) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
+    }
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xf, 0xf, false)));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xf, 0xf, false)));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MYC; ++i)     // exp(-inf) = 0 for the padding chunks
+      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
+    sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0xB1, 0xf, 0xf, false));
+    sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x4E, 0xf, 0xf, false));
+    mx += __logf(sum);
+  }
+
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+
+  {
+    // byte offset of this lane's 32-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
+    const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
+    const char* vp_bytes = reinterpret_cast<const char*>(vp);
+    // Explicit software pipeline over the LP / NB batches (a real loop: unrolled, hipcc computes all 24 samples
+    // first and spills):   gathers(it) issued  ->  coordinates(it + 1) computed under their latency  ->  blend(it)
+    unsigned cw_t, cw_b, co_t, co_b, co_x;            // this lane's sample of the batch: packed weights / pixel offsets
+    gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
+#pragma unroll 1
+    for (int it = 0; it < LP / NB; ++it) {
+      // ---- quad broadcast of the pixel offsets + 16 gathers in flight: top-left, top-right, bottom-left, bottom-right
+      uint4 raw[NB][4];
+#define MVG_QS(SS)                                                                                      \
+      {                                                                                                 \
+        const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
+        const unsigned dxs = quad_bcast<SS>(co_x);                                                      \
+        raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
+        raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs));                            \
+        raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
+        raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                            \
+      }
+      MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
+#undef MVG_QS
+      const unsigned pw_t = cw_t, pw_b = cw_b;        // this batch's weights, broadcast at blend time (fewer live VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
+      // next batch's coordinates while the gathers are in flight (the last iteration recomputes batch 0: branch-free)
+      gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned wt[NB], wb[NB];
+      wt[0] = quad_bcast<0>(pw_t); wt[1] = quad_bcast<1>(pw_t); wt[2] = quad_bcast<2>(pw_t); wt[3] = quad_bcast<3>(pw_t);
+      wb[0] = quad_bcast<0>(pw_b); wb[1] = quad_bcast<1>(pw_b); wb[2] = quad_bcast<2>(pw_b); wb[3] = quad_bcast<3>(pw_b);
+#pragma unroll
+      for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          // left / right pixel (8 channels each) -> per channel the word (left[ch], right[ch]) = the v_dot2c operand for
+          // the packed weights (w_left, w_right): 2 v_perm + 2 v_dot2c per pair of channels
+          const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);
+          const unsigned l4[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
+          const unsigned r4[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);     // (left[2t],   right[2t])
+            const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);     // (left[2t+1], right[2t+1])
+            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);
+            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}

@@ -223,7 +223,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         return self._wc.get(key, params, dtype, build)
 
     # cached operands of the fused chains (csrc/chain.hip), in the order the ops take them
-    def _chain_a_weights(self, dt):
+    def _chain_a_weights(self, dt, fused_sampler=False):
         f32 = torch.float32
         pose_layers = self.pose_embed.MLP.layers
         sw = lambda w: ops.swizzle_weight(w.to(dt))
@@ -233,7 +233,12 @@ class DQDecoderLayer(MvPDecoderLayer):
                self._w("Wpe1_sw", (pose_layers[1].weight,), dt, sw), self._w("bpe1", (pose_layers[1].bias,), f32),
                self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
         pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
-        o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
+        # o of a masked row, computed by the kernel that is going to use it (the variants reduce the last pose layer in
+        # different orders; a masked row inside a mixed tile and one in an all-masked tile must agree bit for bit)
+        if fused_sampler:
+            o_masked = self._w("o_masked_sc", pose_params, f32, lambda *_: ops.gsamp_chain_masked_row_output(*wts))
+        else:
+            o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
         return wts, o_masked
 
     def _chain_b_weights(self, dt):
@@ -271,7 +276,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             self.proj_attn.weights(dt)
         fuse_a, fuse_b = self._fuses_chains(dt)
         if fuse_a:
-            self._chain_a_weights(dt)
+            self._chain_a_weights(dt, fused_sampler=self.proj_attn.fuse_sampler_chain)
         if fuse_b:
             self._chain_b_weights(dt)
         return self
@@ -413,10 +418,15 @@ class DQDecoderLayer(MvPDecoderLayer):
                 order = ctx.order
             elif mode:
                 order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
-            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
-                                                order=order, xw=xw_in)
-            wts, o_masked = self._chain_a_weights(dt)
-            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+            if self.proj_attn.fuse_sampler_chain:       # one kernel: the sampled rows never leave the CU
+                wts, o_masked = self._chain_a_weights(dt, fused_sampler=True)
+                attn, o = self.proj_attn.native_sample_chain(x, ref_lvl, ctx.feat, ctx.levels, V, B, inside.view(-1), order,
+                                                             xw_in, wts, o_masked)
+            else:
+                samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
+                                                    order=order, xw=xw_in)
+                wts, o_masked = self._chain_a_weights(dt)
+                attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
             attn = self.proj_attn.native_forward(x(), ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
 

@@ -92,6 +92,12 @@ class ProjAttn(nn.Module):
         self.use_fast_path = True
         # bf16 fast path: sample the pairs in image-space (Morton) order.  "layer"/True: binned per layer; "first":
         # DQDecoderLayer bins once per forward (first layer) and reuses the order; False: query order
+        # bf16 fast path: sampler and chain A as ONE kernel (csrc/sampchain.hip) instead of two launches.  Built, bit-exact
+        # against the two-kernel form, and measured SLOWER on MI355X (cfg-2: 197 us vs 138 + 38 us per layer; its gather
+        # phase alone takes 175 us: 16 instead of 20 waves per CU and a workgroup barrier in front of the chain phase cost
+        # more than the 20 us of chain A that do hide under the other workgroup's gathers) -- so it is off by default;
+        # MVG_FUSE_SAMPLER=1 selects it.
+        self.fuse_sampler_chain = os.environ.get("MVG_FUSE_SAMPLER", "0") == "1"
         self.sort_pairs = os.environ.get("MVG_SORT_PAIRS", "layer")
         if self.sort_pairs in ("0", "off", "False"):
             self.sort_pairs = False
@@ -240,6 +246,19 @@ class ProjAttn(nn.Module):
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
         value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
         return ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
+
+    def native_sample_chain(self, x, r, feat, levels, V, B, inside, order, xw, chain_weights, o_masked):
+        """bf16 fast path of native_sample with chain A (output projection x in-image mask, pose MLP) fused into the
+        sampling kernel (csrc/sampchain.hip): returns (attn (V*B*Lq, 256) bf16, o (V*B*Lq, 3) f32)."""
+        dt = feat.dtype
+        assert self.uses_fast_path(dt)
+        if order is None and self.sort_pairs and r.shape[1] <= 65536:
+            order = ops.bin_pairs(r, inside, levels)
+        if xw is None:
+            Wq, bq = self._fast_query_weights(dt)
+            xw = ops.linear((x() if callable(x) else x).reshape(-1, feat.shape[2]), Wq, bq, out_dtype=torch.float32)
+        vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
+        return ops.msda_gsamp_chain(vp, G, xw, r, levels, B, inside, order, *chain_weights, o_masked=o_masked)
 
     # ------------------------------------------------------------------------------- forward
     def forward(self, query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,

@@ -31,7 +31,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n== PMC (mean per dispatch)")
 for k in sorted(acc, key=lambda k: -sum(acc[k].get("GRBM_GUI_ACTIVE", [0]))):
-    if not any(s in k for s in ("msda", "linear", "chain", "wreg", "gather", "triang", "pack", "add_ln", "mean_views", "class_head", "rowdot", "project")):
+    if not any(s in k for s in ("msda", "samp_chain", "linear", "chain", "wreg", "gather", "triang", "pack", "add_ln", "mean_views", "class_head", "rowdot", "project")):
         continue
     print(k)
     for c in sorted(acc[k]):
@@ -61,7 +61,7 @@ for k in sorted(acc, key=lambda k: -dur.get(k, 0)):
 # ---- machine-readable HBM-side traffic of the dominant kernel (read by bench.py -> roofline.traffic)
 import json
 for k in acc:
-    if k.startswith("msda_gsamp_kernel") and "FETCH_SIZE" in acc[k]:
+    if (k.startswith("samp_chain_kernel") or k.startswith("msda_gsamp_kernel")) and "FETCH_SIZE" in acc[k]:
         fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
         write_kb = sum(acc[k].get("WRITE_SIZE", [0])) / max(len(acc[k].get("WRITE_SIZE", [0])), 1)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
