@@ -248,6 +248,14 @@ int mvg_triangulate(const float* r, const float* o, const float* cams, const uin
                     const int* any_valid, float* new_ref, float* ref2d, float* proj2d,
                     int V, int B, int NQ, int J, void* stream);
 
+/* mvg_triangulate + the NEXT layer's mvg_project in one launch: the lanes that solved a (query, joint) problem project
+ * its new 3D point (zeros for queries that did not pass, exactly what the next layer receives as reference_points) into
+ * all V views -> r_next (V*B,Lq,2), ref_lvl_next (V*B,Lq,L,2), inside_next (V*B,Lq), bit-identical to mvg_project(new_ref). */
+int mvg_triangulate_project(const float* r, const float* o, const float* cams, const uint8_t* valid,
+                            const int* any_valid, float* new_ref, float* ref2d, float* proj2d,
+                            int V, int B, int NQ, int J, const int64_t* shapes_host, int L,
+                            float* r_next, float* ref_lvl_next, uint8_t* inside_next, void* stream);
+
 /* Batched eigen-decomposition of n symmetric 4x4 fp64 matrices G (n,4,4): evals (n,4) in no particular order, evecs
  * (n,4,4) with the eigenvectors as columns (G v_k = evals_k v_k, v_k = evecs[:, :, k]).  fp64 cyclic Jacobi, one lane
  * per matrix.  Used by the differentiable DLT of the training path (multiview.py:170-228 under autograd): smallest

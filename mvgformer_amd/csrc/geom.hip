@@ -46,18 +46,11 @@ __global__ __launch_bounds__(256) void pack_level_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------
 // A.1 projection: pinhole + radial/tangential distortion, in-image test, clamp, crop affine.
-__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ X, const float* __restrict__ cams,
-                                                      LevelTable lv, float* __restrict__ r,
-                                                      float* __restrict__ ref_lvl, uint8_t* __restrict__ inside,
-                                                      int B, int Lq, long total) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int q = (int)(idx % Lq);
-  const int n = (int)(idx / Lq);
-  const int b = n % B;
-  const float* cam = cams + (long)n * MVG_CAM_STRIDE;
-  const float* xp = X + ((long)b * Lq + q) * 3;
-  const float d0 = xp[0] - cam[9], d1 = xp[1] - cam[10], d2 = xp[2] - cam[11];   // cameras.py:188
+// one (image n, token q) projection of the point (x0, x1, x2) [mm]; idx = n * Lq + q
+__device__ __forceinline__ void project_point(const float x0, const float x1, const float x2, const float* __restrict__ cam,
+                                              const LevelTable& lv, float* __restrict__ r, float* __restrict__ ref_lvl,
+                                              uint8_t* __restrict__ inside, const long idx) {
+  const float d0 = x0 - cam[9], d1 = x1 - cam[10], d2 = x2 - cam[11];   // cameras.py:188
   const float xc0 = cam[0] * d0 + cam[1] * d1 + cam[2] * d2;
   const float xc1 = cam[3] * d0 + cam[4] * d1 + cam[5] * d2;
   const float xc2 = cam[6] * d0 + cam[7] * d1 + cam[8] * d2;
@@ -85,6 +78,19 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
     ref_lvl[(idx * lv.L + l) * 2 + 1] = (ry * Hf) / (Hf - 1.f);
   }
   inside[idx] = in_img ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ X, const float* __restrict__ cams,
+                                                      LevelTable lv, float* __restrict__ r,
+                                                      float* __restrict__ ref_lvl, uint8_t* __restrict__ inside,
+                                                      int B, int Lq, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % Lq);
+  const int n = (int)(idx / Lq);
+  const int b = n % B;
+  const float* xp = X + ((long)b * Lq + q) * 3;
+  project_point(xp[0], xp[1], xp[2], cams + (long)n * MVG_CAM_STRIDE, lv, r, ref_lvl, inside, idx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -339,8 +345,12 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
                                                           const uint8_t* __restrict__ valid,
                                                           const int* __restrict__ any_valid,
                                                           float* __restrict__ new_ref, float* __restrict__ ref2d,
-                                                          float* __restrict__ proj2d, int V, int B, int NQ, int J) {
+                                                          float* __restrict__ proj2d, int V, int B, int NQ, int J,
+                                                          LevelTable lv, float* __restrict__ r_next,
+                                                          float* __restrict__ ref_lvl_next,
+                                                          uint8_t* __restrict__ inside_next) {
   __shared__ double gram[10][TRI_PROBS][TRI_PAD];
+  __shared__ float xnew[TRI_PROBS][3];
   const int tid = threadIdx.x, pl = tid >> 3, sub = tid & 7;
   const int Lq = NQ * J;
   const long nprob = (long)B * Lq;
@@ -353,12 +363,23 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
     bool ok = valid[b * NQ + i] != 0;
     if (!ok && any_valid[0] == 0 && b == 0 && i == 0) ok = true;   // dq_decoder.py:620-623
 
+    // Everything this lane needs is REQUESTED first -- validity, and per view of the lane (views sub, sub + 8, ...; the first
+    // one held in registers) the three pose outputs, the reference point and the camera record -- so that the kernel pays one
+    // memory round trip, not a chain of them (logits -> softmax -> per-view loads): it runs on 240 wavefronts' latency.
+    const long pair0 = ((long)min(sub, V - 1) * B + b) * Lq + q;
+    const float* cam0 = cams + ((long)min(sub, V - 1) * B + b) * MVG_CAM_STRIDE;
+    const float o0x = o[pair0 * 3], o0y = o[pair0 * 3 + 1], o0l = o[pair0 * 3 + 2];
+    const float2 r0 = *reinterpret_cast<const float2*>(r + pair0 * 2);
+    float camr[40];
+#pragma unroll
+    for (int k = 0; k < 40; k += 4) *reinterpret_cast<f32x4*>(&camr[k]) = *reinterpret_cast<const f32x4*>(cam0 + k);
+
     // softmax over views of the confidence logit (dq_decoder.py:706-707)
-    float mx = -INFINITY;
-    for (int v = sub; v < V; v += 8) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
+    float mx = sub < V ? o0l : -INFINITY;
+    for (int v = sub + 8; v < V; v += 8) mx = fmaxf(mx, o[(((long)v * B + b) * Lq + q) * 3 + 2]);
     mx = max8(mx);
-    float den = 0.f;
-    for (int v = sub; v < V; v += 8) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
+    float den = sub < V ? expf(o0l - mx) : 0.f;
+    for (int v = sub + 8; v < V; v += 8) den += expf(o[(((long)v * B + b) * Lq + q) * 3 + 2] - mx);
     den = add8(den);
 
     double G[10];
@@ -367,11 +388,20 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
 
     for (int v = sub; v < V; v += 8) {
       const long pair = ((long)v * B + b) * Lq + q;
-      const float* cam = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
+      const bool first = v == sub;
+      float cam[40];
+      if (first) {
+#pragma unroll
+        for (int k = 0; k < 40; ++k) cam[k] = camr[k];
+      } else {
+        const float* cp = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 40; k += 4) *reinterpret_cast<f32x4*>(&cam[k]) = *reinterpret_cast<const f32x4*>(cp + k);
+      }
       const float imgw = cam[36], imgh = cam[37];
-      const float rx = r[pair * 2], ry = r[pair * 2 + 1];
-      const float dx = o[pair * 3], dy = o[pair * 3 + 1];
-      const float conf = expf(o[pair * 3 + 2] - mx) / den;
+      const float rx = first ? r0.x : r[pair * 2], ry = first ? r0.y : r[pair * 2 + 1];
+      const float dx = first ? o0x : o[pair * 3], dy = first ? o0y : o[pair * 3 + 1];
+      const float conf = expf((first ? o0l : o[pair * 3 + 2]) - mx) / den;
       const float px = rx * imgw, py = ry * imgh;                                   // dq_decoder.py:699
       const float kx = (rx + dx / imgw) * imgw, ky = (ry + dy / imgh) * imgh;       // :679-685,696
       if (live) {
@@ -423,11 +453,9 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
     for (int e = 0; e < 10; ++e) gram[e][pl][sub] = G[e];
   }
   __syncthreads();
-  if (tid >= TRI_PROBS) return;
-
   // ---- phase 2: one lane per problem
+  if (tid < TRI_PROBS && (long)blockIdx.x * TRI_PROBS + tid < nprob) {
   const long idx = (long)blockIdx.x * TRI_PROBS + tid;
-  if (idx >= nprob) return;
   const int q = (int)(idx % Lq), b = (int)(idx / Lq);
   const int i = q / J;
   bool ok = valid[b * NQ + i] != 0;
@@ -447,32 +475,58 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
       }
   }
 
-  double Vm[4][4];
+  double ev[4];
+  {
+    double Vm[4][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Vm[a][c] = (a == c) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 12; ++sweep) {
-    const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
-    const double lg = fmax(fmax(fabs(G[0][0]), fabs(G[1][1])), fmax(fabs(G[2][2]), fabs(G[3][3])));
-    if (off <= 2e-16 * lg) break;     // off-diagonals at the fp64 rounding floor of the matrix: converged
-    jacobi_rotate2(G, Vm, 0, 1, 2, 3);
-    jacobi_rotate2(G, Vm, 0, 2, 1, 3);
-    jacobi_rotate2(G, Vm, 0, 3, 1, 2);
-  }
-  double best = G[0][0];
-  double e0 = Vm[0][0], e1 = Vm[1][0], e2 = Vm[2][0], e3 = Vm[3][0];
+      for (int c = 0; c < 4; ++c) Vm[a][c] = (a == c) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
+      const double lg = fmax(fmax(fabs(G[0][0]), fabs(G[1][1])), fmax(fabs(G[2][2]), fabs(G[3][3])));
+      if (off <= 2e-16 * lg) break;     // off-diagonals at the fp64 rounding floor of the matrix: converged
+      jacobi_rotate2(G, Vm, 0, 1, 2, 3);
+      jacobi_rotate2(G, Vm, 0, 2, 1, 3);
+      jacobi_rotate2(G, Vm, 0, 3, 1, 2);
+    }
+    double best = G[0][0];
+    ev[0] = Vm[0][0]; ev[1] = Vm[1][0]; ev[2] = Vm[2][0]; ev[3] = Vm[3][0];
 #pragma unroll
-  for (int c = 1; c < 4; ++c) {
-    if (G[c][c] < best) {
-      best = G[c][c];
-      e0 = Vm[0][c]; e1 = Vm[1][c]; e2 = Vm[2][c]; e3 = Vm[3][c];
+    for (int c = 1; c < 4; ++c) {
+      if (G[c][c] < best) {
+        best = G[c][c];
+        ev[0] = Vm[0][c]; ev[1] = Vm[1][c]; ev[2] = Vm[2][c]; ev[3] = Vm[3][c];
+      }
     }
   }
+  const float X0 = ok ? (float)(ev[0] / ev[3]) : 0.f;                               // multiview.py:220-221
+  const float X1 = ok ? (float)(ev[1] / ev[3]) : 0.f;
+  const float X2 = ok ? (float)(ev[2] / ev[3]) : 0.f;
   float* nr = new_ref + ((long)b * Lq + q) * 3;
-  nr[0] = ok ? (float)(e0 / e3) : 0.f;                                            // multiview.py:220-221
-  nr[1] = ok ? (float)(e1 / e3) : 0.f;
-  nr[2] = ok ? (float)(e2 / e3) : 0.f;
+  nr[0] = X0;
+  nr[1] = X1;
+  nr[2] = X2;
+  xnew[tid][0] = X0;
+  xnew[tid][1] = X1;
+  xnew[tid][2] = X2;
+  }
+  if (!r_next) return;                  // uniform: the caller does not want the next layer's projections
+  // ---- phase 3: the NEXT layer's projection of the new points (project_kernel's arithmetic on new_ref, which is what the
+  //      next layer receives as reference_points: zeros for queries that did not pass, dq_decoder.py:1013-1029), by the
+  //      8 lanes of each problem: lane `sub` takes views sub, sub + 8, ...
+  __syncthreads();
+  {
+    const long idx = (long)blockIdx.x * TRI_PROBS + pl;
+    if (idx < nprob) {
+      const int q = (int)(idx % Lq), b = (int)(idx / Lq);
+      const float x0 = xnew[pl][0], x1 = xnew[pl][1], x2 = xnew[pl][2];
+      for (int v = sub; v < V; v += 8) {
+        const long n = (long)v * B + b;
+        project_point(x0, x1, x2, cams + n * MVG_CAM_STRIDE, lv, r_next, ref_lvl_next, inside_next, n * Lq + q);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -872,15 +926,36 @@ int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, fl
   return 0;
 }
 
-int mvg_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
-                    float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J, void* stream) {
+static int launch_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
+                              float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J, const LevelTable& lv,
+                              float* r_next, float* ref_lvl_next, uint8_t* inside_next, void* stream) {
   if (!r || !o || !cams || !valid || !any_valid || !new_ref || !ref2d || !proj2d || V <= 0) return MVG_E_BADARG;
   const long nprob = (long)B * NQ * J;            // 64 problems per 512-thread workgroup (8 lanes each in phase 1)
   if (nprob == 0) return 0;
   hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(nprob, TRI_PROBS)), dim3(512), 0, (hipStream_t)stream, r, o, cams,
-                     valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J);
+                     valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, r_next, ref_lvl_next, inside_next);
   MVG_LAUNCH_CHECK();
   return 0;
+}
+
+int mvg_triangulate(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
+                    float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J, void* stream) {
+  LevelTable lv = {};
+  return launch_triangulate(r, o, cams, valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, nullptr, nullptr, nullptr,
+                            stream);
+}
+
+int mvg_triangulate_project(const float* r, const float* o, const float* cams, const uint8_t* valid, const int* any_valid,
+                            float* new_ref, float* ref2d, float* proj2d, int V, int B, int NQ, int J,
+                            const int64_t* shapes_host, int L, float* r_next, float* ref_lvl_next, uint8_t* inside_next,
+                            void* stream) {
+  if (!shapes_host || !r_next || !ref_lvl_next || !inside_next) return MVG_E_BADARG;
+  LevelTable lv;
+  int64_t zeros[MVG_MAX_LEVELS] = {0};
+  int e = mvg_fill_levels(&lv, shapes_host, zeros, L);
+  if (e) return e;
+  return launch_triangulate(r, o, cams, valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, r_next, ref_lvl_next,
+                            inside_next, stream);
 }
 
 int mvg_sym4_eigh(const double* G, double* evals, double* evecs, long n, void* stream) {

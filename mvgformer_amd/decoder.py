@@ -174,6 +174,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.d_model = d_model
         self.compute_dtype = torch.float32
         self.use_fused_chains = True    # bf16 inference: LDS-resident Linear chains (csrc/chain.hip)
+        self.fuse_boundary = True       # the triangulation launch also projects the new points for the next layer
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
@@ -181,6 +182,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self._geo_out = None   # set by DQDecoder.forward: this layer's slices of the stacked 3D / 2D outputs
         self._next_layer = None   # set by DQDecoder.forward: the layer that consumes this layer's output
         self._xw_in = None        # set by the previous layer: this layer's query term (B*Lq,192) f32
+        self._proj_in = None      # set by the previous layer's triangulation launch: (new_ref, (r, ref_lvl, inside)) of this layer
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
         # "no query valid anywhere -> force query (0,0)" rule (dq_decoder.py:620-623) global
         self._any_valid_hook = None
@@ -397,7 +399,11 @@ class DQDecoderLayer(MvPDecoderLayer):
 
         # 1. projective attention features of every view (generate_features, dq_decoder.py:516-593)
         X = reference_points.detach().reshape(B, Lq, 3).float().contiguous()
-        r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
+        proj_in, self._proj_in = self._proj_in, None
+        if proj_in is not None and proj_in[0].data_ptr() == X.data_ptr() and tuple(proj_in[0].shape) == tuple(X.shape):
+            r, ref_lvl, inside = proj_in[1]      # projected by the previous layer's triangulation launch (same arithmetic)
+        else:
+            r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
         x = lambda: self.with_pos_embed(tgt.float(), None if query_pos is None else query_pos.float()).contiguous()
         xw_in, self._xw_in = self._xw_in, None     # query term computed by the previous layer's chain B (or None)
         if xw_in is not None and tuple(xw_in.shape) != (B * Lq, 192):
@@ -488,8 +494,14 @@ class DQDecoderLayer(MvPDecoderLayer):
     def forward_triangulate(self, st, ctx):
         """step 5: triangulation + scatter (learnable_triangulate, dq_decoder.py:399-461,1013-1029)."""
         V, B, NQ, J = st["dims"]
-        new_ref, ref2d, proj2d = ops.triangulate(st["r"], st["o"], ctx.cams, st["valid"], st["any_valid"], V, B, NQ, J,
-                                                 out=self._geo_out)
+        nxt = self._next_layer[0] if (self._next_layer and self.fuse_boundary) else None
+        if nxt is not None:      # the next layer's projection of the new points rides on this launch
+            new_ref, ref2d, proj2d, proj = ops.triangulate(st["r"], st["o"], ctx.cams, st["valid"], st["any_valid"], V, B, NQ,
+                                                           J, out=self._geo_out, next_levels=ctx.levels)
+            nxt._proj_in = (new_ref, proj)
+        else:
+            new_ref, ref2d, proj2d = ops.triangulate(st["r"], st["o"], ctx.cams, st["valid"], st["any_valid"], V, B, NQ, J,
+                                                     out=self._geo_out)
         return st["tgt_update"], new_ref, ref2d, proj2d, st["prob"]
 
 
@@ -654,6 +666,7 @@ class DQDecoder(MvPDecoder):
                 layer._geo_out = None
                 layer._next_layer = None
                 layer._xw_in = None
+                layer._proj_in = None
             self.join_pyramid_projections(side)
         if self.return_intermediate:
             in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape

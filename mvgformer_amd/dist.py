@@ -211,6 +211,7 @@ class GraphedShardedDecoder:
         for layer in layers:
             layer._next_layer = None
             layer._xw_in = None
+            layer._proj_in = None
             layer.proj_attn._vp_event = None
         self.send, self.geo = res
         self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
@@ -281,6 +282,7 @@ class SpeculativeShardedDecoder:
             for layer in layers:
                 layer._next_layer = None
                 layer._xw_in = None
+                layer._proj_in = None
                 layer.proj_attn._vp_event = None
         self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
         self.unpack = torch.cuda.CUDAGraph()

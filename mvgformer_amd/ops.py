@@ -451,9 +451,10 @@ def rowdot3(h, W3, b3):
     return o
 
 
-def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J, out=None):
+def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J, out=None, next_levels=None):
     """out: optional caller-owned (new_ref (B,Lq,3), ref2d (B,V,Lq,2), proj2d (B,V,Lq,2)) contiguous f32 destinations
-    (e.g. slices of the stacked per-layer outputs)."""
+    (e.g. slices of the stacked per-layer outputs).  next_levels (a Levels): also project the new points for the next
+    layer in the same launch -> returns (new_ref, ref2d, proj2d, (r_next, ref_lvl_next, inside_next))."""
     Lq = NQ * J
     dev = r.device
     if out is not None:
@@ -464,6 +465,17 @@ def triangulate(r, o, cams, valid, any_valid, V, B, NQ, J, out=None):
         new_ref = torch.empty((B, Lq, 3), dtype=torch.float32, device=dev)
         ref2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
         proj2d = torch.empty((B, V, Lq, 2), dtype=torch.float32, device=dev)
+    if next_levels is not None:
+        lv = next_levels
+        r_n = torch.empty((V * B, Lq, 2), dtype=torch.float32, device=dev)
+        ref_n = torch.empty((V * B, Lq, lv.L, 2), dtype=torch.float32, device=dev)
+        in_n = torch.empty((V * B, Lq), dtype=torch.uint8, device=dev)
+        with _timed("triangulate_project"):
+          L.check(L.load().mvg_triangulate_project(L.ptr(r), L.ptr(o), L.ptr(cams), L.ptr(valid), L.ptr(any_valid),
+                                                   L.ptr(new_ref), L.ptr(ref2d), L.ptr(proj2d), V, B, NQ, J, lv.shapes_c, lv.L,
+                                                   L.ptr(r_n), L.ptr(ref_n), L.ptr(in_n), L.stream_ptr()),
+                  "mvg_triangulate_project")
+        return new_ref, ref2d, proj2d, (r_n, ref_n, in_n)
     with _timed("triangulate"):
       L.check(L.load().mvg_triangulate(L.ptr(r), L.ptr(o), L.ptr(cams), L.ptr(valid), L.ptr(any_valid), L.ptr(new_ref),
                                      L.ptr(ref2d), L.ptr(proj2d), V, B, NQ, J, L.stream_ptr()), "mvg_triangulate")

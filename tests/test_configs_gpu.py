@@ -467,3 +467,40 @@ def test_fused_sampler_chain_kernel_equals_the_two_kernel_form():
         e_px = float((fused[2][0] - two_default[2][0]).abs().max())
         print("%s: fused vs default two-kernel chain A, layer 0: |hs| %.2e  2D %.2e px" % (case.name, e_hs, e_px))
         assert e_hs < 2e-2 and e_px < 2e-2
+
+
+def test_triangulation_launch_also_projects_for_the_next_layer():
+    """mvg_triangulate_project: the next layer's (r, ref_lvl, inside) written by the triangulation launch are bit-identical to
+    mvg_project run on the new reference points (zeros for queries that did not pass included), and the triangulated points
+    equal mvg_triangulate's; the decoder with and without the fused boundary gives identical outputs."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from tests.golden.cases import LAYER_CASES
+    for cname in ("mini5_half", "mini5_b2"):
+        sp = LAYER_CASES[cname]
+        case = build_case(sp["config"], B=sp.get("B", 1), seed=sp["seed"], NQ=sp.get("NQ"), layers=sp["layers"],
+                          valid_fraction=sp.get("valid_fraction"))
+        g = case_to_device(case, DEV)
+        B, NQ, J, V = case.B, case.NQ, 15, case.V
+        ctx = DecoderContext.build(g.src_views, g.spatial_shapes, g.level_start_index, g.meta, case.img_size, torch.float32, B)
+        gen = torch.Generator().manual_seed(4)
+        X = g.reference_points.reshape(B, NQ * J, 3).contiguous()
+        r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
+        o = (torch.randn((V * B * NQ * J, 3), generator=gen) * torch.tensor([3.0, 3.0, 1.0])).to(DEV)
+        valid = (torch.rand((B, NQ), generator=gen) > 0.4).to(torch.uint8).to(DEV)
+        flag = torch.ones((1,), dtype=torch.int32, device=DEV)
+        a = ops.triangulate(r, o, ctx.cams, valid, flag, V, B, NQ, J)
+        b = ops.triangulate(r, o, ctx.cams, valid, flag, V, B, NQ, J, next_levels=ctx.levels)
+        assert all(torch.equal(x, y) for x, y in zip(a, b[:3]))
+        want = ops.project(b[0], ctx.cams, ctx.levels, V, B)
+        assert all(torch.equal(x, y) for x, y in zip(want, b[3]))
+        assert int((b[0].abs().sum(-1) == 0).sum()) >= int((valid == 0).sum()) * J       # masked queries project the origin
+        for dt in (torch.float32, torch.bfloat16):
+            dec = build_decoder_for_case(case, DEV, dtype=dt)
+            fused = _run(dec, g)
+            for layer in dec.layers:
+                layer.fuse_boundary = False            # separate mvg_project launch per layer
+            plain = _run(dec, g)
+            for k in range(4):
+                assert torch.equal(fused[k], plain[k]), (cname, str(dt), k)
