@@ -102,6 +102,21 @@ int mvg_msda_backward_f32(const float* value, const int64_t* spatial_shapes,
                           float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                           int N, int S, int M, int D, int L, int Lq, int P, void* stream);
 
+/* Deterministic, atomics-free-in-fp32 form of mvg_msda_backward_f32 for D = 32 (csrc/msda_bwd.hip): the samples are binned
+ * by destination tile, a workgroup per tile gathers its value patch into LDS and accumulates grad_value there as 64-bit
+ * fixed-point integers (integer addition is associative: no dependence on the order of arrival), grad_sampling_loc /
+ * grad_attn_weight are reduced over the 32 channels with a fixed shuffle tree.  Bit-reproducible run to run; every output is
+ * fully overwritten (grad_value need not be zero-filled).  workspace: device scratch of
+ * mvg_msda_backward_det_workspace(...) bytes (0 = shape not supported: D != 32, L*P > 256, Lq >= 2^24 -- use the
+ * atomic form).  shapes_host / starts_host: HOST int64 arrays (the level table is a kernel argument here).
+ * Non-finite entries of grad_output are not propagated into grad_value (the fixed-point scale is the largest finite |g|). */
+size_t mvg_msda_backward_det_workspace(int N, int S, int M, int D, int L, int Lq, int P, const int64_t* shapes_host);
+int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, const int64_t* starts_host,
+                              const float* sampling_loc, const float* attn_weight, const float* grad_output,
+                              float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                              int N, int S, int M, int D, int L, int Lq, int P,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- stage entry points of the decoder layer ------------------------------------------ */
 
 /* (N_img,C,H,W) NCHW level -> rows [start, start+H*W) of the channels-last pyramid

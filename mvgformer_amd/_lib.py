@@ -25,6 +25,8 @@ SIGNATURES = {
     "mvg_msda_forward_f32": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_forward_bf16": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_backward_f32": [_vp] * 9 + [_i] * 7 + [_vp],
+    "mvg_msda_backward_det_workspace": [_i] * 7 + [_vp],
+    "mvg_msda_backward_det_f32": [_vp] * 9 + [_i] * 7 + [_vp, C.c_size_t, _vp],
     "mvg_msda_forward_f64": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_backward_f64": [_vp] * 9 + [_i] * 7 + [_vp],
     "mvg_pack_level": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -72,6 +74,7 @@ def load():
         fn.restype = C.c_int
     lib.mvg_version.restype = C.c_char_p
     lib.mvg_bin_pairs_workspace.restype = C.c_size_t
+    lib.mvg_msda_backward_det_workspace.restype = C.c_size_t
     lib.mvg_version.argtypes = []
     _lib = lib
     # A/B knobs for measurements: MVG_TUNE="chain_rm=128,gsamp_threads=256"

@@ -1,0 +1,447 @@
+// Deterministic backward of the multi-scale deformable sampling op for gfx950 (D = 32 channels per head).
+//
+// Reference: deform_cuda.cu:94-164 + cuh:312-413 -- one thread per (query, head, channel) walks its L*P samples and
+// atomicAdd's four bilinear contributions per sample into grad_value (fp32 global atomics; the D = 32 variant at least
+// reduces grad_sampling_loc / grad_attn_weight in shared memory).  The drop-in of round 1 (msda_bwd_kernel, csrc/msda.hip)
+// did the same with wavefront shuffles: 377 M fp32 global atomics per cfg-2 view-layer, 988 us, and a grad_value whose
+// last bits depend on the order the atomics happen to land in.
+//
+// Here grad_value is a GATHER problem solved in LDS, and every sum is order-independent:
+//   1. the samples are binned by DESTINATION: key = (image, level tile of T x T pixels, head) of the sample's upper-left
+//      corner pixel (bin_count -> exclusive scan -> bin_scatter; integer atomics only, and the order inside a bin does not
+//      matter, see 3.);
+//   2. one workgroup per non-empty bin loads the (T+1) x (T+1) x 32 value patch of its tile into LDS -- the four corners of
+//      every sample of the bin are inside it, so grad_sampling_loc / grad_attn_weight need no global gather at all --, and
+//      keeps a (T+1) x (T+1) x 32 accumulator patch next to it;
+//   3. 8 samples x 32 channels per pass: thread c reads grad_output[q, m, c] (128 contiguous bytes per sample), adds its
+//      four corner contributions to the LDS accumulator as 64-bit FIXED-POINT integers (ds_add_u64: integer addition is
+//      associative, so the result does not depend on which wavefront gets there first), reduces the two location gradients
+//      and the weight gradient over the 32 channels with a fixed shuffle tree and writes them (one writer per sample);
+//   4. the patch is added to a global 64-bit accumulator (integer atomics again: neighbouring tiles share their border
+//      pixels), and a last pass converts it to the fp32 grad_value.
+// Fixed point: contributions are bounded by gmax = max |grad_output| (bilinear and attention weights <= 1); they are scaled
+// by 2^30 / gmax and rounded to an int32 (exact: fp32 carries 24 bits), then summed as 64-bit integers -- no overflow before
+// 2^33 contributions per pixel, each rounded to 2^-31 gmax, 2^7 times finer than the fp32 rounding (relative to a sum of
+// the size of gmax) of the atomics it replaces.  Everything is bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int BW_T = 8;                   // tile edge (pixels); the LDS patch is (T+1)^2 pixels
+constexpr int BW_P = BW_T + 1;
+constexpr int BW_D = 32;
+constexpr int BW_NT = 256;                // 8 samples x 32 channels per pass
+constexpr int BW_SPLIT = 1;               // workgroups per bin (interleaved over its entries); 8 measured slower (584 vs 482 us)
+constexpr float BW_FIX = 1073741824.f;     // 2^30: a contribution (|.| <= max |grad_output|) is an exact int32
+
+struct BwLevels {
+  int H[MVG_MAX_LEVELS], W[MVG_MAX_LEVELS], start[MVG_MAX_LEVELS];
+  int tiles_w[MVG_MAX_LEVELS], tile0[MVG_MAX_LEVELS + 1];      // tiles per row, first tile of a level
+  int L, T_total;
+};
+
+// the reference's sample test and upper-left pixel (cuh:295-301); returns false for samples that contribute nothing
+__device__ __forceinline__ bool sample_anchor(const float lx, const float ly, const int H, const int W, float& h_im, float& w_im,
+                                              int& h_low, int& w_low) {
+  h_im = ly * (float)H - 0.5f;
+  w_im = lx * (float)W - 0.5f;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return false;   // also NaN
+  h_low = (int)floorf(h_im);
+  w_low = (int)floorf(w_im);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bw_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fabsf(v[k]);
+      m = (a > m && a < INFINITY) ? a : m;      // NaN / Inf do not set the scale
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float a = fabsf(x[4 * n4 + threadIdx.x]);
+    m = (a > m && a < INFINITY) ? a : m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __shared__ float wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {                                   // one atomic per workgroup (4096 on one address took 40 us)
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));        // non-negative floats order like their bit patterns
+  }
+}
+
+// Binning = a counting sort of the samples by (tile, head) per image, WITHOUT global atomics (2.9 M atomics on ~5 000
+// counters serialise on their hot cache lines: 808 us per pass in the first version).  The samples of an image are cut into
+// BW_PARTS contiguous parts; a workgroup histograms its part in LDS (bw_part_kernel<0>), a second kernel turns the (part, bin)
+// counts into exclusive prefixes over the parts and per-bin totals, a one-workgroup scan of the totals gives the bin
+// offsets, and bw_part_kernel<1> replays the part with LDS cursors.  The order inside a bin is whatever the LDS atomics
+// produce: irrelevant, every sum downstream is order-independent.
+constexpr int BW_PARTS = 128;
+constexpr int BW_MAX_BPI = 12288;         // bins per image that fit the LDS histogram (48 KB)
+
+// sample s of image n (s = (q * M + m) * LP + lp) -> its bin inside the image (tile * M + m), or -1
+__device__ __forceinline__ int sample_bin(const float* __restrict__ loc, const BwLevels& lv, long n, long s, int Lq, int M, int P,
+                                          int LP) {
+  const int lp = (int)(s % LP);
+  const int m = (int)((s / LP) % M);
+  const int l = lp / P;
+  const float2 xy = *reinterpret_cast<const float2*>(loc + (n * (long)Lq * M * LP + s) * 2);
+  float h_im, w_im;
+  int h_low, w_low;
+  if (!sample_anchor(xy.x, xy.y, lv.H[l], lv.W[l], h_im, w_im, h_low, w_low)) return -1;
+  return (lv.tile0[l] + (max(h_low, 0) / BW_T) * lv.tiles_w[l] + max(w_low, 0) / BW_T) * M + m;
+}
+
+// MODE 0: cnt[(n * PARTS + part) * bpi + bin] = samples of the part in the bin.
+// MODE 1: cnt holds the part's first position of every bin (bw_prefix_kernel + bin offsets); writes list.
+template <int MODE>
+__global__ __launch_bounds__(1024) void bw_part_kernel(const float* __restrict__ loc, BwLevels lv, int* __restrict__ cnt,
+                                                       const int* __restrict__ offset, unsigned* __restrict__ list, int Lq, int M,
+                                                       int P, int bpi, long per_img, long chunk) {
+  extern __shared__ int hist[];
+  const int n = blockIdx.x / BW_PARTS, part = blockIdx.x % BW_PARTS, tid = threadIdx.x;
+  int* mine = cnt + ((long)n * BW_PARTS + part) * bpi;
+  for (int i = tid; i < bpi; i += 1024) hist[i] = MODE == 0 ? 0 : mine[i] + offset[(long)n * bpi + i];
+  __syncthreads();
+  const long s0 = part * chunk, s1 = min(per_img, s0 + chunk);
+  const int LP = lv.L * P;
+  for (long s = s0 + tid; s < s1; s += 1024) {
+    const int bin = sample_bin(loc, lv, n, s, Lq, M, P, LP);
+    if (bin < 0) continue;
+    const int pos = atomicAdd(&hist[bin], 1);
+    if (MODE == 1) list[pos] = ((unsigned)(s / ((long)M * LP)) << 8) | (unsigned)(s % LP);      // (q, lp); m is the bin's
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    for (int i = tid; i < bpi; i += 1024) mine[i] = hist[i];
+  }
+}
+
+// per (image, bin): exclusive prefix of the counts over the parts (in place) and the bin total
+__global__ __launch_bounds__(256) void bw_prefix_kernel(int* __restrict__ cnt, int* __restrict__ total, int bpi) {
+  const int n = blockIdx.y, bin = blockIdx.x * 256 + threadIdx.x;
+  if (bin >= bpi) return;
+  int* c = cnt + (long)n * BW_PARTS * bpi + bin;
+  int run = 0;
+#pragma unroll 8
+  for (int p = 0; p < BW_PARTS; ++p) {
+    const int v = c[(long)p * bpi];
+    c[(long)p * bpi] = run;
+    run += v;
+  }
+  total[(long)n * bpi + bin] = run;
+}
+
+// exclusive scan of the bin totals over all images (one workgroup; a few 10 000 entries): offset[i], offset[nb] = all
+__global__ __launch_bounds__(1024) void bw_scan_kernel(const int* __restrict__ total, int* __restrict__ offset, int nb) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024 * 4) {
+    int v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + tid * 4 + k;
+      v[k] = i < nb ? total[i] : 0;
+      s += v[k];
+    }
+    int incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if ((tid & 63) >= d) incl += up;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int t = wsum[w];
+      wbase += (w < (tid >> 6)) ? t : 0;
+      tot += t;
+    }
+    int ex = carry + wbase + incl - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + tid * 4 + k;
+      if (i < nb) offset[i] = ex;
+      ex += v[k];
+    }
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) offset[nb] = carry;
+}
+
+// sum over the 32 lanes of a half wavefront (result in all of them), fixed order: quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror (DPP, full rate), then one exchange with the other 16-lane row
+__device__ __forceinline__ float sum32(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+  return v + __shfl_xor(v, 16, 32);
+}
+
+__global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
+    const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ wgt, const float* __restrict__ gout,
+    BwLevels lv, const int* __restrict__ offset, const unsigned* __restrict__ list, const unsigned* __restrict__ gmax_bits,
+    unsigned long long* __restrict__ accum, float* __restrict__ gloc, float* __restrict__ gwgt, int N, int S, int Lq, int M, int P) {
+  __shared__ float vpatch[BW_P * BW_P][BW_D];                           // 10.1 KB
+  __shared__ unsigned long long apatch[BW_P * BW_P][BW_D];              // 20.3 KB
+  // BW_SPLIT workgroups share a bin (interleaved passes over its entries): bins differ a lot in size -- a coarse-level tile
+  // collects 15x the samples of a fine-level one -- and one workgroup per bin left the kernel waiting for the largest ones.
+  // Every workgroup adds its own patch to the global accumulator: integers, so still order-independent.
+  const int bin = blockIdx.x / BW_SPLIT, split = blockIdx.x % BW_SPLIT;
+  const int e0 = offset[bin], e1 = offset[bin + 1];
+  if (e0 + split * (BW_NT / 64) * 64 >= e1) return;          // nothing in this workgroup's first pass
+  const int m = bin % M;
+  const int nt = bin / M;
+  const int n = nt / lv.T_total, tile = nt - n * lv.T_total;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < MVG_MAX_LEVELS; ++k)
+    if (k < lv.L && tile >= lv.tile0[k]) l = k;
+  const int tl = tile - lv.tile0[l];
+  const int H = lv.H[l], W = lv.W[l];
+  const int y0 = (tl / lv.tiles_w[l]) * BW_T, x0 = (tl % lv.tiles_w[l]) * BW_T;     // patch origin (pixel)
+  const int tid = threadIdx.x, c = tid & 31;
+  const long row_stride = (long)M * BW_D;
+  const float* vbase = value + ((long)n * S + lv.start[l]) * row_stride + (long)m * BW_D;
+  for (int i = tid; i < BW_P * BW_P * BW_D; i += BW_NT) {
+    const int px = i >> 5, ch = i & 31;
+    const int y = y0 + px / BW_P, x = x0 + px % BW_P;
+    vpatch[px][ch] = (y < H && x < W) ? vbase[((long)y * W + x) * row_stride + ch] : 0.f;
+    apatch[px][ch] = 0ull;
+  }
+  __syncthreads();
+  const float gmax = __uint_as_float(gmax_bits[0]);
+  const float fix = gmax > 0.f ? BW_FIX / gmax : 0.f;
+  const int LP = lv.L * P;
+  const float Hf = (float)H, Wf = (float)W;
+  // Two phases per pass of 64 samples per wavefront (the first form recomputed every sample's coordinates, corner weights and
+  // patch indices on all 32 channel lanes -- the kernel was bound by VALU instruction count):
+  //   A. lane j of the wavefront prepares sample j of the pass: id -> location / weight (global loads, 64 in flight per
+  //      wavefront), bounds, the four corner weights x attention weight, the four patch cells;
+  //   B. 32 steps: lanes 0-31 / 32-63 (= the 32 channels) take samples 2 k / 2 k + 1, fetch the prepared scalars from their
+  //      owner lane (ds_bpermute) and do the per-channel work: grad_output, four patch reads, four fixed-point LDS adds,
+  //      the three partial sums and their reduction over the channels.
+  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+  constexpr int NW = BW_NT / 64;
+  for (int eb = e0 + (split * NW + wave) * 64; eb < e1; eb += BW_SPLIT * NW * 64) {
+    // ---- phase A
+    const int e = eb + lane;
+    const bool live = e < e1;
+    const unsigned id = list[min(e, e1 - 1)];
+    const int q = (int)(id >> 8), lp = (int)(id & 255u);
+    const long qm = ((long)n * Lq + q) * M + m;
+    const long sidx = qm * LP + lp;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + sidx * 2);
+    const float aw = wgt[sidx];
+    const float h_im = xy.y * Hf - 0.5f, w_im = xy.x * Wf - 0.5f;
+    const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+    const int h_low = (int)hl_f, w_low = (int)wl_f;
+    const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+    // patch coordinates of the four corners; a corner outside the map (row / col -1 or H / W) contributes nothing (cuh:66-88)
+    const int py = h_low - y0, pxx = w_low - x0;                         // -1 .. T-1
+    const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+    // packed: 4 clamped cell indices (7 bits each, < 81) and the 4 corner-valid bits
+    const unsigned cells = (unsigned)(max(py, 0) * BW_P + max(pxx, 0)) | ((unsigned)(max(py, 0) * BW_P + pxx + 1) << 7) |
+                           ((unsigned)((py + 1) * BW_P + max(pxx, 0)) << 14) | ((unsigned)((py + 1) * BW_P + pxx + 1) << 21) |
+                           ((unsigned)(live && t_ok && l_ok) << 28) | ((unsigned)(live && t_ok && r_ok) << 29) |
+                           ((unsigned)(live && b_ok && l_ok) << 30) | ((unsigned)(live && b_ok && r_ok) << 31);
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+    const int gq = (int)(qm);                                            // row of grad_output ((n * Lq + q) * M + m < 2^31)
+    // ---- phase B, BW_U steps at a time: their grad_output rows are requested together (a row load per step, issued after
+    //      that step's shuffles, ran the loop at one L2 round trip per step)
+    constexpr int BW_U = 4;
+    const int steps = min(32, (e1 - eb + 1) >> 1);
+    for (int k0 = 0; k0 < steps; k0 += BW_U) {
+      unsigned cl[BW_U];
+      int s_gq[BW_U], s_lp[BW_U];
+      float go[BW_U];
+#pragma unroll
+      for (int u = 0; u < BW_U; ++u) {
+        const int src = min(2 * (k0 + u) + half, 63);
+        cl[u] = (k0 + u < steps) ? (unsigned)__shfl((int)cells, src, 64) : 0u;
+        s_gq[u] = __shfl(gq, src, 64);
+        s_lp[u] = __shfl((int)id, src, 64) & 255;
+        go[u] = gout[(long)s_gq[u] * BW_D + c];
+      }
+#pragma unroll
+      for (int u = 0; u < BW_U; ++u) {
+        const int src = min(2 * (k0 + u) + half, 63);
+        const float a_w = __shfl(aw, src, 64);
+        const float s_lh = __shfl(lh, src, 64), s_lw = __shfl(lw, src, 64);
+        const float s_w1 = __shfl(w1, src, 64), s_w2 = __shfl(w2, src, 64), s_w3 = __shfl(w3, src, 64), s_w4 = __shfl(w4, src, 64);
+        const bool any = (cl[u] >> 28) != 0u;                            // uniform over the 32 lanes of the sample
+        const bool k1 = (cl[u] >> 28) & 1u, k2 = (cl[u] >> 29) & 1u, k3 = (cl[u] >> 30) & 1u, k4 = (cl[u] >> 31) & 1u;
+        const int i1 = cl[u] & 127u, i2 = (cl[u] >> 7) & 127u, i3 = (cl[u] >> 14) & 127u, i4 = (cl[u] >> 21) & 127u;
+        const float v1 = k1 ? vpatch[i1][c] : 0.f, v2 = k2 ? vpatch[i2][c] : 0.f;
+        const float v3 = k3 ? vpatch[i3][c] : 0.f, v4 = k4 ? vpatch[i4][c] : 0.f;
+        const float top = go[u] * a_w;
+        // grad_value: fixed-point contributions, |top * w * fix| <= 2^30: exact in int32, accumulated as two's complement int64
+        const float ft = top * fix;
+        {
+          if (k1) atomicAdd(&apatch[i1][c], (unsigned long long)(long long)__float2int_rn(ft * s_w1));
+          if (k2) atomicAdd(&apatch[i2][c], (unsigned long long)(long long)__float2int_rn(ft * s_w2));
+          if (k3) atomicAdd(&apatch[i3][c], (unsigned long long)(long long)__float2int_rn(ft * s_w3));
+          if (k4) atomicAdd(&apatch[i4][c], (unsigned long long)(long long)__float2int_rn(ft * s_w4));
+        }
+        // d/d(w_im), d/d(h_im), d/d(attn) (cuh:128-167), summed over the 32 channels of the head: fixed reduction tree
+        const float s_hh = 1.f - s_lh, s_hw = 1.f - s_lw;
+        float g_w = (s_hh * (v2 - v1) + s_lh * (v4 - v3)) * top * Wf;
+        float g_h = (s_hw * (v3 - v1) + s_lw * (v4 - v2)) * top * Hf;
+        float g_a = go[u] * (s_w1 * v1 + s_w2 * v2 + s_w3 * v3 + s_w4 * v4);
+        {
+          g_w = sum32(g_w);
+          g_h = sum32(g_h);
+          g_a = sum32(g_a);
+        }
+        if (c == 0 && any) {   // a live sample has at least one corner inside the map (it passed the reference's bounds test)
+          const long s_sidx = (long)s_gq[u] * LP + s_lp[u];
+          *reinterpret_cast<float2*>(gloc + s_sidx * 2) = make_float2(g_w, g_h);
+          gwgt[s_sidx] = g_a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* abase = accum + (((long)n * S + lv.start[l]) * M + m) * BW_D;
+  for (int i = tid; i < BW_P * BW_P * BW_D; i += BW_NT) {
+    const int px = i >> 5, ch = i & 31;
+    const int y = y0 + px / BW_P, x = x0 + px % BW_P;
+    const unsigned long long v = apatch[px][ch];
+    if (v != 0ull && y < H && x < W) atomicAdd(abase + ((long)y * W + x) * M * BW_D + ch, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bw_convert_kernel(const long long* __restrict__ accum, const unsigned* __restrict__ gmax_bits,
+                                                         float* __restrict__ gvalue, long n) {
+  const double inv = (double)__uint_as_float(gmax_bits[0]) / (double)BW_FIX;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    gvalue[i] = (float)((double)accum[i] * inv);
+}
+
+int fill_bw_levels(BwLevels* lv, const int64_t* shapes_host, const int64_t* starts_host, int L) {
+  if (L < 1 || L > MVG_MAX_LEVELS) return MVG_E_BADARG;
+  lv->L = L;
+  int t = 0;
+  for (int l = 0; l < L; ++l) {
+    lv->H[l] = (int)shapes_host[2 * l];
+    lv->W[l] = (int)shapes_host[2 * l + 1];
+    lv->start[l] = (int)starts_host[l];
+    if (lv->H[l] <= 0 || lv->W[l] <= 0) return MVG_E_BADARG;
+    lv->tiles_w[l] = (lv->W[l] + BW_T - 1) / BW_T;
+    lv->tile0[l] = t;
+    t += lv->tiles_w[l] * ((lv->H[l] + BW_T - 1) / BW_T);
+  }
+  lv->tile0[L] = t;
+  lv->T_total = t;
+  return 0;
+}
+
+struct BwLayout {
+  size_t accum, cnt, total, offset, list, gmax, bytes;
+};
+
+BwLayout bw_layout(long N, long S, long M, long Lq, long LP, long bpi) {
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  BwLayout w;
+  w.accum = 0;
+  w.cnt = up((size_t)N * S * M * BW_D * 8);
+  w.total = w.cnt + up((size_t)N * BW_PARTS * bpi * 4);
+  w.offset = w.total + up((size_t)N * bpi * 4);
+  w.list = w.offset + up((size_t)(N * bpi + 1) * 4);
+  w.gmax = w.list + up((size_t)N * Lq * M * LP * 4);
+  w.bytes = w.gmax + 256;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mvg_msda_backward_det_workspace(int N, int S, int M, int D, int L, int Lq, int P, const int64_t* shapes_host) {
+  if (N <= 0 || S <= 0 || M <= 0 || D != BW_D || L < 1 || L > MVG_MAX_LEVELS || Lq <= 0 || P <= 0 || !shapes_host) return 0;
+  if ((long)L * P > 256 || Lq >= (1 << 24)) return 0;
+  BwLevels lv;
+  int64_t zeros[MVG_MAX_LEVELS] = {0};
+  if (fill_bw_levels(&lv, shapes_host, zeros, L)) return 0;
+  const long bpi = (long)lv.T_total * M;
+  if (bpi > BW_MAX_BPI || (long)N * bpi * BW_SPLIT > 0x3fffffffL || (long)N * Lq * M * L * P > 0x7fffffffL) return 0;
+  return bw_layout(N, S, M, Lq, (long)L * P, bpi).bytes;
+}
+
+int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, const int64_t* starts_host,
+                              const float* sampling_loc, const float* attn_weight, const float* grad_output,
+                              float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M,
+                              int D, int L, int Lq, int P, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!value || !shapes_host || !starts_host || !sampling_loc || !attn_weight || !grad_output || !grad_value ||
+      !grad_sampling_loc || !grad_attn_weight || !workspace)
+    return MVG_E_BADARG;
+  const size_t need = mvg_msda_backward_det_workspace(N, S, M, D, L, Lq, P, shapes_host);
+  if (need == 0 || workspace_bytes < need) return MVG_E_BADARG;
+  BwLevels lv;
+  int e = fill_bw_levels(&lv, shapes_host, starts_host, L);
+  if (e) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const long LP = (long)L * P, bpi = (long)lv.T_total * M, nbins = (long)N * bpi;
+  const long per_img = (long)Lq * M * LP, nsamp = (long)N * per_img;
+  const BwLayout w = bw_layout(N, S, M, Lq, LP, bpi);
+  char* ws = reinterpret_cast<char*>(workspace);
+  unsigned long long* accum = reinterpret_cast<unsigned long long*>(ws + w.accum);
+  int* cnt = reinterpret_cast<int*>(ws + w.cnt);
+  int* total = reinterpret_cast<int*>(ws + w.total);
+  int* offset = reinterpret_cast<int*>(ws + w.offset);
+  unsigned* list = reinterpret_cast<unsigned*>(ws + w.list);
+  unsigned* gmax = reinterpret_cast<unsigned*>(ws + w.gmax);
+  hipError_t he = hipMemsetAsync(accum, 0, (size_t)N * S * M * BW_D * 8, st);
+  if (he == hipSuccess) he = hipMemsetAsync(gmax, 0, 4, st);
+  // samples that fail the reference's bounds test get zero location / weight gradients and are never binned
+  if (he == hipSuccess) he = hipMemsetAsync(grad_sampling_loc, 0, (size_t)nsamp * 2 * sizeof(float), st);
+  if (he == hipSuccess) he = hipMemsetAsync(grad_attn_weight, 0, (size_t)nsamp * sizeof(float), st);
+  if (he != hipSuccess) return (int)he;
+  static bool configured[MVG_MAX_DEVICES] = {};       // > 64 KB of dynamic LDS is a per-device function attribute
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
+  if (!configured[dev]) {
+    he = hipFuncSetAttribute(reinterpret_cast<const void*>(&bw_part_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             BW_MAX_BPI * 4);
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void*>(&bw_part_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               BW_MAX_BPI * 4);
+    if (he != hipSuccess) return (int)he;
+    configured[dev] = true;
+  }
+  const long ngo = (long)N * Lq * M * BW_D;
+  hipLaunchKernelGGL(bw_absmax_kernel, dim3(512), dim3(256), 0, st, grad_output, ngo, gmax);
+  const long chunk = (per_img + BW_PARTS - 1) / BW_PARTS;
+  const size_t lds = (size_t)bpi * 4;
+  hipLaunchKernelGGL((bw_part_kernel<0>), dim3(N * BW_PARTS), dim3(1024), lds, st, sampling_loc, lv, cnt, (const int*)nullptr,
+                     (unsigned*)nullptr, Lq, M, P, (int)bpi, per_img, chunk);
+  hipLaunchKernelGGL(bw_prefix_kernel, dim3((unsigned)((bpi + 255) / 256), N), dim3(256), 0, st, cnt, total, (int)bpi);
+  hipLaunchKernelGGL(bw_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)total, offset, (int)nbins);
+  hipLaunchKernelGGL((bw_part_kernel<1>), dim3(N * BW_PARTS), dim3(1024), lds, st, sampling_loc, lv, cnt, (const int*)offset,
+                     list, Lq, M, P, (int)bpi, per_img, chunk);
+  hipLaunchKernelGGL(bw_reduce_kernel, dim3((unsigned)(nbins * BW_SPLIT)), dim3(BW_NT), 0, st, value, sampling_loc, attn_weight,
+                     grad_output, lv, (const int*)offset, (const unsigned*)list, (const unsigned*)gmax, accum,
+                     grad_sampling_loc, grad_attn_weight, N, S, Lq, M, P);
+  const long nv = (long)N * S * M * BW_D;
+  hipLaunchKernelGGL(bw_convert_kernel, dim3((unsigned)(nv / 2048 + 1 < 4096 ? nv / 2048 + 1 : 4096)), dim3(256), 0, st,
+                     (const long long*)accum, (const unsigned*)gmax, grad_value, nv);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

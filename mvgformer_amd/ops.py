@@ -12,6 +12,10 @@ import torch
 
 from . import _lib as L
 
+# backward of the sampling op: "det" = deterministic tile-binned form where the shape allows (D = 32), "atomic" = always the
+# fp32-atomics form of round 1 (the reference's own scheme)
+BACKWARD_MODE = __import__("os").environ.get("MVG_BACKWARD", "det")
+
 # ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) -----
 PROFILE = None   # None (off) or dict name -> list[(start_event, end_event)]
 
@@ -110,6 +114,20 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     grad_output = grad_output.contiguous()
     N, S, M, D = value.shape
     _, Lq, _, nl, P, _ = sampling_loc.shape
+    if value.dtype == torch.float32 and BACKWARD_MODE != "atomic":
+        # deterministic form (csrc/msda_bwd.hip): binned by destination tile, fixed-point accumulation in LDS
+        lib = L.load()
+        shapes_c, _ = _i64_host(spatial_shapes)
+        starts_c, _ = _i64_host(level_start_index)
+        ws_bytes = int(lib.mvg_msda_backward_det_workspace(N, S, M, D, nl, Lq, P, shapes_c))
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+            gv, gl, ga = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+            with _timed("msda_backward_det"):
+              L.check(lib.mvg_msda_backward_det_f32(L.ptr(value), shapes_c, starts_c, L.ptr(sampling_loc), L.ptr(attn_weight),
+                                                    L.ptr(grad_output), L.ptr(gv), L.ptr(gl), L.ptr(ga), N, S, M, D, nl, Lq, P,
+                                                    L.ptr(ws), ws_bytes, L.stream_ptr()), "mvg_msda_backward_det_f32")
+            return gv, gl, ga
     gv = torch.zeros_like(value)                                             # deform_cuda.cu:132-134
     gl = torch.empty_like(sampling_loc)
     ga = torch.empty_like(attn_weight)

@@ -504,3 +504,70 @@ def test_triangulation_launch_also_projects_for_the_next_layer():
             plain = _run(dec, g)
             for k in range(4):
                 assert torch.equal(fused[k], plain[k]), (cname, str(dt), k)
+
+
+def test_deterministic_backward_full_size_view_layer_vs_c_oracle():
+    """mvg_msda_backward_det_f32 (csrc/msda_bwd.hip) at the size of ONE cfg-2 view-layer (S = 40 320 pixels, 15 360 tokens x 8
+    heads x 24 samples = 2.9 M samples, 11.8 M corner contributions of 32 channels), locations spread over and beyond the maps
+    so that every bin kind occurs (interior, map border, empty, heavy): against the C restatement of the reference's backward
+    accumulated in double (oracle/msda_ref.c, pinned by tests/test_oracle_golden.py), bit-reproducible run to run, and
+    against the atomic form of round 1 (the reference's own scheme)."""
+    import time
+    from mvgformer_amd import ops
+    from oracle import msda_c
+    shapes = torch.tensor([(128, 240), (64, 120), (32, 60)], dtype=torch.long)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    N, M, D, Lq, P, L = 1, 8, 32, 15360, 8, 3
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    g = torch.Generator().manual_seed(21)
+    value = torch.randn((N, S, M, D), generator=g)
+    centre = torch.rand((N, Lq, 1, 1, 1, 2), generator=g) * 1.1 - 0.05              # some queries partly outside the maps
+    loc = (centre + torch.randn((N, Lq, M, L, P, 2), generator=g) * 0.03).contiguous()
+    loc[:, :64] = 0.5 + torch.randn((N, 64, M, L, P, 2), generator=g) * 1e-3          # a heavy bin: 64 queries on one spot
+    wgt = torch.softmax(torch.randn((N, Lq, M, L * P), generator=g), -1).view(N, Lq, M, L, P).contiguous()
+    go = torch.randn((N, Lq, M * D), generator=g)
+    t0 = time.time()
+    want = msda_c.msda_backward(value, shapes, starts, loc, wgt, go)
+    print("C oracle backward: %.1f s" % (time.time() - t0))
+    dv = lambda t: t.to(DEV)
+    args = (dv(value), dv(shapes), dv(starts), dv(loc), dv(wgt), dv(go))
+    saved = ops.BACKWARD_MODE
+    try:
+        ops.BACKWARD_MODE = "det"
+        a = ops.msda_backward(*args)
+        b = ops.msda_backward(*args)
+        ops.BACKWARD_MODE = "atomic"
+        c = ops.msda_backward(*args)
+    finally:
+        ops.BACKWARD_MODE = saved
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "deterministic backward is not bit-reproducible"
+    for name, got, ref in zip(("grad_value", "grad_loc", "grad_attn"), a, want):
+        scale = float(ref.abs().max())
+        e_det = float((got.cpu().double() - ref).abs().max()) / scale
+        print("%s: deterministic kernel vs C oracle (double accumulation) %.2e of max |g| %.3g" % (name, e_det, scale))
+        # fp32 coordinates and bilinear weights (as the reference computes them) x exact fixed-point sums: 1e-5 of the
+        # largest gradient, 1e-4 for the location gradient (a difference of corner values scaled by W / H)
+        assert e_det < (1e-5 if name != "grad_loc" else 1e-4), (name, e_det)
+    for name, got, ref in zip(("grad_value", "grad_loc", "grad_attn"), c, want):
+        e_at = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        print("%s: atomic kernel (round 1) vs C oracle %.2e" % (name, e_at))
+        assert e_at < (1e-4 if name != "grad_loc" else 1e-3), (name, e_at)
+    # speed (HIP events, same inputs)
+    def timed(mode, n=5):
+        ops.BACKWARD_MODE = mode
+        ops.msda_backward(*args)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            ops.msda_backward(*args)
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e3
+    try:
+        t_det, t_at = timed("det"), timed("atomic")
+    finally:
+        ops.BACKWARD_MODE = saved
+    print("backward of one cfg-2 view-layer: deterministic %.0f us, atomic %.0f us" % (t_det, t_at))

@@ -166,3 +166,27 @@ def test_c_restatement_matches_reference_twin(name):
     c = msda_case(name)
     y = msda_c.msda_forward(c["value"], c["shapes"], c["starts"], c["loc"], c["weight"])
     assert _maxrel(y, g[name + "/out"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["small_f32", "ragged_f32", "edge_f32"])
+def test_c_backward_restatement_matches_autograd_of_the_pinned_oracle(name):
+    """oracle/msda_ref.c::msda_backward_ref (cuh:98-169 restated, double accumulation) against torch autograd through
+    decoder_ref.msda_forward in fp64 -- which is itself pinned to the reference twin's outputs above.  The C form is what the
+    full-size GPU backward test compares with (autograd at that size needs ~10 GB of intermediates)."""
+    import subprocess
+    from oracle import decoder_ref as O
+    from oracle import msda_c
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(GOLD), "..", "oracle")], stdout=subprocess.DEVNULL)
+    c = msda_case(name)
+    v = c["value"].double().requires_grad_(True)
+    lo = c["loc"].double().requires_grad_(True)
+    w = c["weight"].double().requires_grad_(True)
+    y = O.msda_forward(v, c["shapes"], c["starts"], lo, w)
+    go = torch.from_numpy(np.random.RandomState(11).standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * go.double()).sum().backward()
+    gv, gl, ga = msda_c.msda_backward(c["value"], c["shapes"], c["starts"], c["loc"], c["weight"], go)
+    # the C form computes the sample coordinates and bilinear weights in float like the reference kernel (cuh:385-386,113-117)
+    # and only ACCUMULATES in double; autograd runs everything in double: they agree to fp32 coordinate rounding
+    assert _maxrel(gv, v.grad) < 5e-6 and _maxrel(ga, w.grad) < 5e-6
+    sl = slice(7, None) if name == "edge_f32" else slice(None)       # hand-placed texel-border points: d/d(loc) is one-sided there
+    assert _maxrel(gl[:, sl], lo.grad[:, sl]) < 5e-5
