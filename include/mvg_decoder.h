@@ -155,6 +155,18 @@ int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,
                    int N_img, int Lq, int L, int S, void* stream);
 
+/* G-sampling in fp32 (the reference's arithmetic; replaces mvg_gather_ref + the (V*Lq*L x 256 x 192) mvg_linear +
+ * mvg_msda_fused of the fp32 path): value (V*B,S,256) f32 pixel-major; G (V*B*S, 192) f32 = feat @ [Woff; Wattn]^T with the
+ * columns in mvgformer_amd.ops.gsamp_column_order (no bias); xw (B*Lq, 192) f32 = (tgt+query_pos) @ W^T + b, same column
+ * order; samp (V*B*Lq, 256) f32.  Bilinear sampling commutes with the Linear, so the results equal the gather-then-Linear
+ * form to fp32 rounding.  pair_mask / order (or NULL) as in mvg_msda_gsamp: masked pairs are zero-filled without being
+ * sampled (the consumer multiplies exactly these rows by the in-image mask, dq_decoder.py:585-586), slot i of the launch
+ * computes pair order[i].  M=8, D=32, P=8, L<=4. */
+int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, const float* ref_lvl,
+                        const int64_t* shapes_host, const int64_t* starts_host, float* samp,
+                        const uint8_t* pair_mask, const int32_t* order,
+                        int N_img, int Lq, int L, int S, int B, void* stream);
+
 /* ---- bf16 fast path of the ProjAttn front end (replaces mvg_gather_ref + 2 x mvg_linear + mvg_msda_fused) ----
  * Bilinear sampling commutes with a Linear: Linear(bilinear(feat,p) + x) = bilinear(feat@W^T, p) + (x@W^T + b).
  *   mvg_value_proj_planes_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written as head planes

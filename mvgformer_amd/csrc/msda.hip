@@ -404,6 +404,156 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// msda_gfused_f32_kernel -- G-sampling in the reference's own arithmetic (fp32 storage, fp32 math; round 2).
+// msda_fused_kernel needs the (pairs * L, 192) tensor `oa` of offsets / logits, i.e. a gather of 256-channel reference-point
+// rows (`ain`, 236 MB per layer at cfg-2) and a (V * Lq * L) x 256 x 192 GEMM (177 MB out) per layer.  Bilinear sampling commutes
+// with the Linear (see msda_gsamp_kernel), so here the Linear is applied once to the pyramid (G = feat @ Woa^T, fp32, columns
+// in ops.gsamp_column_order) and every (pair, head) gathers its 24 logits + 48 offsets from G at the reference point and adds
+// xw = (tgt + query_pos) @ Woa^T + b -- phase A below, 8 lanes per head, one (image, query) pair per wavefront, results parked
+// in LDS --, then softmax, locations and sampling exactly as msda_fused_kernel<float> does them.
+template <int L>
+__global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __restrict__ value, const float* __restrict__ G,
+                                                                 const float* __restrict__ xw, const float* __restrict__ r,
+                                                                 LevelTable lv, float* __restrict__ samp,
+                                                                 const uint8_t* __restrict__ pair_mask,
+                                                                 const int* __restrict__ order, int n_pairs,
+                                                                 int Lq, int S, int B) {
+  constexpr int D = 32, P = 8, C = 256, LP = L * P, NCHK = 3 * L, NB = 4, CPL = 4, SCP = 3 * LP + 8;
+  typedef RawVec<float, CPL> RV;
+  __shared__ __attribute__((aligned(16))) float scratch[4][8][SCP];
+  // XCD-aware block remap (bijective): XCD x = blockIdx % 8 walks a contiguous block range
+  const int nb = gridDim.x;
+  const int q8 = nb >> 3, r8 = nb & 7;
+  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+  const int lblock = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = lblock * 4 + wave;
+  const int m = lane >> 3, sub = lane & 7;
+  if (slot >= n_pairs) return;                         // one (image, query) pair per wavefront: whole wavefronts leave
+  // slot -> pair through the image-space processing order (mvg_bin_pairs: neighbours in the maps are neighbours in the
+  // launch, pairs outside the image last); pairs the caller masks out (their rows are multiplied by 0 by the consumer,
+  // dq_decoder.py:585-586) are written as zeros without being sampled
+  const int pair = order ? order[slot] : slot;
+  if (pair_mask && !pair_mask[pair]) {
+    *reinterpret_cast<f32x4*>(samp + (long)pair * C + m * D + sub * CPL) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const bool live = true;
+  const int n = pair / Lq, q = pair - n * Lq, b = n % B;
+  float* sc = &scratch[wave][m][0];
+
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk, one chunk per lane
+#pragma unroll
+  for (int k = 0; k < (NCHK + 7) / 8; ++k) {
+    const int ci = sub + 8 * k;
+    if (ci < NCHK) {
+      const int t = ci / 3, part = ci - 3 * t;           // group t of the head (= level of its samples), 16 offsets | 8 logits
+      const int fg = m * L + t;
+      const int l = fg >> 3;                             // level row of the reinterpreted view (projattn.py:180-184)
+      const int col = 24 * (fg & 7) + 8 * part;
+      const int H = lv.H[l], W = lv.W[l];
+      const float Wf = (float)W, Hf = (float)H;
+      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+      const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
+      const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+      const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;    // grid_sample, align_corners=False
+      const float x0f = floorf(ix), y0f = floorf(iy);
+      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      const float tx = ix - x0f, ty = iy - y0f;
+      const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+      const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f, w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+      const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
+      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+      const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
+      const float* p00 = gp + (long)(y0c * W + x0c) * 192;
+      const float* p10 = gp + (long)(y0c * W + x1c) * 192;
+      const float* p01 = gp + (long)(y1c * W + x0c) * 192;
+      const float* p11 = gp + (long)(y1c * W + x1c) * 192;
+      const float* xq = xw + ((long)b * Lq + q) * 192 + col;
+      float* dst = sc + (part == 2 ? 8 * t : LP + 16 * t + 8 * part);
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + 4 * hlf), bq = *reinterpret_cast<const f32x4*>(p10 + 4 * hlf);
+        const f32x4 cq = *reinterpret_cast<const f32x4*>(p01 + 4 * hlf), dq = *reinterpret_cast<const f32x4*>(p11 + 4 * hlf);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xq + 4 * hlf);
+        *reinterpret_cast<f32x4*>(dst + 4 * hlf) = w00 * a + w10 * bq + w01 * cq + w11 * dq + xv;
+      }
+    }
+  }
+  // head-private scratch rows inside one wavefront: LDS operations of a wavefront execute in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- pass 1: max and sum of the head's L*P logits (softmax denominator), redundantly on the 8 lanes of a head
+  float mx = -INFINITY;
+  {
+    f32x4 lg[LP / 4];
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i) {
+      lg[i] = *reinterpret_cast<const f32x4*>(sc + 4 * i);
+      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i)
+      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
+    mx += __logf(sum);                                   // fold 1/sum into the exponent: w = exp(x - mx - log(sum))
+  }
+
+  const float* vbase = value + (long)n * S * C + m * D + sub * CPL;
+  float acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  // ---- pass 2: batches of NB samples, their 4 * NB gathers issued back to back (as msda_fused_kernel)
+#pragma unroll 1
+  for (int it = 0; it < LP / NB; ++it) {
+    const int l = (it * NB) / P;
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+    const float invW = lv.invW[l], invH = lv.invH[l];
+    const float* lvl = vbase + (long)lv.start[l] * C;
+    const f32x4 lg = *reinterpret_cast<const f32x4*>(sc + it * NB);
+    const f32x4 o4a = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2), o4b = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2 + 4);
+    const float ox[NB] = {o4a[0], o4a[2], o4b[0], o4b[2]}, oy[NB] = {o4a[1], o4a[3], o4b[1], o4b[3]};
+    float cw[NB][4];
+    typename RV::type raw[NB][4];
+#pragma unroll
+    for (int s_ = 0; s_ < NB; ++s_) {
+      const float lx = refx + ox[s_] * invW;                           // projattn.py:186-191
+      const float ly = refy + oy[s_] * invH;
+      const float h_raw = ly * Hf - 0.5f;                              // cuh:295-296
+      const float w_raw = lx * Wf - 0.5f;
+      const bool inside = (h_raw > -1.f) && (w_raw > -1.f) && (h_raw < Hf) && (w_raw < Wf);   // cuh:298
+      const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
+      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+      const int h_low = (int)hl_f, w_low = (int)wl_f;
+      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+      const float a = inside ? __expf(lg[s_] - mx) : 0.f;              // softmax weight (projattn.py:184)
+      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+      cw[s_][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;                // cuh:66-88 zero padding
+      cw[s_][1] = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
+      cw[s_][2] = (hh_ok && wl_ok) ? lh * hw * a : 0.f;
+      cw[s_][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
+      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+      const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
+      raw[s_][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
+      raw[s_][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
+      raw[s_][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
+      raw[s_][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all 4*NB loads are issued before the first blend
+#pragma unroll
+    for (int s_ = 0; s_ < NB; ++s_)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s_][k], cw[s_][k]);
+  }
+  if (live) store_acc<float, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
+}
+
+// ------------------------------------------------------------------------------------------
 // msda_gsamp_kernel -- the bf16 sampling kernel of the decoder (the kernel bench.py's roofline reports).
 //
 // (1) G-sampling.  Bilinear sampling commutes with a Linear:
@@ -432,12 +582,12 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 //     v_dot2c_f32_bf16 per batch, fp32 accumulation, no bf16->fp32 unpacking.  (The bilinear x attention
 //     weights are rounded to bf16; products and sums are fp32.)
 template <int L, int NT>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
-__global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
-                                                            const float* __restrict__ xw, const float* __restrict__ r,
-                                                            LevelTable lv, bf16_t* __restrict__ samp,
-                                                            const uint8_t* __restrict__ pair_mask,
-                                                            const int* __restrict__ order, int n_pairs,
-                                                            int Lq, int S, int B, int map_ch) {
+__device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                                const float* __restrict__ xw, const float* __restrict__ r,
+                                                const LevelTable& lv, bf16_t* __restrict__ samp,
+                                                const uint8_t* __restrict__ pair_mask,
+                                                const int* __restrict__ order, int n_pairs,
+                                                int Lq, int S, int B, int map_ch) {
   constexpr int SCP = 3 * L * 8 + 8;   // scratch row: L*P logits, 2*L*P offsets, L reference points
   __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -471,10 +621,29 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
+// Two builds of the same body.  The kernel is bound by (gather latency) x (wavefronts per CU): hipcc's own allocation is 101 VGPRs
+// = 4 wavefronts per SIMD; pinned to 5 per SIMD it fits 96 VGPRs with 5 dwords of scratch spill outside the sampling loop.
+template <int L, int NT>
+__global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                                        const float* __restrict__ xw, const float* __restrict__ r,
+                                                        LevelTable lv, bf16_t* __restrict__ samp,
+                                                        const uint8_t* __restrict__ pair_mask, const int* __restrict__ order,
+                                                        int n_pairs, int Lq, int S, int B, int map_ch) {
+  msda_gsamp_body<L, NT>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
+}
+template <int L, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void msda_gsamp_occ5_kernel(
+    const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G, const float* __restrict__ xw, const float* __restrict__ r,
+    LevelTable lv, bf16_t* __restrict__ samp, const uint8_t* __restrict__ pair_mask, const int* __restrict__ order, int n_pairs,
+    int Lq, int S, int B, int map_ch) {
+  msda_gsamp_body<L, NT>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
+}
+
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
 int g_auto_small = 1;              // tuning knob "auto_small": small launches pick their own workgroup / tile sizes (see mvg_msda_gsamp)
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
+static int g_gsamp_occ5 = 0;      // tuning knob "gsamp_occ5": the 5-wavefronts-per-SIMD build of the 256-thread kernel
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
@@ -715,9 +884,14 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   {                                                                                                               \
     int npb = (int)((pairs + NT / 4 - 1) / (NT / 4));                                                             \
     if (map > 0) npb = (npb + 8 * map - 1) / (8 * map) * (8 * map);                                               \
-    hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,            \
-                       (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S, B,  \
-                       map);                                                                                      \
+    if (g_gsamp_occ5 && NT == 256)                                                                                \
+      hipLaunchKernelGGL((msda_gsamp_occ5_kernel<LL, 256>), dim3(8 * npb), dim3(256), 0, st, (const bf16_t*)vp,   \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
+                         B, map);                                                                                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,          \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
+                         B, map);                                                                                 \
   }
 #define MVG_GSN(LL)                                                                                               \
   if (nthreads == 1024) MVG_GS(LL, 1024) else if (nthreads == 512) MVG_GS(LL, 512)                                \
@@ -761,8 +935,32 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "auto_small") && (value == 0 || value == 1)) { g_auto_small = value; return 0; }
   if (!strcmp(key, "auto_small_b") && (value == 0 || value == 1)) { g_auto_small_b = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
+  if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
+}
+
+int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, const float* ref_lvl, const int64_t* shapes_host,
+                        const int64_t* starts_host, float* samp, const uint8_t* pair_mask, const int32_t* order, int N_img,
+                        int Lq, int L, int S, int B, void* stream) {
+  if (!value || !G || !xw || !ref_lvl || !shapes_host || !starts_host || !samp || B <= 0) return MVG_E_BADARG;
+  LevelTable lv;
+  int e = mvg_fill_levels(&lv, shapes_host, starts_host, L);
+  if (e) return e;
+  const long pairs = (long)N_img * Lq;
+  if (pairs > 0x7fffffffL / 4 || (long)N_img * S * 256 > 0x7fffffffL) return MVG_E_BADARG;     // int pixel offsets x C
+  if (pairs == 0) return 0;
+  const int grid = (int)((pairs + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  switch (L) {
+    case 1: hipLaunchKernelGGL((msda_gfused_f32_kernel<1>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+    case 2: hipLaunchKernelGGL((msda_gfused_f32_kernel<2>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+    case 3: hipLaunchKernelGGL((msda_gfused_f32_kernel<3>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+    case 4: hipLaunchKernelGGL((msda_gfused_f32_kernel<4>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+    default: return MVG_E_BADARG;
+  }
+  MVG_LAUNCH_CHECK();
+  return 0;
 }
 
 int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r, const int64_t* shapes_host,

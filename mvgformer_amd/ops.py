@@ -235,6 +235,26 @@ def msda_fused(value, oa, r, levels):
     return samp
 
 
+def msda_gfused_f32(value, G, xw, r, levels, B, pair_mask=None, order=None):
+    """fp32 G-sampling (include/mvg_decoder.h: mvg_msda_gfused_f32): value (n_img,S,256) f32, G (n_img*S,192) f32 and
+    xw (B*Lq,192) f32 in gsamp_column_order, r (n_img,Lq,L,2) -> samp (n_img*Lq,256) f32."""
+    n_img, S, Cc = value.shape
+    Lq = r.shape[1]
+    assert value.dtype == torch.float32 and G.dtype == torch.float32 and xw.dtype == torch.float32 and Cc == 256
+    assert G.is_contiguous() and tuple(G.shape) == (n_img * S, 192) and xw.is_contiguous() and xw.shape[1] == 192
+    samp = torch.empty((n_img * Lq, 256), dtype=torch.float32, device=value.device)
+    if pair_mask is not None:
+        assert pair_mask.dtype == torch.uint8 and pair_mask.numel() == n_img * Lq and pair_mask.is_contiguous()
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == n_img * Lq and order.is_contiguous()
+    with _timed("msda_gfused_f32"):
+      L.check(L.load().mvg_msda_gfused_f32(L.ptr(value), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
+                                           L.ptr(samp), None if pair_mask is None else L.ptr(pair_mask),
+                                           None if order is None else L.ptr(order), n_img, Lq, levels.L, S, B,
+                                           L.stream_ptr()), "mvg_msda_gfused_f32")
+    return samp
+
+
 def value_proj_planes_ws(feat, w_frag, bias, vp):
     """weight-stationary value projection (bf16 feat, swizzled weight) into head planes vh[img][head][s][32]."""
     n_img, S, K = feat.shape

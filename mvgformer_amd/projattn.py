@@ -98,6 +98,12 @@ class ProjAttn(nn.Module):
         # more than the 20 us of chain A that do hide under the other workgroup's gathers) -- so it is off by default;
         # MVG_FUSE_SAMPLER=1 selects it.
         self.fuse_sampler_chain = os.environ.get("MVG_FUSE_SAMPLER", "0") == "1"
+        # fp32 path: G-sampling (csrc/msda.hip: msda_gfused_f32_kernel) instead of gather -> Linear -> fused sampling.
+        # True / False, or "auto": wherever the offsets / logits Linear has fewer rows on the pyramid (V*S) than on the
+        # gathered reference points (V*Lq*L) -- cfg-2: 40 320 vs 46 080 rows per image, 6.80 -> 6.26 ms; cfg-4 (512 queries:
+        # 39 900 vs 23 040) and a rank's shard of a query-sharded run keep the gather form.  The two forms agree to fp32
+        # rounding, not bit for bit: pin it to True / False where runs with different query counts must match exactly.
+        self.g_sampling_f32 = {"0": False, "1": True}.get(os.environ.get("MVG_G_SAMPLING_F32", "auto"), "auto")
         self.sort_pairs = os.environ.get("MVG_SORT_PAIRS", "layer")
         if self.sort_pairs in ("0", "off", "False"):
             self.sort_pairs = False
@@ -242,6 +248,17 @@ class ProjAttn(nn.Module):
                 xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
             vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
+        use_g = self.g_sampling_f32 if self.g_sampling_f32 != "auto" else r.shape[1] * levels.L >= S
+        if dt == torch.float32 and use_g and Woa.shape[0] == 192 and Cc == 256:
+            # fp32, reference arithmetic, same re-association as the bf16 fast path: the offsets / logits Linear applied to
+            # the pyramid once (G) instead of to V*Lq*L gathered rows -- no `ain` (236 MB) / `oa` (177 MB) per layer
+            Wq, bq = self._fast_query_weights(dt)
+            G32 = ops.linear(feat.view(n_img * S, Cc), Wq, None, out_dtype=dt)
+            xw32 = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=dt)
+            value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)     # projattn.py:169
+            if order is None and self.sort_pairs and r.shape[1] <= 65536:
+                order = ops.bin_pairs(r, pair_mask, levels)
+            return ops.msda_gfused_f32(value.view(n_img, S, Cc), G32, xw32, r, levels, B, pair_mask=pair_mask, order=order)
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
         value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169

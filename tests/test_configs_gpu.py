@@ -283,6 +283,8 @@ def test_cfg5_full_stress_fp32_permutation_and_shards_are_exact():
     from mvgformer_amd.factory import build_decoder_for_case, case_to_device
     case = build_case("cfg5", seed=3, layers=2)
     dec = build_decoder_for_case(case, DEV, dtype=torch.float32)
+    for layer in dec.layers:            # one sampling form for every query count (see ProjAttn.g_sampling_f32)
+        layer.proj_attn.g_sampling_f32 = False
     g = case_to_device(case, DEV)
     NQ, J = case.NQ, 15
     run = lambda t, p, r: dec(t, r, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None, query_pos=p,
@@ -571,3 +573,32 @@ def test_deterministic_backward_full_size_view_layer_vs_c_oracle():
     finally:
         ops.BACKWARD_MODE = saved
     print("backward of one cfg-2 view-layer: deterministic %.0f us, atomic %.0f us" % (t_det, t_at))
+
+
+def test_fp32_g_sampling_equals_the_gather_then_linear_form():
+    """fp32 path: msda_gfused_f32 (offsets / logits Linear applied to the pyramid once, gathered inside the sampler) against
+    the literal gather -> Linear -> fused-sampling decomposition it replaces (projattn.py:148-200): same results to fp32
+    rounding -- on a golden case, on level counts 1..4 and on one full-size cfg-2 layer."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from tests.golden.cases import LAYER_CASES
+    cases = []
+    for cname in ("mini5_all", "mini5_b2"):
+        sp = LAYER_CASES[cname]
+        cases.append(build_case(sp["config"], B=sp.get("B", 1), seed=sp["seed"], NQ=sp.get("NQ"), layers=sp["layers"],
+                                valid_fraction=sp.get("valid_fraction")))
+    cases.append(build_case("cfg2", seed=1, layers=1))
+    for case in cases:
+        dec = build_decoder_for_case(case, DEV, dtype=torch.float32)
+        g = case_to_device(case, DEV)
+        outs = []
+        for flag in (True, False):
+            for layer in dec.layers:
+                layer.proj_attn.g_sampling_f32 = flag
+            outs.append(_run(dec, g))
+        a, b = outs
+        e_hs = float((a[0][0] - b[0][0]).abs().max())
+        e_px = float((a[2][0] - b[2][0]).abs().max())
+        e_mm = float((a[1][0] - b[1][0]).norm(dim=-1).max())
+        print("%s layer 0: G-sampling vs gather+Linear (fp32): |hs| %.2e  2D %.2e px  3D %.4f mm" % (case.name, e_hs, e_px, e_mm))
+        assert e_hs < 2e-5 and e_px < 5e-3 and e_mm < 0.05
+        assert torch.equal(a[1].abs().sum(-1) > 0, b[1].abs().sum(-1) > 0)
