@@ -13,10 +13,11 @@
 //   2. one workgroup per non-empty bin loads the (T+1) x (T+1) x 32 value patch of its tile into LDS -- the four corners of
 //      every sample of the bin are inside it, so grad_sampling_loc / grad_attn_weight need no global gather at all --, and
 //      keeps a (T+1) x (T+1) x 32 accumulator patch next to it;
-//   3. 8 samples x 32 channels per pass: thread c reads grad_output[q, m, c] (128 contiguous bytes per sample), adds its
-//      four corner contributions to the LDS accumulator as 64-bit FIXED-POINT integers (ds_add_u64: integer addition is
-//      associative, so the result does not depend on which wavefront gets there first), reduces the two location gradients
-//      and the weight gradient over the 32 channels with a fixed shuffle tree and writes them (one writer per sample);
+//   3. per wavefront pass, 64 samples: each lane prepares one sample (location, weights, patch cells), then 8 lanes x 4
+//      channels work on each sample: read grad_output[q, m, :] (128 contiguous bytes per sample), add the four corner
+//      contributions to the LDS accumulator as 64-bit FIXED-POINT integers (ds_add_u64: integer addition is associative, so
+//      the result does not depend on which wavefront gets there first), reduce the two location gradients and the weight
+//      gradient over the channels in a fixed order and write them (one writer per sample);
 //   4. the patch is added to a global 64-bit accumulator (integer atomics again: neighbouring tiles share their border
 //      pixels), and a last pass converts it to the fp32 grad_value.
 // Fixed point: contributions are bounded by gmax = max |grad_output| (bilinear and attention weights <= 1); they are scaled
@@ -31,7 +32,7 @@ constexpr int BW_T = 8;                   // tile edge (pixels); the LDS patch i
 constexpr int BW_P = BW_T + 1;
 constexpr int BW_D = 32;
 constexpr int BW_NT = 256;                // 8 samples x 32 channels per pass
-constexpr int BW_SPLIT = 1;               // workgroups per bin (interleaved over its entries); 8 measured slower (584 vs 482 us)
+constexpr int BW_SPLIT = 1;               // workgroups per bin (interleaved over its entries): 2 / 4 / 8 measured 635 / 770 / 761 us against 617 us
 constexpr float BW_FIX = 1073741824.f;     // 2^30: a contribution (|.| <= max |grad_output|) is an exact int32
 
 struct BwLevels {
@@ -183,14 +184,12 @@ __global__ __launch_bounds__(1024) void bw_scan_kernel(const int* __restrict__ t
   if (tid == 0) offset[nb] = carry;
 }
 
-// sum over the 32 lanes of a half wavefront (result in all of them), fixed order: quad_perm xor 1, xor 2, row_half_mirror,
-// row_mirror (DPP, full rate), then one exchange with the other 16-lane row
-__device__ __forceinline__ float sum32(float v) {
+// sum over the 8 lanes of a lane group (result in all of them), fixed order: quad_perm xor 1, xor 2, row_half_mirror
+__device__ __forceinline__ float sum8(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
-  return v + __shfl_xor(v, 16, 32);
+  return v;
 }
 
 __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
@@ -202,7 +201,11 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   // BW_SPLIT workgroups share a bin (interleaved passes over its entries): bins differ a lot in size -- a coarse-level tile
   // collects 15x the samples of a fine-level one -- and one workgroup per bin left the kernel waiting for the largest ones.
   // Every workgroup adds its own patch to the global accumulator: integers, so still order-independent.
-  const int bin = blockIdx.x / BW_SPLIT, split = blockIdx.x % BW_SPLIT;
+  // blockIdx = ((image, tile) * BW_SPLIT + split) * M + head: with M = 8, blockIdx % 8 -- the XCD the block is dispatched to --
+  // is the HEAD, so an XCD's 4-MB L2 holds one head's slice of grad_output (2 MB at cfg-2) and of value; a mapping that put
+  // all heads on every XCD ran 2.3x slower (its grad_output rows came from HBM / Infinity Cache)
+  const int m_ = blockIdx.x % M, rest_ = blockIdx.x / M;
+  const int split = rest_ % BW_SPLIT, bin = (rest_ / BW_SPLIT) * M + m_;
   const int e0 = offset[bin], e1 = offset[bin + 1];
   if (e0 + split * (BW_NT / 64) * 64 >= e1) return;          // nothing in this workgroup's first pass
   const int m = bin % M;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   const int tl = tile - lv.tile0[l];
   const int H = lv.H[l], W = lv.W[l];
   const int y0 = (tl / lv.tiles_w[l]) * BW_T, x0 = (tl % lv.tiles_w[l]) * BW_T;     // patch origin (pixel)
-  const int tid = threadIdx.x, c = tid & 31;
+  const int tid = threadIdx.x;
   const long row_stride = (long)M * BW_D;
   const float* vbase = value + ((long)n * S + lv.start[l]) * row_stride + (long)m * BW_D;
   for (int i = tid; i < BW_P * BW_P * BW_D; i += BW_NT) {
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   //   B. 32 steps: lanes 0-31 / 32-63 (= the 32 channels) take samples 2 k / 2 k + 1, fetch the prepared scalars from their
   //      owner lane (ds_bpermute) and do the per-channel work: grad_output, four patch reads, four fixed-point LDS adds,
   //      the three partial sums and their reduction over the channels.
-  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+  const int wave = tid >> 6, lane = tid & 63;
   constexpr int NW = BW_NT / 64;
   for (int eb = e0 + (split * NW + wave) * 64; eb < e1; eb += BW_SPLIT * NW * 64) {
     // ---- phase A
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
     const float h_im = xy.y * Hf - 0.5f, w_im = xy.x * Wf - 0.5f;
     const float hl_f = floorf(h_im), wl_f = floorf(w_im);
     const int h_low = (int)hl_f, w_low = (int)wl_f;
-    const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+    const float lh = h_im - hl_f, lw = w_im - wl_f;
     // patch coordinates of the four corners; a corner outside the map (row / col -1 or H / W) contributes nothing (cuh:66-88)
     const int py = h_low - y0, pxx = w_low - x0;                         // -1 .. T-1
     const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
@@ -260,56 +263,67 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
                            ((unsigned)((py + 1) * BW_P + max(pxx, 0)) << 14) | ((unsigned)((py + 1) * BW_P + pxx + 1) << 21) |
                            ((unsigned)(live && t_ok && l_ok) << 28) | ((unsigned)(live && t_ok && r_ok) << 29) |
                            ((unsigned)(live && b_ok && l_ok) << 30) | ((unsigned)(live && b_ok && r_ok) << 31);
-    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
     const int gq = (int)(qm);                                            // row of grad_output ((n * Lq + q) * M + m < 2^31)
-    // ---- phase B, BW_U steps at a time: their grad_output rows are requested together (a row load per step, issued after
-    //      that step's shuffles, ran the loop at one L2 round trip per step)
-    constexpr int BW_U = 4;
-    const int steps = min(32, (e1 - eb + 1) >> 1);
+    // ---- phase B: 8 samples per step -- lane (g = lane >> 3, j = lane & 7) takes channels 4 j .. 4 j + 3 of the sample prepared
+    //      by lane 8 k + g.  (With 32 lanes x 1 channel per sample the per-sample scalars -- cell indices, corner flags and
+    //      weights, addresses -- were recomputed on 32 lanes and the kernel was bound by VALU issue: 170 M wave-instructions
+    //      per launch; 4 channels per lane amortise them 4x and shorten the channel reduction from 5 to 3 DPP steps.)
+    constexpr int BW_U = 2;
+    const int g8 = lane >> 3, j = lane & 7;
+    const int steps = min(8, (e1 - eb + 7) >> 3);
     for (int k0 = 0; k0 < steps; k0 += BW_U) {
       unsigned cl[BW_U];
-      int s_gq[BW_U], s_lp[BW_U];
-      float go[BW_U];
+      int s_gq[BW_U];
+      f32x4 go[BW_U];
 #pragma unroll
       for (int u = 0; u < BW_U; ++u) {
-        const int src = min(2 * (k0 + u) + half, 63);
+        const int src = min(8 * (k0 + u) + g8, 63);
         cl[u] = (k0 + u < steps) ? (unsigned)__shfl((int)cells, src, 64) : 0u;
         s_gq[u] = __shfl(gq, src, 64);
-        s_lp[u] = __shfl((int)id, src, 64) & 255;
-        go[u] = gout[(long)s_gq[u] * BW_D + c];
+        go[u] = *reinterpret_cast<const f32x4*>(gout + (long)s_gq[u] * BW_D + 4 * j);
       }
 #pragma unroll
       for (int u = 0; u < BW_U; ++u) {
-        const int src = min(2 * (k0 + u) + half, 63);
+        const int src = min(8 * (k0 + u) + g8, 63);
         const float a_w = __shfl(aw, src, 64);
         const float s_lh = __shfl(lh, src, 64), s_lw = __shfl(lw, src, 64);
-        const float s_w1 = __shfl(w1, src, 64), s_w2 = __shfl(w2, src, 64), s_w3 = __shfl(w3, src, 64), s_w4 = __shfl(w4, src, 64);
-        const bool any = (cl[u] >> 28) != 0u;                            // uniform over the 32 lanes of the sample
+        const int s_lp = __shfl((int)id, src, 64) & 255;
+        const float s_hh = 1.f - s_lh, s_hw = 1.f - s_lw;
+        const float s_w1 = s_hh * s_hw, s_w2 = s_hh * s_lw, s_w3 = s_lh * s_hw, s_w4 = s_lh * s_lw;
+        const bool any = (cl[u] >> 28) != 0u;                            // uniform over the 8 lanes of the sample
         const bool k1 = (cl[u] >> 28) & 1u, k2 = (cl[u] >> 29) & 1u, k3 = (cl[u] >> 30) & 1u, k4 = (cl[u] >> 31) & 1u;
         const int i1 = cl[u] & 127u, i2 = (cl[u] >> 7) & 127u, i3 = (cl[u] >> 14) & 127u, i4 = (cl[u] >> 21) & 127u;
-        const float v1 = k1 ? vpatch[i1][c] : 0.f, v2 = k2 ? vpatch[i2][c] : 0.f;
-        const float v3 = k3 ? vpatch[i3][c] : 0.f, v4 = k4 ? vpatch[i4][c] : 0.f;
-        const float top = go[u] * a_w;
-        // grad_value: fixed-point contributions, |top * w * fix| <= 2^30: exact in int32, accumulated as two's complement int64
-        const float ft = top * fix;
-        {
-          if (k1) atomicAdd(&apatch[i1][c], (unsigned long long)(long long)__float2int_rn(ft * s_w1));
-          if (k2) atomicAdd(&apatch[i2][c], (unsigned long long)(long long)__float2int_rn(ft * s_w2));
-          if (k3) atomicAdd(&apatch[i3][c], (unsigned long long)(long long)__float2int_rn(ft * s_w3));
-          if (k4) atomicAdd(&apatch[i4][c], (unsigned long long)(long long)__float2int_rn(ft * s_w4));
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 v1 = k1 ? *reinterpret_cast<const f32x4*>(&vpatch[i1][4 * j]) : z4;
+        const f32x4 v2 = k2 ? *reinterpret_cast<const f32x4*>(&vpatch[i2][4 * j]) : z4;
+        const f32x4 v3 = k3 ? *reinterpret_cast<const f32x4*>(&vpatch[i3][4 * j]) : z4;
+        const f32x4 v4 = k4 ? *reinterpret_cast<const f32x4*>(&vpatch[i4][4 * j]) : z4;
+        const f32x4 top = go[u] * a_w;
+        // grad_value: fixed-point contributions, |top * w * fix| <= 2^30: exact in int32, accumulated as two's complement int64.
+        // Branch-free: a corner outside the map adds 0 to a legal (clamped) cell -- rare, and cheaper than 16 exec-mask changes.
+        const f32x4 ft = top * fix;
+        const float f1 = k1 ? s_w1 : 0.f, f2 = k2 ? s_w2 : 0.f, f3 = k3 ? s_w3 : 0.f, f4 = k4 ? s_w4 : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          atomicAdd(&apatch[i1][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f1));
+          atomicAdd(&apatch[i2][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f2));
+          atomicAdd(&apatch[i3][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f3));
+          atomicAdd(&apatch[i4][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f4));
         }
-        // d/d(w_im), d/d(h_im), d/d(attn) (cuh:128-167), summed over the 32 channels of the head: fixed reduction tree
-        const float s_hh = 1.f - s_lh, s_hw = 1.f - s_lw;
-        float g_w = (s_hh * (v2 - v1) + s_lh * (v4 - v3)) * top * Wf;
-        float g_h = (s_hw * (v3 - v1) + s_lw * (v4 - v2)) * top * Hf;
-        float g_a = go[u] * (s_w1 * v1 + s_w2 * v2 + s_w3 * v3 + s_w4 * v4);
-        {
-          g_w = sum32(g_w);
-          g_h = sum32(g_h);
-          g_a = sum32(g_a);
+        // d/d(w_im), d/d(h_im), d/d(attn) (cuh:128-167): this lane's 4 channels in ascending order, then the 8 lanes of the
+        // sample with a fixed DPP tree
+        float g_w = 0.f, g_h = 0.f, g_a = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          g_w += (s_hh * (v2[ch] - v1[ch]) + s_lh * (v4[ch] - v3[ch])) * top[ch];
+          g_h += (s_hw * (v3[ch] - v1[ch]) + s_lw * (v4[ch] - v2[ch])) * top[ch];
+          g_a += go[u][ch] * (s_w1 * v1[ch] + s_w2 * v2[ch] + s_w3 * v3[ch] + s_w4 * v4[ch]);
         }
-        if (c == 0 && any) {   // a live sample has at least one corner inside the map (it passed the reference's bounds test)
-          const long s_sidx = (long)s_gq[u] * LP + s_lp[u];
+        g_w = sum8(g_w) * Wf;
+        g_h = sum8(g_h) * Hf;
+        g_a = sum8(g_a);
+        if (j == 0 && any) {   // a live sample has at least one corner inside the map (it passed the reference's bounds test)
+          const long s_sidx = (long)s_gq[u] * LP + s_lp;
           *reinterpret_cast<float2*>(gloc + s_sidx * 2) = make_float2(g_w, g_h);
           gwgt[s_sidx] = g_a;
         }
