@@ -1,5 +1,5 @@
 """Per-kernel timeline of the last forward in a rocprofv3 kernel trace (start/end relative to the step's first
-kernel, stream/queue) -- shows what the side-stream GEMMs overlap with.  tools/timeline.py <trace dir>"""
+kernel, stream/queue) -- shows what the side-stream kernels overlap with.  tools/timeline.py <trace dir>"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -8,8 +8,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "pack_level" in r["Kernel_Name"]]
 start = idx[-3]
 t0 = int(rows[start]["Start_Timestamp"])
-end = max(i for i, r in enumerate(rows) if "triangulate" in r["Kernel_Name"])
-print("# one forward (eager launches), us relative to the first pack kernel; q = HSA queue (main / side stream)")
+end = max(i for i, r in enumerate(rows) if "triangulate" in r["Kernel_Name"] or "finish_layer" in r["Kernel_Name"])
+print("# one forward, us relative to the first pack kernel; q = HSA queue (main / side streams)")
 print("%-42s %-4s %8s %8s  %6s" % ("kernel", "q", "start", "end", "dur"))
 for r in rows[start:end + 1]:
     n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:42]
