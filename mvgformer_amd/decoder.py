@@ -335,18 +335,17 @@ class DQDecoderLayer(MvPDecoderLayer):
             X = X.detach()                                                    # dq_decoder.py:338-339
         WH = src_spatial_shapes.flip(-1).float()
         x = self.with_pos_embed(tgt, query_pos)
-        to_dev = lambda d: {k: v.to(dev) for k, v in d.items()}
-        attn_views, r_views = [], []
-        for v in range(V):
-            cam = to_dev(meta[v]["camera"])
-            A_crop = G.crop_affine(meta[v]["center"], meta[v]["scale"], self.img_size, dev)
-            r, inside = G.project_points(X, cam, meta[v]["center"], A_crop, self.img_size)
-            ref_lvl = r.unsqueeze(2) * WH / (WH - 1)                           # dq_decoder.py:570-573
-            src_v = [s_[v * B:(v + 1) * B] for s_ in src_views]
-            a = self.proj_attn(x, ref_lvl, src_v, None, src_spatial_shapes, level_start_index)
-            attn_views.append(inside.unsqueeze(-1).to(a.dtype) * a)            # dq_decoder.py:585-586
-            r_views.append(r)
-        mean = torch.stack(attn_views, 0).mean(0)
+        # all V views as ONE batch of V*B images (image n = v*B + b, the order of src_views): one projection, one ProjAttn
+        # call and one pose MLP instead of V of each -- the training step is launch-bound (5 800 launches per step at cfg-2)
+        cam_all = {k: torch.cat([meta[v]["camera"][k].to(dev) for v in range(V)], 0)
+                   for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
+        center_all = torch.cat([meta[v]["center"].to(dev) for v in range(V)], 0)
+        A_crop = torch.cat([G.crop_affine(meta[v]["center"], meta[v]["scale"], self.img_size, dev) for v in range(V)], 0)
+        r_all, inside_all = G.project_points(X.repeat(V, 1, 1), cam_all, center_all, A_crop, self.img_size, views=V)
+        ref_lvl = r_all.unsqueeze(2) * WH / (WH - 1)                               # dq_decoder.py:570-573
+        a_all = self.proj_attn(x.repeat(V, 1, 1), ref_lvl, src_views, None, src_spatial_shapes, level_start_index)
+        a_all = inside_all.unsqueeze(-1).to(a_all.dtype) * a_all                   # dq_decoder.py:585-586
+        mean = a_all.view(V, B, Lq, C).mean(0)
         tgt_update = self.norm2(tgt + self.dropout2(self.feature_update_mlp(mean)))
         if self.open_forward_ffn:
             tgt_update = self.forward_ffn(tgt_update)
@@ -361,14 +360,10 @@ class DQDecoderLayer(MvPDecoderLayer):
             valid = prob[..., 1] > threshold
         if not bool(valid.any()):
             valid[0, 0] = True                                                 # dq_decoder.py:620-623
-        ref2d, proj2d, logit = [], [], []
-        for v in range(V):
-            off, cl = self.pose_embed(attn_views[v])
-            ref2d.append((r_views[v] + off / img) * img)
-            proj2d.append(r_views[v] * img)
-            logit.append(cl)
-        ref2d, proj2d = torch.stack(ref2d, 1), torch.stack(proj2d, 1)          # (B,V,Lq,2)
-        conf = torch.softmax(torch.stack(logit, 1), 1)
+        off, cl = self.pose_embed(a_all)                                        # (V*B,Lq,2), (V*B,Lq)
+        ref2d = ((r_all + off / img) * img).view(V, B, Lq, 2).transpose(0, 1)    # (B,V,Lq,2)
+        proj2d = (r_all * img).view(V, B, Lq, 2).transpose(0, 1)
+        conf = torch.softmax(cl.reshape(V, B, Lq).transpose(0, 1), 1)
         cam = {k: torch.stack([meta[v]["camera"][k].to(dev) for v in range(V)], 1)
                for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
         Ainv = torch.stack([meta[v]["inv_affine_trans"][:, :2, :].to(dev) for v in range(V)], 1).float()   # (B,V,2,3)

@@ -27,8 +27,9 @@ def crop_affine(center, scale, img_size, device):
     return A.float().to(device)
 
 
-def project_points(X, cam, center, A_crop, img_size):
-    """X (B,Lq,3) mm -> r (B,Lq,2) normalised network-image coords, inside (B,Lq) bool."""
+def project_points(X, cam, center, A_crop, img_size, views=1):
+    """X (B,Lq,3) mm -> r (B,Lq,2) normalised network-image coords, inside (B,Lq) bool.  views > 1: the batch is `views`
+    stacked views (image v*B' + b); the clamp bound below is then taken per view, as a per-view call would."""
     f32 = torch.float32
     R = cam["R"].to(f32)
     T = cam["T"].to(f32).reshape(-1, 3, 1)
@@ -45,7 +46,8 @@ def project_points(X, cam, center, A_crop, img_size):
     u = (f * y + c).transpose(1, 2)
     wh = center.to(u.device).unsqueeze(1) * 2
     inside = (u[..., 0] >= 0) & (u[..., 1] >= 0) & (u[..., 0] < wh[..., 0]) & (u[..., 1] < wh[..., 1])
-    u = torch.minimum(torch.clamp(u, min=-1.0), wh.max().to(u.dtype))
+    bound = wh.reshape(views, -1).amax(1).repeat_interleave(wh.shape[0] // views).view(-1, 1, 1)   # dq_decoder.py:382-383
+    u = torch.minimum(torch.clamp(u, min=-1.0), bound.to(u.dtype))
     n = torch.matmul(torch.cat([u, torch.ones_like(u[..., :1])], -1), A_crop.transpose(1, 2))
     return n / torch.tensor(img_size, dtype=f32, device=u.device), inside
 

@@ -104,6 +104,8 @@ class ProjAttn(nn.Module):
         # 39 900 vs 23 040) and a rank's shard of a query-sharded run keep the gather form.  The two forms agree to fp32
         # rounding, not bit for bit: pin it to True / False where runs with different query counts must match exactly.
         self.g_sampling_f32 = {"0": False, "1": True}.get(os.environ.get("MVG_G_SAMPLING_F32", "auto"), "auto")
+        # training path: reference-point features through the HIP sampling op (False: torch grid_sample per level)
+        self.ref_gather_native = os.environ.get("MVG_REF_GATHER", "1") != "0"
         self.sort_pairs = os.environ.get("MVG_SORT_PAIRS", "layer")
         if self.sort_pairs in ("0", "off", "False"):
             self.sort_pairs = False
@@ -278,6 +280,20 @@ class ProjAttn(nn.Module):
         return ops.msda_gsamp_chain(vp, G, xw, r, levels, B, inside, order, *chain_weights, o_masked=o_masked)
 
     # ------------------------------------------------------------------------------- forward
+    def _ref_gather(self, flat, loc, shapes, starts):
+        """bilinear features of every level at its reference point: flat (n, S, C) channels-last pyramid, loc (n, Lq, L, 2)
+        in [0, 1] map coordinates (align_corners=False, zero padding -- grid_sample's and the op's common convention)
+        -> (n, Lq, L, C), differentiable in flat and loc through DeformFunction."""
+        n, Lq, nl, _ = loc.shape
+        M = self.n_heads
+        C = flat.shape[-1]
+        locs = loc.view(n, Lq, 1, 1, nl, 1, 2).expand(n, Lq, nl, M, nl, 1, 2).reshape(n, Lq * nl, M, nl, 1, 2)
+        onehot = torch.eye(nl, dtype=flat.dtype, device=flat.device).view(1, 1, nl, 1, nl, 1)
+        w = onehot.expand(n, Lq, nl, M, nl, 1).reshape(n, Lq * nl, M, nl, 1)
+        out = DeformFunction.apply(flat.view(n, -1, M, C // M), shapes.contiguous(), starts.contiguous(), locs.contiguous(),
+                                   w.contiguous(), self.im2col_step)
+        return out.view(n, Lq, nl, C)
+
     def forward(self, query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,
                 input_level_start_index, input_padding_mask=None):
         """Reference signature (projattn.py:115-117).  query (n_views, Lq, C); reference_points
@@ -303,15 +319,23 @@ class ProjAttn(nn.Module):
                                       1, n_views)
             return out.view(n_views, Len_q, c).to(query.dtype)
         sample_grid = torch.clamp(reference_points * 2.0 - 1.0, -1.1, 1.1)
-        feats = [F.grid_sample(src_views[l], sample_grid[:, :, l:l + 1, :], align_corners=False).squeeze(-1)
-                 .permute(0, 2, 1) for l in range(feat_lvls)]
         input_flatten = torch.cat([s.flatten(2) for s in src_views], dim=-1).permute(0, 2, 1)
         assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == input_flatten.shape[1]
+        if self.ref_gather_native and input_flatten.dtype == torch.float32:
+            # reference-point features through the sampling op itself (forward AND deterministic backward kernels) instead
+            # of L grid_sample launches on the NCHW maps (projattn.py:134-141; 17 % of a training step): the channels-last
+            # pyramid is the op's value with M heads of C / M channels, token (q, l) samples level l at the clamped
+            # reference point with weight 1 (one point per level, the other levels' weights are 0).
+            input_flatten = input_flatten.contiguous()
+            feats = self._ref_gather(input_flatten, (sample_grid + 1.0) * 0.5, input_spatial_shapes, input_level_start_index)
+        else:
+            feats = torch.stack([F.grid_sample(src_views[l], sample_grid[:, :, l:l + 1, :], align_corners=False).squeeze(-1)
+                                 .permute(0, 2, 1) for l in range(feat_lvls)], dim=2)
         value = self.rayconv(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(n_views, -1, self.n_heads, self.d_model // self.n_heads)
-        xin = torch.stack(feats, dim=2) + query.unsqueeze(2)
+        xin = feats + query.unsqueeze(2)
         sampling_offsets = self.sampling_offsets(xin).view(n_views, Len_q, self.n_heads, feat_lvls, self.n_points, 2)
         attention_weights = self.attention_weights(xin).view(n_views, Len_q, self.n_heads, feat_lvls * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(n_views, Len_q, self.n_heads, feat_lvls,

@@ -450,6 +450,46 @@ def test_decoder_layer_training_path_matches_inference_and_backprops():
         assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name
 
 
+def test_training_path_reference_point_gather_through_the_sampling_op():
+    """ProjAttn under autograd: the reference-point features come from the HIP sampling op (one point per level, forward and
+    deterministic backward kernels) -- same output and same gradients (query, reference points incl. points at and beyond the
+    map border, feature maps, every weight) as L torch grid_sample calls on the NCHW maps (projattn.py:134-141)."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case("mini5_b2")
+    dec = build_decoder_for_case(case, DEV)
+    gc = case_to_device(case, DEV)
+    pa = dec.layers[0].proj_attn
+    B = case.B
+    nl = len(gc.src_views)
+    gen = torch.Generator().manual_seed(3)
+    Lq = 240
+    ref = (torch.rand((B, Lq, nl, 2), generator=gen) * 1.3 - 0.15).to(DEV)          # some outside, some past the clamp
+    ref[:, :4] = torch.tensor([0.0, 1.0], device=DEV)                                # corners
+    q0 = torch.randn((B, Lq, 256), generator=gen).to(DEV)
+    src0 = [s_[:B].clone() for s_ in gc.src_views]
+    res = {}
+    for native in (False, True):
+        pa.ref_gather_native = native
+        q = q0.clone().requires_grad_(True)
+        r = ref.clone().requires_grad_(True)
+        src = [t.clone().requires_grad_(True) for t in src0]
+        for p_ in pa.parameters():
+            p_.grad = None
+        out = pa(q, r, src, None, gc.spatial_shapes, gc.level_start_index)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        (out * w).sum().backward()
+        res[native] = (out.detach(), q.grad, r.grad, [t.grad for t in src], {n: p_.grad.clone() for n, p_ in pa.named_parameters()})
+    a, b = res[False], res[True]
+    rel = lambda x, y: float((x - y).abs().max()) / max(float(x.abs().max()), 1e-12)
+    assert rel(a[0], b[0]) < 2e-5, rel(a[0], b[0])
+    assert rel(a[1], b[1]) < 5e-5 and rel(a[2], b[2]) < 2e-4, (rel(a[1], b[1]), rel(a[2], b[2]))
+    for x, y in zip(a[3], b[3]):
+        assert rel(x, y) < 5e-5, rel(x, y)
+    for n in a[4]:
+        assert rel(a[4][n], b[4][n]) < 1e-4, (n, rel(a[4][n], b[4][n]))
+    pa.ref_gather_native = True
+
+
 def test_bf16_fast_path_matches_generic_kernels():
     """bf16 fast path (weight-stationary value / G projections into the pixel-pair layout + G-sampling kernel:
     Linear and bilinear sampling commute) vs the generic bf16 kernels (ref-point gather -> per-row Linear ->
