@@ -102,10 +102,13 @@ __device__ __forceinline__ int sample_bin(const float* __restrict__ loc, const B
 
 // MODE 0: cnt[(n * PARTS + part) * bpi + bin] = samples of the part in the bin.
 // MODE 1: cnt holds the part's first position of every bin (bw_prefix_kernel + bin offsets); writes list.
+// MODE 1 also writes the zero location / weight gradients of the samples that fail the reference's bounds test: they are
+// never binned, so nobody else writes them (this replaces two memsets of the whole gradient tensors).
 template <int MODE>
 __global__ __launch_bounds__(1024) void bw_part_kernel(const float* __restrict__ loc, BwLevels lv, int* __restrict__ cnt,
                                                        const int* __restrict__ offset, unsigned* __restrict__ list, int Lq, int M,
-                                                       int P, int bpi, long per_img, long chunk) {
+                                                       int P, int bpi, long per_img, long chunk, float* __restrict__ gloc,
+                                                       float* __restrict__ gwgt) {
   extern __shared__ int hist[];
   const int n = blockIdx.x / BW_PARTS, part = blockIdx.x % BW_PARTS, tid = threadIdx.x;
   int* mine = cnt + ((long)n * BW_PARTS + part) * bpi;
@@ -115,7 +118,14 @@ __global__ __launch_bounds__(1024) void bw_part_kernel(const float* __restrict__
   const int LP = lv.L * P;
   for (long s = s0 + tid; s < s1; s += 1024) {
     const int bin = sample_bin(loc, lv, n, s, Lq, M, P, LP);
-    if (bin < 0) continue;
+    if (bin < 0) {
+      if (MODE == 1) {
+        const long sidx = (long)n * per_img + s;
+        *reinterpret_cast<float2*>(gloc + sidx * 2) = make_float2(0.f, 0.f);
+        gwgt[sidx] = 0.f;
+      }
+      continue;
+    }
     const int pos = atomicAdd(&hist[bin], 1);
     if (MODE == 1) list[pos] = ((unsigned)(s / ((long)M * LP)) << 8) | (unsigned)(s % LP);      // (q, lp); m is the bin's
   }
@@ -125,19 +135,37 @@ __global__ __launch_bounds__(1024) void bw_part_kernel(const float* __restrict__
   }
 }
 
-// per (image, bin): exclusive prefix of the counts over the parts (in place) and the bin total
+// per (image, bin): exclusive prefix of the counts over the parts (in place) and the bin total.  8 lanes per bin, 16 parts
+// each (one thread per bin walked 128 dependent strided loads: 19 us for 5 040 bins), combined with a 3-step lane scan.
 __global__ __launch_bounds__(256) void bw_prefix_kernel(int* __restrict__ cnt, int* __restrict__ total, int bpi) {
-  const int n = blockIdx.y, bin = blockIdx.x * 256 + threadIdx.x;
-  if (bin >= bpi) return;
-  int* c = cnt + (long)n * BW_PARTS * bpi + bin;
-  int run = 0;
-#pragma unroll 8
-  for (int p = 0; p < BW_PARTS; ++p) {
-    const int v = c[(long)p * bpi];
-    c[(long)p * bpi] = run;
-    run += v;
+  static_assert(BW_PARTS % 8 == 0, "8 lanes per bin");
+  constexpr int PPL = BW_PARTS / 8;
+  const int n = blockIdx.y, sub = threadIdx.x >> 5, bin = blockIdx.x * 32 + (threadIdx.x & 31);
+  // lanes of a wavefront: bins (lane & 31) for sub = 2 w and 2 w + 1; a bin's 8 sub-ranges live in 4 wavefronts -> combine in LDS
+  __shared__ int part_sum[8][32];
+  const bool ok = bin < bpi;
+  int* c = cnt + (long)n * BW_PARTS * bpi + (ok ? bin : 0) + (long)sub * PPL * bpi;
+  int v[PPL], run = 0;
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) v[p] = ok ? c[(long)p * bpi] : 0;
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) run += v[p];
+  part_sum[sub][threadIdx.x & 31] = run;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int t = part_sum[k][threadIdx.x & 31];
+    base += k < sub ? t : 0;
+    tot += t;
   }
-  total[(long)n * bpi + bin] = run;
+  if (!ok) return;
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    c[(long)p * bpi] = base;
+    base += v[p];
+  }
+  if (sub == 0) total[(long)n * bpi + bin] = tot;
 }
 
 // exclusive scan of the bin totals over all images (one workgroup; a few 10 000 entries): offset[i], offset[nb] = all
@@ -195,7 +223,8 @@ __device__ __forceinline__ float sum8(float v) {
 __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ wgt, const float* __restrict__ gout,
     BwLevels lv, const int* __restrict__ offset, const unsigned* __restrict__ list, const unsigned* __restrict__ gmax_bits,
-    unsigned long long* __restrict__ accum, float* __restrict__ gloc, float* __restrict__ gwgt, int N, int S, int Lq, int M, int P) {
+    unsigned long long* __restrict__ accum, float* __restrict__ gvalue, float* __restrict__ gloc, float* __restrict__ gwgt, int N,
+    int S, int Lq, int M, int P) {
   __shared__ float vpatch[BW_P * BW_P][BW_D];                           // 10.1 KB
   __shared__ unsigned long long apatch[BW_P * BW_P][BW_D];              // 20.3 KB
   // BW_SPLIT workgroups share a bin (interleaved passes over its entries): bins differ a lot in size -- a coarse-level tile
@@ -206,8 +235,8 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   // all heads on every XCD ran 2.3x slower (its grad_output rows came from HBM / Infinity Cache)
   const int m_ = blockIdx.x % M, rest_ = blockIdx.x / M;
   const int split = rest_ % BW_SPLIT, bin = (rest_ / BW_SPLIT) * M + m_;
+  static_assert(BW_SPLIT == 1, "the interior of a tile is written by exactly one workgroup");
   const int e0 = offset[bin], e1 = offset[bin + 1];
-  if (e0 + split * (BW_NT / 64) * 64 >= e1) return;          // nothing in this workgroup's first pass
   const int m = bin % M;
   const int nt = bin / M;
   const int n = nt / lv.T_total, tile = nt - n * lv.T_total;
@@ -220,6 +249,18 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   const int y0 = (tl / lv.tiles_w[l]) * BW_T, x0 = (tl % lv.tiles_w[l]) * BW_T;     // patch origin (pixel)
   const int tid = threadIdx.x;
   const long row_stride = (long)M * BW_D;
+  // Pixels with x % T != 0 and y % T != 0 receive contributions from THIS tile only (a neighbour's patch reaches just its first
+  // row / column): they are written straight to grad_value, no global accumulator, no memset, no conversion pass for 49 of 64
+  // pixels.  The first row and column of every tile are shared with up to three neighbours and go through `accum`.
+  float* gbase = gvalue + ((long)n * S + lv.start[l]) * row_stride + (long)m * BW_D;
+  if (e0 + split * (BW_NT / 64) * 64 >= e1) {                // an empty bin still owns its interior: zeros
+    for (int i = tid; i < (BW_T - 1) * (BW_T - 1) * BW_D; i += BW_NT) {
+      const int px = i >> 5, ch = i & 31;
+      const int y = y0 + 1 + px / (BW_T - 1), x = x0 + 1 + px % (BW_T - 1);
+      if (y < H && x < W) gbase[((long)y * W + x) * row_stride + ch] = 0.f;
+    }
+    return;
+  }
   const float* vbase = value + ((long)n * S + lv.start[l]) * row_stride + (long)m * BW_D;
   for (int i = tid; i < BW_P * BW_P * BW_D; i += BW_NT) {
     const int px = i >> 5, ch = i & 31;
@@ -303,12 +344,20 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
         // Branch-free: a corner outside the map adds 0 to a legal (clamped) cell -- rare, and cheaper than 16 exec-mask changes.
         const f32x4 ft = top * fix;
         const float f1 = k1 ? s_w1 : 0.f, f2 = k2 ? s_w2 : 0.f, f3 = k3 ? s_w3 : 0.f, f4 = k4 ? s_w4 : 0.f;
+        // Every patch cell is one 256-byte row = all 64 LDS banks, and lane (sample g8, j) adds to banks 8 j + 2 ch (+1) of ITS
+        // cell: with the same channel order on all 8 samples of the wavefront every instruction hit 16 banks 8 deep (PMC: 65 % of
+        // the kernel's LDS cycles were bank conflicts).  Sample g8 therefore walks its 4 channels starting at channel g8 & 3:
+        // 4 of the 8 samples are on disjoint banks at any step (2-way is the floor: 512 bytes per instruction on a 256-byte LDS).
+        const int rot = g8 & 3;
+        const f32x4 fa = (rot & 1) ? f32x4{ft[1], ft[2], ft[3], ft[0]} : ft;
+        const f32x4 fr = (rot & 2) ? f32x4{fa[2], fa[3], fa[0], fa[1]} : fa;         // fr[t] = ft[(t + rot) & 3]
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-          atomicAdd(&apatch[i1][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f1));
-          atomicAdd(&apatch[i2][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f2));
-          atomicAdd(&apatch[i3][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f3));
-          atomicAdd(&apatch[i4][4 * j + ch], (unsigned long long)(long long)__float2int_rn(ft[ch] * f4));
+        for (int t = 0; t < 4; ++t) {
+          const int cc = 4 * j + ((t + rot) & 3);
+          atomicAdd(&apatch[i1][cc], (unsigned long long)(long long)__float2int_rn(fr[t] * f1));
+          atomicAdd(&apatch[i2][cc], (unsigned long long)(long long)__float2int_rn(fr[t] * f2));
+          atomicAdd(&apatch[i3][cc], (unsigned long long)(long long)__float2int_rn(fr[t] * f3));
+          atomicAdd(&apatch[i4][cc], (unsigned long long)(long long)__float2int_rn(fr[t] * f4));
         }
         // d/d(w_im), d/d(h_im), d/d(attn) (cuh:128-167): this lane's 4 channels in ascending order, then the 8 lanes of the
         // sample with a fixed DPP tree
@@ -332,19 +381,39 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   }
   __syncthreads();
   unsigned long long* abase = accum + (((long)n * S + lv.start[l]) * M + m) * BW_D;
+  const double inv = (double)gmax / (double)BW_FIX;                      // bw_convert_kernel's arithmetic
   for (int i = tid; i < BW_P * BW_P * BW_D; i += BW_NT) {
     const int px = i >> 5, ch = i & 31;
-    const int y = y0 + px / BW_P, x = x0 + px % BW_P;
+    const int py = px / BW_P, pxx = px % BW_P;
+    const int y = y0 + py, x = x0 + pxx;
     const unsigned long long v = apatch[px][ch];
-    if (v != 0ull && y < H && x < W) atomicAdd(abase + ((long)y * W + x) * M * BW_D + ch, v);
+    if (y >= H || x >= W) continue;
+    if (py % BW_T != 0 && pxx % BW_T != 0) gbase[((long)y * W + x) * row_stride + ch] = (float)((double)(long long)v * inv);
+    else if (v != 0ull) atomicAdd(abase + ((long)y * W + x) * M * BW_D + ch, v);
   }
 }
 
-__global__ __launch_bounds__(256) void bw_convert_kernel(const long long* __restrict__ accum, const unsigned* __restrict__ gmax_bits,
-                                                         float* __restrict__ gvalue, long n) {
-  const double inv = (double)__uint_as_float(gmax_bits[0]) / (double)BW_FIX;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    gvalue[i] = (float)((double)accum[i] * inv);
+// The shared pixels (x % T == 0 or y % T == 0) of every map, one workgroup per (map row, 32-pixel segment):
+//   MODE 0: accum <- 0 (before the reduce kernel; also resets the scale word)   MODE 1: grad_value <- accum * gmax / 2^30
+template <int MODE>
+__global__ __launch_bounds__(256) void bw_shared_kernel(unsigned long long* __restrict__ accum, unsigned* __restrict__ gmax_bits,
+                                                        float* __restrict__ gvalue, BwLevels lv, int S, int M, int rows_per_img) {
+  if (MODE == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) gmax_bits[0] = 0u;
+  const int n = blockIdx.x / rows_per_img;
+  int y = blockIdx.x - n * rows_per_img, l = 0;
+  while (l + 1 < lv.L && y >= lv.H[l]) y -= lv.H[l++];
+  const int W = lv.W[l], xa = blockIdx.y * 32;
+  if (xa >= W) return;
+  const int step = (y % BW_T == 0) ? 1 : BW_T, xb = min(W, xa + 32);
+  const int per_px = M * BW_D;
+  const double inv = MODE == 1 ? (double)__uint_as_float(gmax_bits[0]) / (double)BW_FIX : 0.0;
+  for (int x = xa; x < xb; x += step) {                       // xa is a multiple of 32, hence of T
+    const long base = (((long)n * S + lv.start[l]) + (long)y * W + x) * per_px;
+    for (int e = threadIdx.x; e < per_px; e += 256) {
+      if (MODE == 0) accum[base + e] = 0ull;
+      else gvalue[base + e] = (float)((double)(long long)accum[base + e] * inv);
+    }
+  }
 }
 
 int fill_bw_levels(BwLevels* lv, const int64_t* shapes_host, const int64_t* starts_host, int L) {
@@ -420,12 +489,8 @@ int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, co
   int* offset = reinterpret_cast<int*>(ws + w.offset);
   unsigned* list = reinterpret_cast<unsigned*>(ws + w.list);
   unsigned* gmax = reinterpret_cast<unsigned*>(ws + w.gmax);
-  hipError_t he = hipMemsetAsync(accum, 0, (size_t)N * S * M * BW_D * 8, st);
-  if (he == hipSuccess) he = hipMemsetAsync(gmax, 0, 4, st);
-  // samples that fail the reference's bounds test get zero location / weight gradients and are never binned
-  if (he == hipSuccess) he = hipMemsetAsync(grad_sampling_loc, 0, (size_t)nsamp * 2 * sizeof(float), st);
-  if (he == hipSuccess) he = hipMemsetAsync(grad_attn_weight, 0, (size_t)nsamp * sizeof(float), st);
-  if (he != hipSuccess) return (int)he;
+  hipError_t he = hipSuccess;
+  (void)nsamp;
   static bool configured[MVG_MAX_DEVICES] = {};       // > 64 KB of dynamic LDS is a per-device function attribute
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
@@ -439,21 +504,26 @@ int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, co
     configured[dev] = true;
   }
   const long ngo = (long)N * Lq * M * BW_D;
+  int rows_per_img = 0, max_w = 0;
+  for (int l = 0; l < L; ++l) {
+    rows_per_img += lv.H[l];
+    max_w = lv.W[l] > max_w ? lv.W[l] : max_w;
+  }
+  const dim3 shared_grid((unsigned)(N * rows_per_img), (unsigned)((max_w + 31) / 32));
+  hipLaunchKernelGGL((bw_shared_kernel<0>), shared_grid, dim3(256), 0, st, accum, gmax, grad_value, lv, S, M, rows_per_img);
   hipLaunchKernelGGL(bw_absmax_kernel, dim3(512), dim3(256), 0, st, grad_output, ngo, gmax);
   const long chunk = (per_img + BW_PARTS - 1) / BW_PARTS;
   const size_t lds = (size_t)bpi * 4;
   hipLaunchKernelGGL((bw_part_kernel<0>), dim3(N * BW_PARTS), dim3(1024), lds, st, sampling_loc, lv, cnt, (const int*)nullptr,
-                     (unsigned*)nullptr, Lq, M, P, (int)bpi, per_img, chunk);
-  hipLaunchKernelGGL(bw_prefix_kernel, dim3((unsigned)((bpi + 255) / 256), N), dim3(256), 0, st, cnt, total, (int)bpi);
+                     (unsigned*)nullptr, Lq, M, P, (int)bpi, per_img, chunk, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bw_prefix_kernel, dim3((unsigned)((bpi + 31) / 32), N), dim3(256), 0, st, cnt, total, (int)bpi);
   hipLaunchKernelGGL(bw_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)total, offset, (int)nbins);
   hipLaunchKernelGGL((bw_part_kernel<1>), dim3(N * BW_PARTS), dim3(1024), lds, st, sampling_loc, lv, cnt, (const int*)offset,
-                     list, Lq, M, P, (int)bpi, per_img, chunk);
+                     list, Lq, M, P, (int)bpi, per_img, chunk, grad_sampling_loc, grad_attn_weight);
   hipLaunchKernelGGL(bw_reduce_kernel, dim3((unsigned)(nbins * BW_SPLIT)), dim3(BW_NT), 0, st, value, sampling_loc, attn_weight,
-                     grad_output, lv, (const int*)offset, (const unsigned*)list, (const unsigned*)gmax, accum,
+                     grad_output, lv, (const int*)offset, (const unsigned*)list, (const unsigned*)gmax, accum, grad_value,
                      grad_sampling_loc, grad_attn_weight, N, S, Lq, M, P);
-  const long nv = (long)N * S * M * BW_D;
-  hipLaunchKernelGGL(bw_convert_kernel, dim3((unsigned)(nv / 2048 + 1 < 4096 ? nv / 2048 + 1 : 4096)), dim3(256), 0, st,
-                     (const long long*)accum, (const unsigned*)gmax, grad_value, nv);
+  hipLaunchKernelGGL((bw_shared_kernel<1>), shared_grid, dim3(256), 0, st, accum, gmax, grad_value, lv, S, M, rows_per_img);
   MVG_LAUNCH_CHECK();
   return 0;
 }

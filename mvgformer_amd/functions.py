@@ -4,6 +4,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import deformable as DF
+from . import ops
 
 
 class DeformFunction(Function):
@@ -15,11 +16,16 @@ class DeformFunction(Function):
                                    attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                               attention_weights)
+        # host copies of the level tables for the deterministic backward (its binning workspace is sized on the host): looked
+        # up here, where the tensors are the caller's own objects and usually carry the copy already -- not a sync per backward
+        ctx.host_levels = ops.host_levels(value_spatial_shapes, value_level_start_index) if value.is_cuda else None
         return output
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, starts, loc, attn = ctx.saved_tensors
-        gv, gl, ga = DF.deform_backward(value, shapes, starts, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+        DF._check_step(value, ctx.im2col_step)
+        with DF._device_of(value):
+            gv, gl, ga = ops.msda_backward(value, shapes, starts, loc, attn, grad_output.contiguous(), host=ctx.host_levels)
         return gv, None, None, gl, ga, None

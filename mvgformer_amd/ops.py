@@ -55,6 +55,26 @@ def _i64_host(t):
     return (C.c_int64 * len(flat))(*flat.tolist()), flat
 
 
+def host_levels(spatial_shapes, level_start_index):
+    """(shapes_c, starts_c) host ctypes copies of the two level tables.  A device tensor costs one D2H sync the first time it is
+    seen; the copy is then kept ON THE TENSOR OBJECT (valid while its version counter is unchanged), so a training loop that
+    reuses its level tensors -- and the backward of a forward that already looked them up -- never syncs again."""
+    out = []
+    for t in (spatial_shapes, level_start_index):
+        cached = getattr(t, "_mvg_host", None) if isinstance(t, torch.Tensor) else None
+        if cached is not None and cached[0] == t._version:
+            out.append(cached[1])
+            continue
+        arr, _ = _i64_host(t)
+        if isinstance(t, torch.Tensor):
+            try:
+                t._mvg_host = (t._version, arr)
+            except Exception:      # pragma: no cover - tensor subclasses without a __dict__
+                pass
+        out.append(arr)
+    return tuple(out)
+
+
 class Levels:
     """Host copy of (spatial_shapes, level_start_index): avoids a D2H sync per call."""
 
@@ -103,8 +123,9 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
     return out
 
 
-def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
-    """Deformable.deform_backward (lib/models/ops/src/deform.h:53-72)."""
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, host=None):
+    """Deformable.deform_backward (lib/models/ops/src/deform.h:53-72).  host: host_levels(...) of the two tables when the
+    caller already has them (DeformFunction keeps the forward's)."""
     L.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
     if value.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("deform_backward: float32 / float64 only")        # AT_DISPATCH_FLOATING_TYPES, deform_cuda.cu:145
@@ -117,8 +138,7 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     if value.dtype == torch.float32 and BACKWARD_MODE != "atomic":
         # deterministic form (csrc/msda_bwd.hip): binned by destination tile, fixed-point accumulation in LDS
         lib = L.load()
-        shapes_c, _ = _i64_host(spatial_shapes)
-        starts_c, _ = _i64_host(level_start_index)
+        shapes_c, starts_c = host if host is not None else host_levels(spatial_shapes, level_start_index)
         ws_bytes = int(lib.mvg_msda_backward_det_workspace(N, S, M, D, nl, Lq, P, shapes_c))
         if ws_bytes:
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
