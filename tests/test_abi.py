@@ -115,3 +115,21 @@ def test_every_reference_yaml_entry_point_builds_a_decoder():
         layer._check_supported()                                  # every shipped YAML is on the built hot path
         assert layer.proj_attn.n_points == 8 and layer.proj_attn.n_heads == 8 and layer.num_joints == 15
         assert len(layer.state_dict()) == 32
+
+
+def test_host_level_tables_are_cached_per_tensor_and_follow_in_place_updates():
+    """ops.host_levels keeps the host copy of (spatial_shapes, level_start_index) on the tensor object (so the deterministic
+    backward sizes its workspace without a D2H sync per call) and drops it when the tensor is modified in place."""
+    import torch
+    from mvgformer_amd import ops
+    shapes = torch.tensor([[8, 12], [4, 6]], dtype=torch.long)
+    starts = torch.tensor([0, 96], dtype=torch.long)
+    a = ops.host_levels(shapes, starts)
+    b = ops.host_levels(shapes, starts)
+    assert a[0] is b[0] and a[1] is b[1]                       # second lookup: the cached ctypes arrays
+    assert list(a[0]) == [8, 12, 4, 6] and list(a[1]) == [0, 96]
+    shapes[1, 0] = 5                                           # bumps the version counter
+    c = ops.host_levels(shapes, starts)
+    assert c[0] is not a[0] and list(c[0]) == [8, 12, 5, 6] and c[1] is a[1]
+    other = ops.host_levels(shapes.clone(), starts)            # a different tensor object never sees somebody else's copy
+    assert other[0] is not c[0] and list(other[0]) == [8, 12, 5, 6]
