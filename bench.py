@@ -338,6 +338,7 @@ def main():
 
         # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
         prof = {}
+        live_frac = None
         if sharded:
             mdist.install_any_valid_sync(dec, None)
         if args.profile_steps > 0:                 # every rank runs it (the sharded forward contains collectives)
@@ -347,10 +348,24 @@ def main():
             # that the roofline figure is the sampling kernel's own duration (as in the rocprofv3 kernel trace of
             # tools/prof.sh), not its duration while sharing the GPU with a GEMM
             overlap, dec.overlap_pyramid = getattr(dec, "overlap_pyramid", False), False
-            for _ in range(args.profile_steps):
-                forward()
-            torch.cuda.synchronize()
+            # fraction of (image, query) pairs inside their image, per sampling launch (the others are skipped): recorded here,
+            # in the eager pass, for the L1-path figure of the roofline object
+            live_fracs = []
+            gsamp_orig = ops.msda_gsamp
+
+            def gsamp_counting(vp, G_, xw, r, levels, B_, pair_mask=None, order=None):
+                if pair_mask is not None:
+                    live_fracs.append(pair_mask.float().mean())
+                return gsamp_orig(vp, G_, xw, r, levels, B_, pair_mask=pair_mask, order=order)
+            ops.msda_gsamp = gsamp_counting
+            try:
+                for _ in range(args.profile_steps):
+                    forward()
+                torch.cuda.synchronize()
+            finally:
+                ops.msda_gsamp = gsamp_orig
             dec.overlap_pyramid = overlap
+            live_frac = float(torch.stack(live_fracs).mean()) if live_fracs else None
             if rank == 0:
                 prof = ops.profile_summary()
                 ops.PROFILE = None
@@ -412,6 +427,20 @@ def main():
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
                 "fused_minimum_bytes_per_launch": V * (S * 256 + Lq_loc * 256) * elem}
+        if samp_key == "msda_gsamp":
+            # The roof this kernel actually runs against: its gathers are served by the L1s, which deliver
+            # 55-57 B/clk/CU = ~35 TB/s to loads of this shape (tools/probes/l1_gather_probe).  Bytes delivered to the lanes per
+            # launch: every in-image (pair, head) gathers L*P samples x 4 corners x 64 B of value rows + 4 corners x 9 x 16 B of G.
+            live = live_frac if live_frac is not None else 1.0
+            n_lv, n_pt, n_head = len(case.shapes), 8, 8
+            per_unit = n_lv * n_pt * 4 * 64 + 4 * 9 * 16
+            delivered = int(V * Lq_loc * n_head * per_unit * live)
+            l1_peak = 57.0 * 256 * 2.4           # GB/s: 57 B/clk/CU x 256 CUs x 2.4 GHz
+            roof["l1_path"] = {"delivered_bytes_per_launch": delivered, "in_image_pair_fraction": round(live, 4),
+                               "achieved": round(delivered / (ms * 1e-3) / 1e9, 1), "peak": round(l1_peak, 1), "unit": "GB/s",
+                               "frac": round(delivered / (ms * 1e-3) / 1e9 / l1_peak, 4),
+                               "note": "binding roof of the gather kernel: what the L1s deliver to 16-byte-per-lane gathers (one wave "
+                                       "instruction per 16 clk, tools/probes/l1_gather_probe); pairs outside their image are skipped"}
     kern = {k: {"launches": n, "avg_us": round(ms * 1e3, 2)} for k, (n, ms) in sorted(prof.items())}
     # per-rank time split (kernel time per forward from the eager profile pass, each kernel alone): "fixed" = work that does
     # not shrink when the queries are sharded (pyramid packing + the query-independent pyramid GEMMs, replicated on every
