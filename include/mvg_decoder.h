@@ -62,6 +62,7 @@ const char* mvg_version(void);
  *   "auto_small" = 1 | 0 : launches with few queries per image (<= 8192 joint tokens, e.g. a rank's shard of a
  *       query-sharded run) use 128-thread sampling workgroups and single-block chunks (bit-identical results);
  *   "auto_small_b" = 1 | 0 : chain B with 32-row tiles (2 persons) while that leaves at most 128 of the 64-row tiles;
+ *   "auto_small_a" = 1 | 0 : chain A with 64-row tiles while the launch has at most 320 tiles of 128 rows (bit-identical rows);
  *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
  *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs;
  *   "bin_multi" = 1 | 0 : multi-workgroup binning for large Lq (needs the workspace of mvg_bin_pairs);

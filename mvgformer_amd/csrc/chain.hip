@@ -408,6 +408,7 @@ int g_chain_ring = 4;     // tuning knob "chain_ring": weight prefetch depth (k-
 int g_chain_split = 1;    // tuning knob "chain_split": 1 = column-split wave mapping of chain B (JN = 1), 0 = row-block split
 int g_chain_waves = 8;    // tuning knob "chain_waves": wavefronts per workgroup of chain B (4 | 8); measured 86 -> 69 us
 int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 measured slower: 93 vs 79 us)
+int g_auto_small_a = 1;   // tuning knob "auto_small_a": chain A with 64-row tiles while the launch has at most 320 tiles of 128 rows
 int g_auto_small_b = 1;   // tuning knob "auto_small_b": chain B with 32-row tiles when that still leaves <= 128 64-row tiles
 int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128); 128: 65 -> 55 us (half the
                        // weight bytes per row through the L1 miss path, the resource that bounds these kernels)
@@ -441,10 +442,13 @@ extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, cons
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  // NOTE: the tile size is NOT chosen by the row count (64-row tiles are 2 % faster for a rank's shard of a
-  // query-sharded run): the last pose layer's fp32 reduction order differs between the variants in the last bit, and
-  // o_masked (one row, computed by whatever variant this function picks) must equal a masked row computed inside a
-  // mixed tile of the big launch -- which rows those are changes from run to run with the binning order.
+  // Every variant computes a row bit-identically (stage GEMMs: the k-step order depends on the column group only; last pose layer:
+  // a reduction tree that does not depend on the threads per row, chain_a_body), so the tile size may follow the row count: with
+  // at most 320 tiles of 128 rows -- a rank's shard of a query-sharded run, small scenes -- 64-row tiles put twice as many
+  // workgroups on the chip (measured at cfg-2 with 128 / 256 / 512 queries: -2.6 / -0.6 / -1.4 % of the forward; the full 1024
+  // queries are 1.4 % faster with 128-row tiles).
+  if (g_auto_small_a && g_chain_rm == 128 && g_chain_a_waves == 4 && rows <= 320 * 128)
+    return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 128 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<128, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 64 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<64, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);

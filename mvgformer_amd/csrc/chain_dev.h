@@ -268,31 +268,53 @@ __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* 
   __syncthreads();
   write_act<MT, JN>(act, acc, b1, true, all, tid);
   __syncthreads();
-  // last layer (3 outputs): 4 threads per row (RM = 64) / 8 threads per row (RM = 32)
-  constexpr int TPR = NT / RM, CPT = 256 / TPR;
+  // last layer (3 outputs): TPR = 2 | 4 | 8 threads per row (RM = 128 | 64 | 32 rows on 256 threads, ...).  The 256-term dot
+  // products are summed in an order that does NOT depend on TPR: eight 32-column chunk sums c0..c7 (each accumulated in column
+  // order), then the balanced tree ((c0+c1)+(c2+c3)) + ((c4+c5)+(c6+c7)) -- inside a lane while it owns several chunks, across
+  // lanes (DPP) after that.  Every tile size therefore gives bit-identical rows, and the launcher may pick it by the row count.
+  constexpr int TPR = NT / RM, CPT = 256 / TPR, NCHK = CPT / 32;
+  static_assert(TPR == 2 || TPR == 4 || TPR == 8, "threads per row of the last pose layer");
   const int row = tid / TPR, part = tid % TPR;
-  float s[3] = {0.f, 0.f, 0.f};
+  float s[3];
+  {
+    float cs[3][NCHK];
 #pragma unroll
-  for (int c = 0; c < CPT; c += 8) {
-    const uint4 hv = *reinterpret_cast<const uint4*>(act + row * ACT_PITCH + (part * CPT + c) * 2);
-    const unsigned w4[4] = {hv.x, hv.y, hv.z, hv.w};
-    float hf[8];
+    for (int q = 0; q < NCHK; ++q) {
+      float a3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      hf[2 * t] = __uint_as_float(w4[t] << 16);
-      hf[2 * t + 1] = __uint_as_float(w4[t] & 0xffff0000u);
+      for (int c = 0; c < 32; c += 8) {
+        const int col = part * CPT + q * 32 + c;
+        const uint4 hv = *reinterpret_cast<const uint4*>(act + row * ACT_PITCH + col * 2);
+        const unsigned w4[4] = {hv.x, hv.y, hv.z, hv.w};
+        float hf[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          hf[2 * t] = __uint_as_float(w4[t] << 16);
+          hf[2 * t + 1] = __uint_as_float(w4[t] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col + 4);
+          a3[k] += hf[0] * wa[0] + hf[1] * wa[1] + hf[2] * wa[2] + hf[3] * wa[3] + hf[4] * wb[0] + hf[5] * wb[1] +
+                   hf[6] * wb[2] + hf[7] * wb[3];
+          // Keep the three accumulators scalar.  hipcc (ROCm 7.2) pairs them into v_pk_mul/v_pk_fma_f32 fed by
+          // v_mov/v_pk_mov shuffles of the ds_read_b128 results, and that sequence returned wrong sums in lanes 48-63 of
+          // a wavefront, run-to-run differently, whenever two workgroups shared a CU (found by tools/soak.py; the
+          // packed pair was always the culprit: component 2, computed with scalar FMAs, never differed).
+          asm volatile("" : "+v"(a3[k]));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cs[k][q] = a3[k];
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + part * CPT + c);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + part * CPT + c + 4);
-      s[k] += hf[0] * wa[0] + hf[1] * wa[1] + hf[2] * wa[2] + hf[3] * wa[3] + hf[4] * wb[0] + hf[5] * wb[1] +
-              hf[6] * wb[2] + hf[7] * wb[3];
-      // Keep the three accumulators scalar.  hipcc (ROCm 7.2) pairs s[0], s[1] into v_pk_mul/v_pk_fma_f32 fed by
-      // v_mov/v_pk_mov shuffles of the ds_read_b128 results, and that sequence returned wrong sums in lanes 48-63 of
-      // a wavefront, run-to-run differently, whenever two workgroups shared a CU (found by tools/soak.py; the
-      // packed pair was always the culprit: component 2, computed with scalar FMAs, never differed).
-      asm volatile("" : "+v"(s[k]));
+      float v;
+      if (NCHK == 4) v = (cs[k][0] + cs[k][1]) + (cs[k][2] + cs[k][3]);
+      else if (NCHK == 2) v = cs[k][0] + cs[k][1];
+      else v = cs[k][0];
+      s[k] = v;
     }
   }
   // sum over the TPR (2 | 4 | 8) adjacent lanes of a row with DPP (quad_perm xor 1, xor 2, row_half_mirror)
@@ -304,7 +326,6 @@ __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* 
     if (TPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
     s[k] = v;
   }
-  static_assert(TPR == 2 || TPR == 4 || TPR == 8, "threads per row of the last pose layer");
   if (part == 0 && rid[row] >= 0) {
     float* og = o + (long)rid[row] * 3;
     og[0] = s[0] + b2[0];

@@ -916,6 +916,7 @@ extern int g_chain_split;
 extern int g_chain_ring;
 extern int g_wreg_grid;
 extern int g_auto_small_b;
+extern int g_auto_small_a;
 extern int g_bin_multi;
 extern int g_sampchain_map;
 extern int g_sampchain_mode;
@@ -934,6 +935,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "sampchain_mode") && value >= 0 && value <= 2) { g_sampchain_mode = value; return 0; }
   if (!strcmp(key, "auto_small") && (value == 0 || value == 1)) { g_auto_small = value; return 0; }
   if (!strcmp(key, "auto_small_b") && (value == 0 || value == 1)) { g_auto_small_b = value; return 0; }
+  if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
