@@ -348,8 +348,14 @@ def main():
             # that the roofline figure is the sampling kernel's own duration (as in the rocprofv3 kernel trace of
             # tools/prof.sh), not its duration while sharing the GPU with a GEMM
             overlap, dec.overlap_pyramid = getattr(dec, "overlap_pyramid", False), False
-            # fraction of (image, query) pairs inside their image, per sampling launch (the others are skipped): recorded here,
-            # in the eager pass, for the L1-path figure of the roofline object
+            for _ in range(args.profile_steps):
+                forward()
+            torch.cuda.synchronize()
+            if rank == 0:
+                prof = ops.profile_summary()
+                ops.PROFILE = None
+            # fraction of (image, query) pairs inside their image, per sampling launch (the others are skipped): one more eager
+            # forward, outside the timed pass, for the L1-path figure of the roofline object
             live_fracs = []
             gsamp_orig = ops.msda_gsamp
 
@@ -359,16 +365,12 @@ def main():
                 return gsamp_orig(vp, G_, xw, r, levels, B_, pair_mask=pair_mask, order=order)
             ops.msda_gsamp = gsamp_counting
             try:
-                for _ in range(args.profile_steps):
-                    forward()
+                forward()
                 torch.cuda.synchronize()
             finally:
                 ops.msda_gsamp = gsamp_orig
             dec.overlap_pyramid = overlap
             live_frac = float(torch.stack(live_fracs).mean()) if live_fracs else None
-            if rank == 0:
-                prof = ops.profile_summary()
-                ops.PROFILE = None
 
     if rank != 0:
         if world > 1:
