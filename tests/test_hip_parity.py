@@ -87,7 +87,7 @@ def test_deform_forward_bf16_and_ragged_batch():
                                   c["weight"].repeat(3, 1, 1, 1, 1)[:3].contiguous(), 2)
 
 
-@pytest.mark.parametrize("name", ["small_f32", "edge_f32"])
+@pytest.mark.parametrize("name", ["small_f32", "ragged_f32", "edge_f32"])
 def test_deform_backward_vs_oracle_autograd(name, O):
     """gradients of the HIP backward vs torch autograd through the oracle restatement (fp64)."""
     from mvgformer_amd.functions import DeformFunction
