@@ -7,6 +7,20 @@
 #include <vector>
 #include "chain_dev.h"
 
+// MFMA with the weight fragment read straight from an AGPR quad ("a") or a VGPR quad ("v"); accumulator in VGPRs.
+__device__ __forceinline__ void mfma_wa(f32x16& acc, const f32x4& w, const f32x4& a) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_wv(f32x16& acc, const f32x4& w, const f32x4& a) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_wa0(f32x16& acc, const f32x4& w, const f32x4& a) {     // first k-step: C = 0
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_wv0(f32x16& acc, const f32x4& w, const f32x4& a) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(a));
+}
+
 constexpr int TP = ACT_PITCH;
 constexpr int TILE = 32 * TP;
 
@@ -76,18 +90,19 @@ __global__ __launch_bounds__(256, 1) void systolic4_kernel(const bf16_t* __restr
     char* d3 = Y3 + (t & 1) * TILE;
 #define PHASE(S, SRC, PREV, DST, RELU)                                                                                        \
   {                                                                                                                           \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[S][j][e] = 0.f;          \
-    f32x4 ar[3];                                                                                                              \
+    f32x4 ar[2];                                                                                                              \
     ar[0] = *reinterpret_cast<const f32x4*>(SRC);                                                                             \
     ar[1] = *reinterpret_cast<const f32x4*>(SRC + 32);                                                                        \
-    ar[2] = *reinterpret_cast<const f32x4*>(SRC + 64);                                                                        \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                                          \
-      const f32x4 ac = ar[i % 3];                                                                                             \
-      if (i + 3 < 16) ar[i % 3] = *reinterpret_cast<const f32x4*>(SRC + (i + 3) * 32);                                        \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                           \
-        acc[S][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[S][i][j]),                           \
-                                                            __builtin_bit_cast(bf16x8, ac), acc[S][j], 0, 0, 0);              \
+      const f32x4 ac = ar[i & 1];                                                                                             \
+      if (i + 2 < 16) ar[i & 1] = *reinterpret_cast<const f32x4*>(SRC + (i + 2) * 32);                                        \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                         \
+        /* 256 AGPRs hold stage 1 and all but the last k-step of stage 2 (a full 256 left hipcc two fragments short) */     \
+        if (S == 2 || (S == 1 && i == 15)) { if (i == 0) mfma_wv0(acc[S][j], w[S][i][j], ac); else mfma_wv(acc[S][j], w[S][i][j], ac); } \
+        else { if (i == 0) mfma_wa0(acc[S][j], w[S][i][j], ac); else mfma_wa(acc[S][j], w[S][i][j], ac); }                    \
+      }                                                                                                                       \
       if (MODE != 1 && (i & 1) == 0) {                                                                                        \
+        if (i == 0) asm volatile("s_nop 15");      /* MFMA results of the previous phase -> VALU reads below */                \
         const int j = i >> 3, g = (i & 7) >> 1;                                                                               \
         float v[4];                                                                                                           \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                       \
