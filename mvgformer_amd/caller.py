@@ -51,6 +51,14 @@ def sample_space_reference_points(num_instance, space_size, space_center, batch,
     return joints.expand(batch, -1, -1, -1).reshape(batch, -1, 3).float()
 
 
+def level_tables(src_views):
+    """(L, 2) long spatial shapes and (L,) level starts from the backbone's maps (dq_transformer.py:360-388)."""
+    dev = src_views[0].device
+    shapes = torch.as_tensor([list(s.shape[-2:]) for s in src_views], dtype=torch.long, device=dev)
+    starts = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    return shapes, starts
+
+
 def decoder_outputs_to_dict(hs, inter_references, inter_references_2d, inter_references_2d_projs, outputs_classes,
                             num_instance, num_joints, convert_joint_format_indices=None):
     """final-layer ``out`` dict of DyanmicQueryTransformer.forward (+ per-layer lists)."""
@@ -90,8 +98,9 @@ class DecoderHead(nn.Module):
     fills it from a published checkpoint."""
 
     def __init__(self, decoder, num_instance, num_joints, d_model, space_size, space_center,
-                 convert_joint_format_indices=None):
+                 convert_joint_format_indices=None, t_pose=None):
         super().__init__()
+        self.t_pose = t_pose                       # (J, 3) mm; None = the reference's tpose.pt values (TPOSE_MM)
         self.decoder = decoder
         self.num_instance, self.num_joints = num_instance, num_joints
         self.joint_embedding = nn.Embedding(num_joints, d_model * 2)
@@ -106,11 +115,10 @@ class DecoderHead(nn.Module):
         V = len(meta)
         batch = src_views[0].shape[0] // V
         if spatial_shapes is None:
-            spatial_shapes = torch.tensor([list(s.shape[-2:]) for s in src_views], dtype=torch.long, device=dev)
-            level_start_index = torch.cat([spatial_shapes.new_zeros(1),
-                                           (spatial_shapes[:, 0] * spatial_shapes[:, 1]).cumsum(0)[:-1]])
+            spatial_shapes, level_start_index = level_tables(src_views)
         query_pos, tgt = person_joint_queries(self.joint_embedding.weight, self.instance_embedding.weight, batch)
-        ref = sample_space_reference_points(self.num_instance, self.space_size, self.space_center, batch, dev)
+        ref = sample_space_reference_points(self.num_instance, self.space_size, self.space_center, batch, dev,
+                                            t_pose=self.t_pose)
         hs, refs, refs2d, projs2d, classes = self.decoder(
             tgt.contiguous(), ref, src_views, meta, spatial_shapes, level_start_index, None,
             query_pos=query_pos.contiguous(), threshold=threshold)

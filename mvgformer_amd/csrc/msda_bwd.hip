@@ -20,10 +20,15 @@
 //      gradient over the channels in a fixed order and write them (one writer per sample);
 //   4. the patch is added to a global 64-bit accumulator (integer atomics again: neighbouring tiles share their border
 //      pixels), and a last pass converts it to the fp32 grad_value.
-// Fixed point: contributions are bounded by gmax = max |grad_output| (bilinear and attention weights <= 1); they are scaled
-// by 2^30 / gmax and rounded to an int32 (exact: fp32 carries 24 bits), then summed as 64-bit integers -- no overflow before
-// 2^33 contributions per pixel, each rounded to 2^-31 gmax, 2^7 times finer than the fp32 rounding (relative to a sum of
-// the size of gmax) of the atomics it replaces.  Everything is bit-reproducible run to run.
+// Fixed point: a contribution grad_output * attn_weight * bilinear weight of image n is bounded by
+// bound_n = max |grad_output[n]| * max |attn_weight[n]| (finite entries; the bilinear weights are <= 1).  Contributions are scaled
+// by 2^30 / bound_n (clamped to 2^126 for bounds below 2^-96) and rounded to an int32 (exact: fp32 carries 24 bits), then summed as
+// 64-bit integers -- no overflow before 2^33 contributions per pixel, each rounded to 2^-31 bound_n, 2^7 times finer than the fp32
+// rounding (relative to a sum of the size of bound_n) of the atomics it replaces.  The scale is PER IMAGE and includes the
+// attention weights' own maximum, so a generic caller (un-normalised weights > 1, one image of the batch with outlier
+// gradients, gradients of 1e-35) neither saturates the int32 nor loses the other images' precision.  Dynamic range: what is
+// below 2^-31 of its image's bound rounds to zero (fp32 atomics would keep such a term only while the running sum is as small).
+// Everything is bit-reproducible run to run.
 #include "common.h"
 
 namespace {
@@ -52,19 +57,27 @@ __device__ __forceinline__ bool sample_anchor(const float lx, const float ly, co
   return true;
 }
 
-__global__ __launch_bounds__(256) void bw_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+// blockIdx.y = image, blockIdx.z = tensor (0: grad_output, 1: attn_weight); out[2 * image + tensor] = max |finite entry|
+__global__ __launch_bounds__(256) void bw_absmax_kernel(const float* __restrict__ x0, long n0, const float* __restrict__ x1,
+                                                        long n1, unsigned* __restrict__ out) {
+  const long n = blockIdx.z ? n1 : n0;
+  const float* __restrict__ x = (blockIdx.z ? x1 : x0) + (long)blockIdx.y * n;
+  out += 2 * blockIdx.y + blockIdx.z;
   float m = 0.f;
-  const long n4 = n >> 2;
+  const long lead = min(n, (long)((4 - ((reinterpret_cast<uintptr_t>(x) >> 2) & 3)) & 3));      // floats up to 16-byte alignment
+  const long n4 = (n - lead) >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + lead + 4 * i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float a = fabsf(v[k]);
       m = (a > m && a < INFINITY) ? a : m;      // NaN / Inf do not set the scale
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const float a = fabsf(x[4 * n4 + threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x < 8) {     // the unaligned head and the tail
+    const long i = threadIdx.x < 4 ? (long)threadIdx.x : lead + 4 * n4 + (threadIdx.x - 4);
+    const bool in = threadIdx.x < 4 ? i < lead : i < n;
+    const float a = in ? fabsf(x[i]) : 0.f;
     m = (a > m && a < INFINITY) ? a : m;
   }
 #pragma unroll
@@ -77,6 +90,13 @@ __global__ __launch_bounds__(256) void bw_absmax_kernel(const float* __restrict_
     if (m > 0.f) atomicMax(out, __float_as_uint(m));        // non-negative floats order like their bit patterns
   }
 }
+
+// scale of image n's fixed-point contributions and its inverse (the same two expressions in every kernel that needs them)
+__device__ inline float bw_fix_of(const unsigned* __restrict__ scale_bits, int n) {
+  const float bound = __uint_as_float(scale_bits[2 * n]) * __uint_as_float(scale_bits[2 * n + 1]);
+  return (bound > 0.f && bound < INFINITY) ? fminf(BW_FIX / bound, 0x1p126f) : 0.f;
+}
+__device__ inline double bw_inv_of(float fix) { return fix > 0.f ? 1.0 / (double)fix : 0.0; }
 
 // Binning = a counting sort of the samples by (tile, head) per image, WITHOUT global atomics (2.9 M atomics on ~5 000
 // counters serialise on their hot cache lines: 808 us per pass in the first version).  The samples of an image are cut into
@@ -269,8 +289,7 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
     apatch[px][ch] = 0ull;
   }
   __syncthreads();
-  const float gmax = __uint_as_float(gmax_bits[0]);
-  const float fix = gmax > 0.f ? BW_FIX / gmax : 0.f;
+  const float fix = bw_fix_of(gmax_bits, n);
   const int LP = lv.L * P;
   const float Hf = (float)H, Wf = (float)W;
   // Two phases per pass of 64 samples per wavefront (the first form recomputed every sample's coordinates, corner weights and
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
   }
   __syncthreads();
   unsigned long long* abase = accum + (((long)n * S + lv.start[l]) * M + m) * BW_D;
-  const double inv = (double)gmax / (double)BW_FIX;                      // bw_convert_kernel's arithmetic
+  const double inv = bw_inv_of(fix);                                     // bw_shared_kernel<1>'s arithmetic
   for (int i = tid; i < BW_P * BW_P * BW_D; i += BW_NT) {
     const int px = i >> 5, ch = i & 31;
     const int py = px / BW_P, pxx = px % BW_P;
@@ -394,19 +413,19 @@ __global__ __launch_bounds__(BW_NT) void bw_reduce_kernel(
 }
 
 // The shared pixels (x % T == 0 or y % T == 0) of every map, one workgroup per (map row, 32-pixel segment):
-//   MODE 0: accum <- 0 (before the reduce kernel; also resets the scale word)   MODE 1: grad_value <- accum * gmax / 2^30
+//   MODE 0: accum <- 0 (before the reduce kernel; also resets the image's scale words)   MODE 1: grad_value <- accum / scale
 template <int MODE>
 __global__ __launch_bounds__(256) void bw_shared_kernel(unsigned long long* __restrict__ accum, unsigned* __restrict__ gmax_bits,
                                                         float* __restrict__ gvalue, BwLevels lv, int S, int M, int rows_per_img) {
-  if (MODE == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) gmax_bits[0] = 0u;
   const int n = blockIdx.x / rows_per_img;
+  if (MODE == 0 && blockIdx.x == n * rows_per_img && blockIdx.y == 0 && threadIdx.x < 2) gmax_bits[2 * n + threadIdx.x] = 0u;
   int y = blockIdx.x - n * rows_per_img, l = 0;
   while (l + 1 < lv.L && y >= lv.H[l]) y -= lv.H[l++];
   const int W = lv.W[l], xa = blockIdx.y * 32;
   if (xa >= W) return;
   const int step = (y % BW_T == 0) ? 1 : BW_T, xb = min(W, xa + 32);
   const int per_px = M * BW_D;
-  const double inv = MODE == 1 ? (double)__uint_as_float(gmax_bits[0]) / (double)BW_FIX : 0.0;
+  const double inv = MODE == 1 ? bw_inv_of(bw_fix_of(gmax_bits, n)) : 0.0;
   for (int x = xa; x < xb; x += step) {                       // xa is a multiple of 32, hence of T
     const long base = (((long)n * S + lv.start[l]) + (long)y * W + x) * per_px;
     for (int e = threadIdx.x; e < per_px; e += 256) {
@@ -447,7 +466,7 @@ BwLayout bw_layout(long N, long S, long M, long Lq, long LP, long bpi) {
   w.offset = w.total + up((size_t)N * bpi * 4);
   w.list = w.offset + up((size_t)(N * bpi + 1) * 4);
   w.gmax = w.list + up((size_t)N * Lq * M * LP * 4);
-  w.bytes = w.gmax + 256;
+  w.bytes = w.gmax + up((size_t)N * 8);
   return w;
 }
 
@@ -511,7 +530,8 @@ int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, co
   }
   const dim3 shared_grid((unsigned)(N * rows_per_img), (unsigned)((max_w + 31) / 32));
   hipLaunchKernelGGL((bw_shared_kernel<0>), shared_grid, dim3(256), 0, st, accum, gmax, grad_value, lv, S, M, rows_per_img);
-  hipLaunchKernelGGL(bw_absmax_kernel, dim3(512), dim3(256), 0, st, grad_output, ngo, gmax);
+  hipLaunchKernelGGL(bw_absmax_kernel, dim3(N >= 8 ? 64 : 256, N, 2), dim3(256), 0, st, grad_output, ngo / N, attn_weight,
+                     per_img, gmax);
   const long chunk = (per_img + BW_PARTS - 1) / BW_PARTS;
   const size_t lds = (size_t)bpi * 4;
   hipLaunchKernelGGL((bw_part_kernel<0>), dim3(N * BW_PARTS), dim3(1024), lds, st, sampling_loc, lv, cnt, (const int*)nullptr,

@@ -276,6 +276,9 @@ class DQDecoderLayer(MvPDecoderLayer):
             self.proj_attn.prepare_fast_path(dt)
         else:
             self.proj_attn.weights(dt)
+            if dt == torch.float32 and self.proj_attn.g_sampling_f32 is not False and \
+                    self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192:
+                self.proj_attn._fast_query_weights(dt)      # the fp32 G-sampling branch of native_sample (Woa_perm / boa_perm)
         fuse_a, fuse_b = self._fuses_chains(dt)
         if fuse_a:
             self._chain_a_weights(dt, fused_sampler=self.proj_attn.fuse_sampler_chain)

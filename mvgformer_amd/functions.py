@@ -17,8 +17,11 @@ class DeformFunction(Function):
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                               attention_weights)
         # host copies of the level tables for the deterministic backward (its binning workspace is sized on the host): looked
-        # up here, where the tensors are the caller's own objects and usually carry the copy already -- not a sync per backward
-        ctx.host_levels = ops.host_levels(value_spatial_shapes, value_level_start_index) if value.is_cuda else None
+        # up here, where the tensors are the caller's own objects and usually carry the copy already -- not a sync per
+        # backward.  Only when a gradient will be asked for: under no_grad (and inside a HIP-graph capture, where the D2H
+        # copy of a first look-up is illegal) the forward touches nothing on the host.
+        needs = value.is_cuda and any(ctx.needs_input_grad)
+        ctx.host_levels = ops.host_levels(value_spatial_shapes, value_level_start_index) if needs else None
         return output
 
     @staticmethod

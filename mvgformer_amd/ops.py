@@ -62,13 +62,14 @@ def host_levels(spatial_shapes, level_start_index):
     out = []
     for t in (spatial_shapes, level_start_index):
         cached = getattr(t, "_mvg_host", None) if isinstance(t, torch.Tensor) else None
-        if cached is not None and cached[0] == t._version:
+        # keyed on (storage address, version): in-place writes bump the version, .data / set_() re-pointing changes the address
+        if cached is not None and cached[0] == (t.data_ptr(), t._version):
             out.append(cached[1])
             continue
         arr, _ = _i64_host(t)
         if isinstance(t, torch.Tensor):
             try:
-                t._mvg_host = (t._version, arr)
+                t._mvg_host = ((t.data_ptr(), t._version), arr)
             except Exception:      # pragma: no cover - tensor subclasses without a __dict__
                 pass
         out.append(arr)
@@ -125,7 +126,12 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
 
 def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, host=None):
     """Deformable.deform_backward (lib/models/ops/src/deform.h:53-72).  host: host_levels(...) of the two tables when the
-    caller already has them (DeformFunction keeps the forward's)."""
+    caller already has them (DeformFunction keeps the forward's).
+
+    float32 with D = 32 runs the deterministic form (MVG_BACKWARD=atomic selects the reference's fp32-atomic scheme): grad_value is
+    summed in 64-bit fixed point with one scale PER IMAGE, 2^30 / (max |grad_output[n]| * max |attn_weight[n]|) over the finite
+    entries -- any weight magnitude and any gradient magnitude down to 2^-96 are exact int32 contributions; what is smaller than
+    2^-31 of its image's largest possible contribution rounds to zero.  Non-finite grad_output entries do not enter grad_value."""
     L.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
     if value.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("deform_backward: float32 / float64 only")        # AT_DISPATCH_FLOATING_TYPES, deform_cuda.cu:145

@@ -280,6 +280,13 @@ class ProjAttn(nn.Module):
         return ops.msda_gsamp_chain(vp, G, xw, r, levels, B, inside, order, *chain_weights, o_masked=o_masked)
 
     # ------------------------------------------------------------------------------- forward
+    def _step(self, n):
+        """im2col_step handed to the op for a batch of n images.  The reference calls the op once per view with the per-view
+        batch B (dq_decoder.py:552-593) and its kernel chunks the batch by im2col_step = 64 (deform_cuda.cu:61-86); here all
+        V views go through as ONE batch of V * B images and the kernels never chunk, so the argument is only the op's
+        compatibility check: a step that divides n whenever the reference's per-view call would have passed."""
+        return n if n <= self.im2col_step else math.gcd(n, self.im2col_step)
+
     def _ref_gather(self, flat, loc, shapes, starts):
         """bilinear features of every level at its reference point: flat (n, S, C) channels-last pyramid, loc (n, Lq, L, 2)
         in [0, 1] map coordinates (align_corners=False, zero padding -- grid_sample's and the op's common convention)
@@ -291,7 +298,7 @@ class ProjAttn(nn.Module):
         onehot = torch.eye(nl, dtype=flat.dtype, device=flat.device).view(1, 1, nl, 1, nl, 1)
         w = onehot.expand(n, Lq, nl, M, nl, 1).reshape(n, Lq * nl, M, nl, 1)
         out = DeformFunction.apply(flat.view(n, -1, M, C // M), shapes.contiguous(), starts.contiguous(), locs.contiguous(),
-                                   w.contiguous(), self.im2col_step)
+                                   w.contiguous(), self._step(n))
         return out.view(n, Lq, nl, C)
 
     def forward(self, query, reference_points, src_views, camera_ray_embeds, input_spatial_shapes,
@@ -345,7 +352,7 @@ class ProjAttn(nn.Module):
             + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
         output = DeformFunction.apply(value.contiguous(), input_spatial_shapes.contiguous(),
                                       input_level_start_index.contiguous(), sampling_locations.contiguous(),
-                                      attention_weights.contiguous(), self.im2col_step)
+                                      attention_weights.contiguous(), self._step(n_views))
         return self.output_proj(output)
 
 

@@ -63,3 +63,49 @@ def msda_case(name):
 def threshold_margin(cls_list, thr):
     """smallest |prob - thr| over all layers (parity tests need this >> rounding)."""
     return min(float((c[..., 1] - thr).abs().min()) for c in cls_list)
+
+
+# caller glue (make_golden_caller.py): two loader batches of B=2 through the reference's model forward + validate_3d
+CALLER_CASE = dict(config="mini5", seed=31, layers=2, B=2, batches=2, threshold=0.1, valid_fraction=0.5)
+
+
+def caller_embeddings(NQ, C=256, J=15, seed=77):
+    """joint_embedding.weight (J, 2C), instance_embedding.weight (NQ, 2C) -- seeded stand-ins for the checkpoint's."""
+    rs = np.random.RandomState(seed)
+    je = torch.from_numpy(rs.standard_normal((J, 2 * C)).astype(np.float32))
+    ie = torch.from_numpy(rs.standard_normal((NQ, 2 * C)).astype(np.float32))
+    return je, ie
+
+
+# gradient fixtures (make_golden_grad.py): layer 0 of these LAYER_CASES under autograd; ``indices`` = the matched-query
+# lists a training step passes (dq_decoder.py:900-901), None = the class-head filter (validation inside a training loop)
+GRAD_CASES = {
+    "mini5_all": dict(indices=[[1, 4, 5, 7, 10]]),
+    "mini5_half": dict(indices=None),
+    "mini5_b2": dict(indices=[[0, 3], [1, 2, 5]]),
+}
+GRAD_ROW_STRIDE = 4          # 2-D weight gradients above 16 384 elements are stored as rows [::4]
+
+
+def msda_grad_output(name, shape):
+    seed = {"small_f32": 7, "ragged_f32": 8, "edge_f32": 9}[name]
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(tuple(shape)).astype(np.float32))
+
+
+def layer_loss(outputs, seed=5):
+    """Fixed scalar of a layer's 5-tuple: seeded linear functionals, scaled so every output matters (features O(1),
+    3D in mm, 2D in px, probabilities)."""
+    hs, ref3d, ref2d, proj2d, prob = outputs
+    rs = np.random.RandomState(seed)
+
+    def w(t):
+        return torch.from_numpy(rs.standard_normal(tuple(t.shape))).to(device=t.device, dtype=t.dtype)
+    return ((hs * w(hs)).sum() + 1e-2 * (ref3d * w(ref3d)).sum() + 1e-1 * (ref2d * w(ref2d)).sum()
+            + 10.0 * (prob * w(prob)).sum())
+
+
+def subsample_grad(name, g):
+    """what the fixture keeps of a parameter gradient (numpy / torch, any device)."""
+    if g.ndim == 2 and g.shape[0] * g.shape[1] > 16384:
+        return g[::GRAD_ROW_STRIDE]
+    return g

@@ -1,7 +1,91 @@
-"""CPU tests of the caller-side glue (mvgformer_amd.caller) against the formulas of the reference's
-DyanmicQueryTransformer.forward / validate_3d."""
+"""CPU tests of the caller-side glue (mvgformer_amd.caller), pinned to tests/golden/caller.npz: arrays produced by
+RUNNING the reference's own DyanmicQueryTransformer.forward (lib/models/dq_transformer.py:335-755) and validate_3d
+(lib/core/function.py:329-585) in the build container (tests/golden/make_golden_caller.py)."""
+import os
+
 import numpy as np
+import pytest
 import torch
+
+from tests.golden.cases import CALLER_CASE, caller_embeddings
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "caller.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_inverse_sigmoid_equals_reference_values(gold):
+    """lib/models/util/misc.py:608-612 on edge values (0, eps, 1, out-of-range)."""
+    from mvgformer_amd import caller
+    y = caller.inverse_sigmoid(_t(gold["inverse_sigmoid/x"]))
+    assert torch.equal(y, _t(gold["inverse_sigmoid/y"]))
+
+
+def test_query_embedding_sum_and_split_equal_reference(gold):
+    """dq_transformer.py:394-432: the decoder's tgt / query_pos as the reference model built them."""
+    from mvgformer_amd import caller
+    je, ie = caller_embeddings(12)
+    qpos, tgt = caller.person_joint_queries(je, ie, CALLER_CASE["B"])
+    for b in range(CALLER_CASE["batches"]):
+        for i in range(CALLER_CASE["B"]):
+            assert torch.equal(tgt[i], _t(gold["panoptic/b%d/tgt" % b])[0])
+            assert torch.equal(qpos[i], _t(gold["panoptic/b%d/query_pos" % b])[0])
+
+
+def test_sample_space_reference_points_equal_reference(gold):
+    """dq_transformer.py:298-323 + generate_T_pose :225-236 + norm2absolute, NQ = 12 (4 x 4 grid, first 12 cells)."""
+    from mvgformer_amd import caller
+    from mvgformer_amd.synthetic import CONFIGS
+    c = CONFIGS[CALLER_CASE["config"]]
+    want = _t(gold["panoptic/b0/reference_points"])
+    got = caller.sample_space_reference_points(12, c["space_size"], c["space_center"], CALLER_CASE["B"], "cpu",
+                                               t_pose=_t(gold["tpose"]))
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    # the built-in T-pose constant is the reference's tpose.pt to 1e-12 mm -> same fp32 points up to one ulp
+    dflt = caller.sample_space_reference_points(12, c["space_size"], c["space_center"], CALLER_CASE["B"], "cpu")
+    assert float((dflt - want).abs().max()) <= 1.3e-4
+    assert float(np.abs(gold["tpose"] - caller.TPOSE_MM).max()) < 1e-12
+
+
+@pytest.mark.parametrize("fmt", ["panoptic", "shelf"])
+def test_out_dict_and_packed_predictions_equal_reference(gold, fmt):
+    """dq_transformer.py:569-603 (incl. the Shelf/Campus permutation) and function.py:386-396, fed with the
+    REFERENCE decoder's raw outputs: every array of the reference's out dict and validate_3d's packed preds, exactly."""
+    from mvgformer_amd import caller
+    conv = None if fmt == "panoptic" else [int(i) for i in gold["convert_joint_format_indices"]]
+    thr = float(gold["threshold"])
+    for b in range(CALLER_CASE["batches"]):
+        pre = "panoptic/b%d/" % b
+        hs = torch.zeros(*[int(n) for n in gold[pre + "hs_shape"]][:3], 1)
+        cls = [c for c in _t(gold[pre + "dec_cls"])]
+        out = caller.decoder_outputs_to_dict(hs, _t(gold[pre + "dec_refs"]), _t(gold[pre + "dec_refs2d"]),
+                                             _t(gold[pre + "dec_projs2d"]), cls, 12, 15, conv)
+        pred = caller.pack_predictions(out, thr)
+        want = _t(gold["%s/b%d/pred" % (fmt, b)])
+        assert pred.shape == want.shape and torch.equal(pred, want)
+        assert set(np.unique(want[..., 3].numpy())) == {-1.0, 0.0}          # both outcomes of (score > thr) - 1
+        if b == CALLER_CASE["batches"] - 1:
+            assert torch.equal(out["pred_logits"], _t(gold[fmt + "/out/pred_logits"]))
+            assert torch.equal(out["pred_poses"]["outputs_coord"], _t(gold[fmt + "/out/pred_poses"]))
+            assert torch.equal(out["pred_poses_2d"]["outputs_coord_2d"], _t(gold[fmt + "/out/pred_poses_2d"]))
+            assert torch.equal(out["pred_poses_2d_proj"]["outputs_coord_2d_proj"], _t(gold[fmt + "/out/pred_poses_2d_proj"]))
+
+
+def test_level_tables_built_by_the_head_equal_reference(gold):
+    """dq_transformer.py:360-388: spatial shapes / level starts derived from the backbone's maps."""
+    from mvgformer_amd import caller
+    from mvgformer_amd.synthetic import build_case
+    case = build_case(CALLER_CASE["config"], B=CALLER_CASE["B"], seed=CALLER_CASE["seed"], layers=1)
+    shapes, starts = caller.level_tables(case.src_views)
+    assert torch.equal(shapes, _t(gold["panoptic/b0/spatial_shapes"]))
+    assert torch.equal(starts, _t(gold["panoptic/b0/level_start_index"]))
 
 from mvgformer_amd import caller
 from mvgformer_amd.synthetic import CONFIGS, init_reference_points
