@@ -62,7 +62,7 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
 // [8 sub, 8 sub + 8) of the head): phase A gathers the head's L*P logits + 2*L*P offsets = bilinear(G) + xw into the
 // quad-private LDS row `sc` (3*L*P + 8 floats), pass 1 takes the softmax denominator, pass 2 samples the head plane.
 // No workgroup barrier inside: the quads of a wavefront are independent, inactive quads may skip the call.
-template <int L>
+template <int L, int PIPE = 0>
 __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                            const float* __restrict__ xw, const float* __restrict__ r,
                                            const LevelTable& lv, float* __restrict__ sc, int pair, int m, int sub,
@@ -153,7 +153,7 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 
-  {
+  if constexpr (PIPE == 0) {
     // byte offset of this lane's 32-byte column slice inside vp (uniform base + 32-bit offsets: < 4 GB)
     const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
     const char* vp_bytes = reinterpret_cast<const char*>(vp);
@@ -203,5 +203,67 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+  } else {
+    // PIPE == 1 (round 3): the same arithmetic in the same order, the gathers double-buffered in half batches of 2 samples
+    // (8 loads): while half A is blended, half B's 8 loads -- issued before -- are in flight, and the next half A is issued
+    // before half B is blended.  A wavefront never sits in a blend with nothing outstanding (the single-buffered form
+    // drained all 16 gathers, blended ~150 VALU instructions, then started the next round trip: 7 serialised round trips
+    // per (pair, head)); vmcnt is in order, so "half A arrived" is s_waitcnt vmcnt(8).  Same 64 gather VGPRs.
+    const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
+    const char* vp_bytes = reinterpret_cast<const char*>(vp);
+    constexpr int NIT = LP / NB;
+    unsigned cw_t, cw_b, co_t, co_b, co_x;
+    gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
+    uint4 ra[2][4], rb[2][4];
+#define MVG_ISSUE(BUF, J, SS)                                                                           \
+    {                                                                                                   \
+      const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;        \
+      const unsigned dxs = quad_bcast<SS>(co_x);                                                        \
+      BUF[J][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                       \
+      BUF[J][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs));                               \
+      BUF[J][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                       \
+      BUF[J][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                               \
+    }
+#define MVG_BLEND(BUF, J, SS)                                                                           \
+    {                                                                                                   \
+      const unsigned wts = quad_bcast<SS>(pw_t), wbs = quad_bcast<SS>(pw_b);                            \
+      _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                             \
+        const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wbs : wts);                              \
+        const unsigned l4[4] = {BUF[J][2 * row].x, BUF[J][2 * row].y, BUF[J][2 * row].z, BUF[J][2 * row].w};                 \
+        const unsigned r4[4] = {BUF[J][2 * row + 1].x, BUF[J][2 * row + 1].y, BUF[J][2 * row + 1].z, BUF[J][2 * row + 1].w}; \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+          const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);                         \
+          const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);                         \
+          acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);             \
+          acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false);     \
+        }                                                                                               \
+      }                                                                                                 \
+    }
+    MVG_ISSUE(ra, 0, 0) MVG_ISSUE(ra, 1, 1)
+    unsigned pw_t, pw_b;
+#pragma unroll 1
+    for (int it = 0; it < NIT - 1; ++it) {
+      MVG_ISSUE(rb, 0, 2) MVG_ISSUE(rb, 1, 3)
+      pw_t = cw_t;
+      pw_b = cw_b;
+      __builtin_amdgcn_sched_barrier(0);
+      gsamp_coords<L>(it + 1, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
+      __builtin_amdgcn_sched_barrier(0);
+      MVG_BLEND(ra, 0, 0) MVG_BLEND(ra, 1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      MVG_ISSUE(ra, 0, 0) MVG_ISSUE(ra, 1, 1)          // first half of batch it + 1
+      __builtin_amdgcn_sched_barrier(0);
+      MVG_BLEND(rb, 0, 2) MVG_BLEND(rb, 1, 3)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MVG_ISSUE(rb, 0, 2) MVG_ISSUE(rb, 1, 3)            // last batch: nothing left to issue behind it
+    pw_t = cw_t;
+    pw_b = cw_b;
+    __builtin_amdgcn_sched_barrier(0);
+    MVG_BLEND(ra, 0, 0) MVG_BLEND(ra, 1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    MVG_BLEND(rb, 0, 2) MVG_BLEND(rb, 1, 3)
+#undef MVG_ISSUE
+#undef MVG_BLEND
   }
 }

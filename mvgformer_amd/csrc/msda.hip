@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __
 //     are issued back to back (sched_barrier: hipcc otherwise sinks them to their uses); the blend is 64
 //     v_dot2c_f32_bf16 per batch, fp32 accumulation, no bf16->fp32 unpacking.  (The bilinear x attention
 //     weights are rounded to bf16; products and sums are fp32.)
-template <int L, int NT>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
+template <int L, int NT, int PIPE = 0>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
 __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                 const float* __restrict__ xw, const float* __restrict__ r,
                                                 const LevelTable& lv, bf16_t* __restrict__ samp,
@@ -617,7 +617,7 @@ __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, c
     return;
   }
   float acc[8];
-  gsamp_unit<L>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc);
+  gsamp_unit<L, PIPE>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc);
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
@@ -639,6 +639,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   msda_gsamp_body<L, NT>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
 }
 
+// PIPE = 1: the gathers double-buffered in half batches (gsamp_dev.h) -- same results bit for bit
+template <int L, int NT>
+__global__ __launch_bounds__(NT) void msda_gsamp_pipe_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                                             const float* __restrict__ xw, const float* __restrict__ r,
+                                                             LevelTable lv, bf16_t* __restrict__ samp,
+                                                             const uint8_t* __restrict__ pair_mask, const int* __restrict__ order,
+                                                             int n_pairs, int Lq, int S, int B, int map_ch) {
+  msda_gsamp_body<L, NT, 1>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
+}
+
+static int g_gsamp_pipe = 0;       // tuning knob "gsamp_pipe": 1 = double-buffered gathers in half batches (round 3: 93 VGPRs = 5 waves / SIMD,
+                                   // isolated launch with a warm Infinity Cache 105 -> 100 us, but 1.303 -> 1.314 ms per forward: the extra
+                                   // wavefronts thrash the L1s once the planes come from HBM; pinned to 4 waves / SIMD it equals the default)
 static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
 int g_auto_small = 1;              // tuning knob "auto_small": small launches pick their own workgroup / tile sizes (see mvg_msda_gsamp)
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
@@ -888,6 +901,10 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
       hipLaunchKernelGGL((msda_gsamp_occ5_kernel<LL, 256>), dim3(8 * npb), dim3(256), 0, st, (const bf16_t*)vp,   \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
+    else if (g_gsamp_pipe)                                                                                        \
+      hipLaunchKernelGGL((msda_gsamp_pipe_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,     \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
+                         B, map);                                                                                 \
     else                                                                                                          \
       hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,          \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
@@ -938,6 +955,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
+  if (!strcmp(key, "gsamp_pipe") && (value == 0 || value == 1)) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }

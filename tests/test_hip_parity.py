@@ -492,7 +492,7 @@ def test_decoder_head_vs_reference_model_forward_and_validate_3d(fmt):
         pred = pred.cpu()
         assert pred.shape == want.shape
         assert torch.equal(pred[..., 3], want[..., 3])                                   # (score > thr) - 1: identical
-        assert float((pred[..., 4] - want[..., 4]).abs().max()) < 2e-5                   # score
+        assert float((pred[..., 4] - want[..., 4]).abs().max()) < 1e-4                   # score (free-running, layer 2)
         valid = want[..., 0, 3] == 0
         assert 0 < int(valid.sum()) < valid.numel()
         assert torch.equal(pred[..., :3][~valid], want[..., :3][~valid])                 # zeros for the others
@@ -599,6 +599,28 @@ def test_layer_gradients_vs_reference_autograd(cname, O):
         else:
             w_ref = max(w_ref, r_ref)
     print("%s gradients: vs reference fp32 %.2e (pose head %.2e), vs fp64 oracle %.2e" % (cname, w_ref, w_ref_dlt, w64))
+
+
+def test_projattn_training_path_with_more_than_im2col_step_images():
+    """all V views run as one batch of V * B images; 5 views x B = 16 -> 80 images > im2col_step = 64 with
+    80 % 64 != 0 must work like the reference's per-view calls (batch 16 each) do -- and equal them."""
+    from mvgformer_amd.projattn import ProjAttn
+    torch.manual_seed(3)
+    pa = ProjAttn(256, 1, 8, 8, "ablation_not_use_rayconv").to(DEV)
+    pa._reset_parameters()
+    V, B, Lq = 5, 16, 7
+    shapes = torch.tensor([[6, 10], [3, 5]], dtype=torch.long, device=DEV)
+    starts = torch.tensor([0, 60], dtype=torch.long, device=DEV)
+    src = [torch.randn(V * B, 256, 6, 10, device=DEV), torch.randn(V * B, 256, 3, 5, device=DEV)]
+    q = torch.randn(V * B, Lq, 256, device=DEV, requires_grad=True)
+    ref = torch.rand(V * B, Lq, 2, 2, device=DEV)
+    out = pa(q, ref, src, None, shapes, starts)                      # one batch of 80 images
+    out.square().sum().backward()
+    assert out.shape == (V * B, Lq, 256) and torch.isfinite(q.grad).all()
+    q2 = q.detach().clone().requires_grad_(True)                     # the reference's call pattern: per view, batch B
+    per_view = torch.cat([pa(q2[v * B:(v + 1) * B], ref[v * B:(v + 1) * B], [s[v * B:(v + 1) * B] for s in src], None,
+                             shapes, starts) for v in range(V)], 0)
+    assert float((out - per_view).abs().max()) < 1e-5
 
 
 def test_training_path_reference_point_gather_through_the_sampling_op():
@@ -1379,12 +1401,12 @@ def test_differentiable_dlt_matches_svd_autograd():
     assert torch.allclose(w.sort(-1).values, torch.linalg.eigvalsh(S.cpu()).to(DEV), rtol=1e-12, atol=1e-12 * float(S.abs().max()))
 
 
-_KNOBS = [("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
+_KNOBS = [("gsamp_pipe", 1, True), ("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
           ("gsamp_map", 8, True), ("bin_multi", 0, True), ("auto_small", 0, True), ("wreg_grid", 256, True),
           ("wreg_grid", 64, True), ("auto_small_b", 0, False), ("auto_small_a", 0, True), ("chain_rm", 64, True), ("chain_rm", 256, False),
           ("chain_a_waves", 8, False), ("chain_waves", 4, False), ("chain_split", 0, False), ("chain_ring", 8, False),
           ("chain_ring", 16, False), ("sampchain_map", 1, True), ("sampchain_map", 16, True)]
-_KNOB_DEFAULTS = dict(gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
+_KNOB_DEFAULTS = dict(gsamp_pipe=0, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
                       chain_a_waves=4, chain_waves=8, chain_split=1, chain_ring=4, sampchain_map=4)
 # knobs of the fused sampler + chain A kernel (csrc/sampchain.hip, MVG_FUSE_SAMPLER=1); the default is the two-kernel form
 _FUSED_KERNEL_KNOBS = ("sampchain_map",)

@@ -1,0 +1,102 @@
+"""A/B of msda_gsamp variants on the cfg-2 layer-0 inputs (in-image mask + Morton order, as in the forward): isolated launches,
+HIP-event timed, outputs compared bit for bit.  python tools/ab_gsamp.py key=value[,key=value...] ..."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from mvgformer_amd import _lib, ops  # noqa: E402
+from mvgformer_amd.decoder import DecoderContext  # noqa: E402
+from mvgformer_amd.factory import build_decoder_for_case, case_to_device  # noqa: E402
+from mvgformer_amd.synthetic import build_case  # noqa: E402
+
+cfg = os.environ.get("AB_CONFIG", "cfg2")
+case = build_case(cfg, seed=0, layers=1)
+dec = build_decoder_for_case(case, "cuda", torch.bfloat16)
+g = case_to_device(case, "cuda")
+pa = dec.layers[0].proj_attn
+lib = _lib.load()
+variants = [dict(kv.split("=") for kv in a.split(",")) if a != "default" else {} for a in (sys.argv[1:] or ["default"])]
+with torch.no_grad():
+    ctx = DecoderContext.build(g.src_views, g.spatial_shapes, g.level_start_index, g.meta, case.img_size, torch.bfloat16, 1)
+    r, ref_lvl, inside = ops.project(g.reference_points, ctx.cams, ctx.levels, ctx.V, 1)
+    x = (g.tgt + g.query_pos).contiguous()
+    vp = pa.project_values(ctx.feat)
+    Wq, bq = pa._fast_query_weights(torch.bfloat16)
+    xw = ops.linear(x.reshape(-1, 256), Wq, bq, out_dtype=torch.float32)
+    G = ops.feat_linear_ws(ctx.feat, pa.query_term_weights(torch.bfloat16)[0], 192)
+    msk = inside.view(-1)
+    order = ops.bin_pairs(ref_lvl, msk, ctx.levels)
+    print("%s: %d pairs, in-image %.3f" % (cfg, msk.numel(), float(msk.float().mean())))
+    base = None
+    for rep in range(2):
+        for v in variants:
+            for k, val in v.items():
+                assert lib.mvg_set_tuning(k.encode(), int(val)) == 0, k
+            for _ in range(5):
+                out = ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1, pair_mask=msk, order=order)
+            torch.cuda.synchronize()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(50):
+                out = ops.msda_gsamp(vp, G, xw, ref_lvl, ctx.levels, 1, pair_mask=msk, order=order)
+            e_.record()
+            torch.cuda.synchronize()
+            if base is None:
+                base = out.clone()
+            print("%-40s %8.1f us   identical to first: %s" % (v or "default", s_.elapsed_time(e_) / 50 * 1e3, bool(torch.equal(out, base))))
+
+# ---- cache residency probe (round 3): the same launch with (a) one (vh, G) set re-used (warm Infinity Cache: 180 MB < 256 MB),
+# (b) four sets in rotation like the four layers of a forward (720 MB), (c) each launch preceded by the two pyramid GEMMs that
+# produce its set (value planes + G written just before they are sampled)
+if os.environ.get("AB_RESIDENCY", "1") != "0":
+    with torch.no_grad():
+        sets = [(vp.clone(), G.clone()) for _ in range(4)]
+        Woa_f = pa.query_term_weights(torch.bfloat16)[0]
+
+        def timed(tag, fn, n=40):
+            for _ in range(4):
+                fn(0)
+            torch.cuda.synchronize()
+            evs = []
+            for i in range(n):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                pre = fn(i, prepare=True)
+                a.record()
+                fn(i)
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            ts = sorted(x.elapsed_time(y) * 1e3 for x, y in evs)
+            print("%-62s median %7.1f us  (min %.1f)" % (tag, ts[len(ts) // 2], ts[0]))
+
+        def same(i, prepare=False):
+            if not prepare:
+                ops.msda_gsamp(sets[0][0], sets[0][1], xw, ref_lvl, ctx.levels, 1, pair_mask=msk, order=order)
+
+        def rot(i, prepare=False):
+            if not prepare:
+                ops.msda_gsamp(sets[i % 4][0], sets[i % 4][1], xw, ref_lvl, ctx.levels, 1, pair_mask=msk, order=order)
+
+        fresh = {}
+
+        def jit(i, prepare=False):
+            if prepare:      # the producing GEMMs, outside the timed bracket, right before the sampler
+                fresh["vp"] = pa.project_values(ctx.feat)
+                fresh["G"] = ops.feat_linear_ws(ctx.feat, Woa_f, 192)
+            else:
+                ops.msda_gsamp(fresh.get("vp", vp), fresh.get("G", G), xw, ref_lvl, ctx.levels, 1, pair_mask=msk, order=order)
+
+        big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+
+        def cold(i, prepare=False):
+            if prepare:
+                big.fill_(i & 255)          # 1 GB written: flushes L2 and the Infinity Cache
+            else:
+                ops.msda_gsamp(sets[0][0], sets[0][1], xw, ref_lvl, ctx.levels, 1, pair_mask=msk, order=order)
+        timed("sampler, one (vh, G) set re-used (warm)", same)
+        timed("sampler, four sets in rotation (a forward's footprint)", rot)
+        timed("sampler right after the GEMMs that wrote its set", jit)
+        timed("sampler after 1 GB of unrelated writes (cold)", cold)
