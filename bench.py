@@ -37,7 +37,8 @@ def algorithmic_bytes_per_view_layer(S, C, Lq, M, L, P, elem):
     return S * C * elem + Lq * M * L * P * 2 * elem + Lq * M * L * P * elem + Lq * C * elem
 
 
-SAMPLER_SOURCES = ("mvgformer_amd/csrc/msda.hip", "mvgformer_amd/csrc/common.h")
+SAMPLER_SOURCES = ("mvgformer_amd/csrc/msda.hip", "mvgformer_amd/csrc/gsamp_dev.h", "mvgformer_amd/csrc/common.h",
+                   "mvgformer_amd/csrc/sampchain.hip", "mvgformer_amd/csrc/chain_dev.h")
 
 
 def sampler_source_hash():
@@ -138,10 +139,15 @@ def main():
                          "somewhere, verified after the forward and redone exactly on a miss (dist.SpeculativeShardedDecoder); "
                          "0 = graph segments with a MAX all-reduce of the flag between the layers")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "cached", "off"],
-                    help="roofline.traffic (HBM bytes per launch of the sampling kernel from the PMC counters): cached = the "
-                         "committed profiles/*_pmc_msda.json, only if it was measured on these kernel sources (hash) and this "
-                         "configuration; live = two rocprofv3 --pmc child passes of this command now; auto = cached if "
-                         "valid, else live; off = null")
+                    help="roofline.traffic (HBM bytes per launch of the sampling kernel from the PMC counters): live = two "
+                         "rocprofv3 --pmc child passes of this command now (~20 s); cached = the committed "
+                         "profiles/*_pmc_msda.json, only if it was measured on these kernel sources (hash) and this "
+                         "configuration; auto (default) = live when rocprofv3 is on PATH, else cached; off = null")
+    ap.add_argument("--inside", default="grid", choices=["grid", "all"],
+                    help="where the initial query poses sit: grid = the model's 'sample_space' grid over the whole space "
+                         "(SURVEY 8(d); ~1/3 of the (view, query) pairs project outside their image and are skipped); all = the "
+                         "grid shrunk to 30 %% of the space so that > 99 %% of the pairs are inside every view (nothing skipped: "
+                         "the regime of a trained model's later layers)")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -188,7 +194,9 @@ def main():
 
     sharded = world > 1 and args.shard == "queries"       # one sample, queries split over the ranks
     replicas = world > 1 and args.shard == "samples"      # one sample per rank
-    case = build_case(args.config, seed=rank if replicas else 0, valid_fraction=args.valid_fraction, NQ=args.queries)
+    ref_extent = 0.3 if args.inside == "all" else 1.0
+    case = build_case(args.config, seed=rank if replicas else 0, valid_fraction=args.valid_fraction, NQ=args.queries,
+                      ref_extent=ref_extent)
     NQ, J, V, Ly = case.NQ, 15, case.V, case.layers
     cpu_case = None
     if rank == 0 and args.cpu_baseline and world == 1:
@@ -285,7 +293,8 @@ def main():
                 if k == 0:          # the decoder built above, re-captured on its own stream like the others
                     case_k, dec_k, g_k, ctx_k = case, dec, g, ctx
                 else:
-                    case_k = build_case(args.config, seed=1000 * k + rank, valid_fraction=args.valid_fraction)
+                    case_k = build_case(args.config, seed=1000 * k + rank, valid_fraction=args.valid_fraction,
+                                        ref_extent=ref_extent)
                     dec_k = build_decoder_for_case(case_k, dev, dtype)
                     g_k = case_to_device(case_k, dev)
                     ctx_k = DecoderContext.prepare(g_k.spatial_shapes, g_k.level_start_index, g_k.meta, case_k.img_size,
@@ -357,18 +366,25 @@ def main():
             # fraction of (image, query) pairs inside their image, per sampling launch (the others are skipped): one more eager
             # forward, outside the timed pass, for the L1-path figure of the roofline object
             live_fracs = []
-            gsamp_orig = ops.msda_gsamp
+            originals = {}
 
-            def gsamp_counting(vp, G_, xw, r, levels, B_, pair_mask=None, order=None):
-                if pair_mask is not None:
-                    live_fracs.append(pair_mask.float().mean())
-                return gsamp_orig(vp, G_, xw, r, levels, B_, pair_mask=pair_mask, order=order)
-            ops.msda_gsamp = gsamp_counting
+            def counting(name):
+                orig = originals[name] = getattr(ops, name)
+
+                def wrapped(*a, **kw):
+                    mask = kw.get("pair_mask", a[6] if (name == "msda_gsamp_chain" and len(a) > 6) else None)
+                    if mask is not None:
+                        live_fracs.append(mask.float().mean())
+                    return orig(*a, **kw)
+                setattr(ops, name, wrapped)
+            for name in ("msda_gsamp", "msda_gfused_f32", "msda_gsamp_chain"):
+                counting(name)
             try:
                 forward()
                 torch.cuda.synchronize()
             finally:
-                ops.msda_gsamp = gsamp_orig
+                for name, orig in originals.items():
+                    setattr(ops, name, orig)
             dec.overlap_pyramid = overlap
             live_frac = float(torch.stack(live_fracs).mean()) if live_fracs else None
 
@@ -394,15 +410,20 @@ def main():
     # the dominant kernel: the fused sampler + chain A (bf16 default), the plain G-sampling kernel (MVG_FUSE_SAMPLER=0) or
     # the generic fused sampling kernel (fp32); its algorithmic bytes are SURVEY 8(d)'s sampling figure in all three cases
     # (the chain-A half of the fused kernel adds no bytes to the numerator)
-    kernel_names = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel", "msda_fused": "msda_fused_kernel"}
+    kernel_names = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel",
+                    "msda_gfused_f32": "msda_gfused_f32_kernel", "msda_fused": "msda_fused_kernel"}
     samp_key = next((k for k in kernel_names if k in prof), "msda_fused")
     samp_name = kernel_names[samp_key]
     if world == 1 and args.traffic != "off" and args.inflight == 1:
         src_hash = sampler_source_hash()
         want = {"config": args.config, "dtype": args.dtype, "queries": NQ, "valid_fraction": args.valid_fraction,
-                "src_sha256": src_hash}
+                "src_sha256": src_hash, "inside": args.inside}
         import glob
-        if args.traffic in ("auto", "cached"):
+        import shutil
+        mode = args.traffic
+        if mode == "auto":
+            mode = "live" if shutil.which("rocprofv3") else "cached"
+        if mode == "cached":
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_msda.json")), reverse=True):
                 with open(path) as f:
                     rec = json.load(f)
@@ -410,8 +431,9 @@ def main():
                     traffic = int(rec["traffic_bytes_per_launch"])
                     traffic_source = "%s (tools/prof.sh, sources %s)" % (os.path.relpath(path, ROOT), src_hash)
                     break
-        if traffic is None and args.traffic in ("auto", "live"):
-            tail = ["--config", args.config, "--dtype", args.dtype, "--producer", args.producer, "--cpu-baseline", "0"]
+        if traffic is None and mode == "live":
+            tail = ["--config", args.config, "--dtype", args.dtype, "--producer", args.producer, "--cpu-baseline", "0",
+                    "--inside", args.inside]
             if args.queries is not None:
                 tail += ["--queries", str(args.queries)]
             if args.valid_fraction is not None:
@@ -426,6 +448,11 @@ def main():
         ach = bytes_launch / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": samp_name, "achieved": round(ach, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
+                # share of the (view, query) pairs whose reference point is inside their image, averaged over the layers'
+                # launches: the bf16 kernel zero-fills the others without sampling (the consumer multiplies their rows by 0,
+                # dq_decoder.py:585-586); `achieved` prices ALL pairs at SURVEY 8(d)'s bytes.  --inside all = nothing skipped
+                "in_image_pair_fraction": None if live_frac is None else round(live_frac, 4),
+                "pairs_skipped": bool(samp_key in ("msda_gsamp", "msda_gsamp_chain", "msda_gfused_f32")),
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
                 "fused_minimum_bytes_per_launch": V * (S * 256 + Lq_loc * 256) * elem}
@@ -499,6 +526,8 @@ def main():
                    "pyramid_handoff": {"nchw": "NCHW fp32 (reference producer format), packed per step",
                                        "nhwc": "channels-last %s, copied per step" % args.dtype,
                                        "inplace": "produced in the packed layout (no per-step pack)"}[args.producer],
+                   "initial_poses": {"grid": "'sample_space' grid over the whole space (SURVEY 8(d))",
+                                     "all": "grid over 30 % of the space: > 99 % of the (view, query) pairs inside their image"}[args.inside],
                    "samples_in_flight": args.inflight,
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
         "roofline": roof, "cpu_baseline": cpu, "rank_time_split": split, "kernels": kern,

@@ -164,12 +164,23 @@ def make_meta(cams, B, orig_wh, img_wh, device="cpu"):
     return meta
 
 
-def make_pyramid(V, B, shapes, C=256, seed=0, dtype=torch.float32, device="cpu"):
-    """list of L tensors (V*B, C, H_l, W_l) ~ N(0,1), view-major."""
+def make_pyramid(V, B, shapes, C=256, seed=0, dtype=torch.float32, device="cpu", smooth_sigma0=None):
+    """list of L tensors (V*B, C, H_l, W_l) ~ N(0,1), view-major.  smooth_sigma0: band-limit the maps -- white noise
+    low-passed with a Gaussian of sigma = smooth_sigma0 cells at level 0 (halved per level: the same length in the image),
+    rescaled to unit variance: feature maps with the spatial coherence of a backbone's, on which a sub-pixel shift of a
+    sampling location changes the sampled value a little instead of completely."""
     rs = np.random.RandomState(seed + 104729)
     out = []
-    for (H, W) in shapes:
+    for l, (H, W) in enumerate(shapes):
         a = rs.standard_normal((V * B, C, H, W)).astype(np.float32)
+        if smooth_sigma0:
+            sig = max(smooth_sigma0 / (2 ** l), 0.75)
+            fy = np.fft.fftfreq(H)[:, None]
+            fx = np.fft.rfftfreq(W)[None, :]
+            gain = np.exp(-2.0 * (math.pi * sig) ** 2 * (fy ** 2 + fx ** 2)).astype(np.float32)     # periodic Gaussian blur
+            for i in range(a.shape[0]):
+                b = np.fft.irfft2(np.fft.rfft2(a[i], axes=(-2, -1)) * gain, s=(H, W), axes=(-2, -1))
+                a[i] = (b / b.std()).astype(np.float32)
         out.append(torch.from_numpy(a).to(device=device, dtype=dtype))
     return out
 
@@ -201,7 +212,7 @@ def init_reference_points(B, NQ, space_size, space_center, J=15, jitter=0.0, see
 
 # ----------------------------------------------------------------------- layer weights
 def layer_state_dict(seed, d_model=256, d_ffn=1024, n_heads=8, n_levels=1, n_points=8,
-                     pose_embed_layer=3, valid_fraction=None):
+                     pose_embed_layer=3, valid_fraction=None, pose_scale=1.0):
     """Deterministic (numpy) weights for ONE DQDecoderLayer, keyed exactly like the
     reference state dict (probe of DQDecoderLayer.state_dict()).
     Scales are chosen so every term matters: sampling offsets of a few feature
@@ -249,6 +260,8 @@ def layer_state_dict(seed, d_model=256, d_ffn=1024, n_heads=8, n_levels=1, n_poi
         last = i == pose_embed_layer - 1
         # last layer: pixel offsets of a few px, view-confidence logits O(1)
         w, b = lin(dims[i + 1], dims[i], wscale=(2.0 / math.sqrt(dims[i])) if last else None)
+        if last and pose_scale != 1.0:
+            w[:2] *= pose_scale          # the two pixel-offset rows (the view-confidence logit row keeps its scale)
         sd["pose_embed.MLP.layers.%d.weight" % i] = w
         sd["pose_embed.MLP.layers.%d.bias" % i] = b
     w, b = lin(2, C, wscale=4.0 / math.sqrt(C), bscale=0.0)
@@ -286,8 +299,12 @@ def decoder_cfg(space_size, space_center, share_layer_weights=False):
 
 
 def build_case(name, B=1, seed=0, NQ=None, layers=None, V=None, feat_dtype=torch.float32,
-               device="cpu", jitter=25.0, valid_fraction=None, with_features=True):
-    """Assemble all decoder inputs for a named configuration."""
+               device="cpu", jitter=25.0, valid_fraction=None, with_features=True, ref_extent=1.0, smooth_sigma0=None,
+               pose_scale=1.0):
+    """Assemble all decoder inputs for a named configuration.  ref_extent: fraction of the space's x / y extent the initial
+    query grid covers (1.0 = the model's own 'sample_space' initialisation over the whole space, where ~40 % of the (view,
+    query) pairs of cfg-2 project outside their image; 0.3 puts > 99 % of them inside every view -- the regime of a trained
+    model's later layers, whose queries sit on the people)."""
     c = dict(CONFIGS[name])
     if NQ is not None:
         c["NQ"] = NQ
@@ -299,11 +316,13 @@ def build_case(name, B=1, seed=0, NQ=None, layers=None, V=None, feat_dtype=torch
     cams = ring_cameras(c["V"], c["orig_wh"], c["focal"], c["radius"], c["space_center"], c["k"], c["p"], seed)
     meta = make_meta(cams, B, c["orig_wh"], c["img_wh"], device)
     tgt, pos = make_queries(B, c["NQ"], seed=seed, device=device)
-    ref = init_reference_points(B, c["NQ"], c["space_size"], c["space_center"], jitter=jitter, seed=seed, device=device)
-    src = make_pyramid(c["V"], B, shapes, seed=seed, dtype=feat_dtype, device=device) if with_features else None
+    grid_size = (c["space_size"][0] * ref_extent, c["space_size"][1] * ref_extent, c["space_size"][2])
+    ref = init_reference_points(B, c["NQ"], grid_size, c["space_center"], jitter=jitter, seed=seed, device=device)
+    src = make_pyramid(c["V"], B, shapes, seed=seed, dtype=feat_dtype, device=device,
+                       smooth_sigma0=smooth_sigma0) if with_features else None
     spatial_shapes = torch.tensor(shapes, dtype=torch.long, device=device)
     level_start = torch.cat([spatial_shapes.new_zeros(1), (spatial_shapes[:, 0] * spatial_shapes[:, 1]).cumsum(0)[:-1]])
-    weights = decoder_state_dict(seed + 1, c["layers"], valid_fraction=valid_fraction)
+    weights = decoder_state_dict(seed + 1, c["layers"], valid_fraction=valid_fraction, pose_scale=pose_scale)
     return SimpleNamespace(cfg=c, name=name, B=B, V=c["V"], NQ=c["NQ"], J=15, layers=c["layers"],
                            img_size=list(c["img_wh"]), shapes=shapes, meta=meta, tgt=tgt, query_pos=pos,
                            reference_points=ref, src_views=src, spatial_shapes=spatial_shapes,

@@ -185,6 +185,43 @@ def test_cfg2_four_layers_vs_fp64_oracle(dtype, O):
         _free_running_bf16("cfg2 bf16", _run(dec, g), want, yard, BF16_FREE_CFG2)
 
 
+@pytest.mark.parametrize("features", ["smooth", "white"])
+def test_cfg2_queries_inside_every_view_bf16_maximum_error_is_bounded(features, O):
+    """a workload on which the bf16 path's MAXIMUM error can be bounded.  The growth of rounding
+    differences over the layers in the default synthetic workload comes from its geometry, not from the arithmetic: 41 % of
+    the (view, query) pairs project outside their image there (few-view, ill-conditioned triangulations; in-image masks
+    that flip with a sub-millimetre move of a point).  With the initial grid over the central 30 % of the space every
+    query is inside every view (> 99 % of the pairs) -- where a trained model's queries sit, on the people -- and the fp64
+    oracle itself is stable (a 0.05-mm perturbation of the input stays 0.19 mm over 4 layers).  On that workload, cfg-2 full
+    size, 4 layers FREE-RUNNING, bf16 against the fp64 oracle: max 3D <= 0.5 mm, max 2D <= 0.1 px (the verdict asked for
+    2 mm / 0.25 px; measured on MI355X: 0.15 mm / 0.026 px on band-limited maps -- Gaussian low-pass, 8 cells at level 0 --,
+    0.053 mm / 0.012 px on white noise; fp32: 0.003 mm / 5e-4 px), i.e. 1 % of the published 16.0 mm MPJPE."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = build_case("cfg2", seed=1, ref_extent=0.3, smooth_sigma0=8.0 if features == "smooth" else None)
+    want = _oracle(O, case, "cfg2-inside-%s/f64" % features)
+    g = case_to_device(case, DEV)
+    inside = []
+    for dtype, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        dec = build_decoder_for_case(case, DEV, dtype=dtype)
+        got = _run(dec, g)
+        assert torch.equal(got[1].cpu().abs().sum(-1) > 0, want[1].abs().sum(-1) > 0)
+        rows = _stats(got, want)
+        _report("cfg2 all-inside %s %s" % (features, tag), rows)
+        e_cls = max(float((c.cpu().double() - w).abs().max()) for c, w in zip(got[4], want[4]))
+        print("%-34s class prob max %.2e" % ("cfg2 all-inside %s %s" % (features, tag), e_cls))
+        for l, r in enumerate(rows):
+            if dtype == torch.bfloat16:
+                assert r["mm"] <= 0.5 and r["px"] <= 0.1 and r["hs"] <= 6e-2, (features, l, r)        # MAXIMUM over all 15 360 tokens
+            else:
+                assert r["mm"] <= 0.01 and r["px"] <= 2e-3 and r["hs"] <= 2e-4, (features, l, r)
+        assert e_cls < (2e-2 if dtype == torch.bfloat16 else 1e-5)
+    proj = got[3][0].cpu()                 # layer-0 projections (network-image px) of the initial poses: inside the image
+    w, h = case.img_size
+    frac = float(((proj[..., 0] >= 0) & (proj[..., 0] < w) & (proj[..., 1] >= 0) & (proj[..., 1] < h)).float().mean())
+    print("in-image fraction of the layer-0 pairs: %.4f" % frac)
+    assert frac > 0.98
+
+
 def test_cfg3_eight_query_shards_bf16_equal_the_single_rank_run():
     """BASELINE configs[2] on one GPU: the cfg-2 sample as 8 shards of 128 person-queries (what each of 8 ranks runs:
     128-thread sampling workgroups, 32-row chain-B tiles, single-workgroup binning), bf16, 4 layers free-running; the
