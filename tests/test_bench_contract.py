@@ -66,3 +66,27 @@ def test_plain_multi_gpu_command_launches_its_own_ranks():
     assert "rank 0/2: process group up (gloo)" in out and "rank 1/2: process group up (gloo)" in out, out[-3000:]
     assert "no CPU path" in out
     assert "launch with torch.distributed.run" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("speculative", [1, 0])
+def test_two_rank_query_sharded_bench_runs_end_to_end_on_one_gpu(speculative):
+    """`python bench.py --gpus 2` end to end on the one-GPU box: the script starts its own two ranks (torch.distributed.run,
+    127.0.0.1), both on cuda:0 with gloo carrying the collectives (RCCL needs one device per rank), query shards of 512,
+    the forward as one HIP graph with the speculative any-valid flag (or graph segments + per-layer all-reduce), the one
+    all-gather of the pose set per step, barrier + max-over-ranks timing, ONE JSON line from rank 0."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MVG_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--speculative", str(speculative), "--traffic", "off", "--profile-steps", "1"],
+                       cwd=ROOT, env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4
+    assert "queries sharded x2" in d["config"]["parallelism"] and d["config"]["hip_graph"] is True
+    assert ("speculative" in d["config"]["parallelism"]) == bool(speculative)
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]       # one sample per step, whole job
+    assert "process group up (gloo)" in p.stderr
