@@ -58,6 +58,68 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
   dx = (unsigned)(wr_c - wl_c) * 64u;
 }
 
+// ---- LDS window of the coarsest level (round 3, msda_gsamp_win_kernel).  The 64 pairs of a sampling workgroup are neighbours in
+// the image (Morton order), so the samples they take from the coarsest level fall into a small rectangle of the (image, head)
+// plane: the workgroup stages that rectangle (WIN x WIN pixels x 64 B, 80-byte pitch) in LDS once and serves every sample
+// whose 2 x 2 footprint lies inside it with ds_read_b128 instead of a gather through the L1; all others take the global
+// path as before.  Same bytes either way: results are bit-identical to the plain kernel.
+typedef __attribute__((address_space(3))) const unsigned char* lds_bytes_t;
+constexpr int GSAMP_WIN = 16, GSAMP_WIN_PITCH = 80;
+struct GsampWin {
+  lds_bytes_t base;      // LDS copy of the window, pixel (y, x) at ((y - y0) * wx + (x - x0)) * GSAMP_WIN_PITCH
+  int x0, y0, wx, wy;    // window origin / extent in pixels of level L - 1
+  int n;                 // image the window was staged from
+};
+
+typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_load16(lds_bytes_t p) {
+  const gs_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const gs_u32x4*>(p);   // ds_read_b128
+  return uint4{v.x, v.y, v.z, v.w};
+}
+
+// gsamp_coords for a kernel with a staged window: for samples of the coarsest level whose four (clamped) corner pixels are
+// inside the window -- and whose pair belongs to the staged image -- ot / ob / dx are byte offsets into the LDS copy and fl = 1
+template <int L>
+__device__ __forceinline__ void gsamp_coords_win(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
+                                                 int sub, const GsampWin& win, bool win_ok, unsigned& wt, unsigned& wb,
+                                                 unsigned& ot, unsigned& ob, unsigned& dx, unsigned& fl) {
+  constexpr int P = 8, NB = 4, LP = L * P;
+  const int l = (it * NB) / P;
+  const int H = lv.H[l], W = lv.W[l];
+  const float Wf = (float)W, Hf = (float)H;
+  const float2 rr = *reinterpret_cast<const float2*>(sc + 3 * LP + 2 * l);
+  const float rx = rr.x, ry = rr.y;
+  const float lgs = sc[it * NB + sub];
+  const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
+  const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];
+  const float h_raw = ly * Hf - 0.5f, w_raw = lx * Wf - 0.5f;
+  const bool inside = (h_raw > -1.f) & (w_raw > -1.f) & (h_raw < Hf) & (w_raw < Wf);
+  const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
+  const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+  const int h_low = (int)hl_f, w_low = (int)wl_f;
+  const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+  const float e = __expf(lgs - mx);
+  const float a = inside ? e : 0.f;
+  const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+  const float t0 = hh * hw * a, t1 = hh * lw * a, t2 = lh * hw * a, t3 = lh * lw * a;
+  const float c0 = (hl_ok & wl_ok) ? t0 : 0.f, c1 = (hl_ok & wh_ok) ? t1 : 0.f;
+  const float c2 = (hh_ok & wl_ok) ? t2 : 0.f, c3 = (hh_ok & wh_ok) ? t3 : 0.f;
+  wt = pack_bf16x2(c0, c1);
+  wb = pack_bf16x2(c2, c3);
+  const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+  const int wl_c = min(max(w_low, 0), W - 1), wr_c = min(max(w_low + 1, 0), W - 1);
+  const bool in_win = (l == L - 1) & win_ok & (wl_c >= win.x0) & (wr_c < win.x0 + win.wx) & (hl_c >= win.y0) &
+                      (hh_c < win.y0 + win.wy);
+  const unsigned base = (unsigned)lv.start[l];
+  const unsigned g_t = (base + (unsigned)(hl_c * W + wl_c)) * 64u, g_b = (base + (unsigned)(hh_c * W + wl_c)) * 64u;
+  const unsigned w_t = (unsigned)((hl_c - win.y0) * win.wx + (wl_c - win.x0)) * (unsigned)GSAMP_WIN_PITCH;
+  const unsigned w_b = (unsigned)((hh_c - win.y0) * win.wx + (wl_c - win.x0)) * (unsigned)GSAMP_WIN_PITCH;
+  ot = in_win ? w_t : g_t;
+  ob = in_win ? w_b : g_b;
+  dx = (unsigned)(wr_c - wl_c) * (in_win ? (unsigned)GSAMP_WIN_PITCH : 64u);
+  fl = in_win ? 1u : 0u;
+}
+
 // One (image-query pair, head) of the G-sampling kernel, computed by the 4 lanes of a quad (lane `sub` owns channels
 // [8 sub, 8 sub + 8) of the head): phase A gathers the head's L*P logits + 2*L*P offsets = bilinear(G) + xw into the
 // quad-private LDS row `sc` (3*L*P + 8 floats), pass 1 takes the softmax denominator, pass 2 samples the head plane.
@@ -66,7 +128,7 @@ template <int L, int PIPE = 0>
 __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                            const float* __restrict__ xw, const float* __restrict__ r,
                                            const LevelTable& lv, float* __restrict__ sc, int pair, int m, int sub,
-                                           int Lq, int S, int B, float (&acc)[8]) {
+                                           int Lq, int S, int B, float (&acc)[8], const GsampWin* win = nullptr) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4;
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
 
@@ -203,6 +265,84 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+  } else if constexpr (PIPE == 2) {
+    // PIPE == 2: the plain loop for the levels above the coarsest, then the coarsest level with the LDS window
+    const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
+    const char* vp_bytes = reinterpret_cast<const char*>(vp);
+    const GsampWin w = *win;
+    const bool win_ok = n == w.n;
+    const lds_bytes_t wl_base = w.base + sub * 16;
+    constexpr int NIT = LP / NB, NPLAIN = (L - 1) * P / NB;
+    unsigned cw_t, cw_b, co_t, co_b, co_x, co_f;
+    gsamp_coords_win<L>(0, sc, mx, lv, sub, w, win_ok, cw_t, cw_b, co_t, co_b, co_x, co_f);
+#define MVG_BLEND4()                                                                                    \
+    {                                                                                                   \
+      unsigned wt[NB], wb[NB];                                                                          \
+      wt[0] = quad_bcast<0>(pw_t); wt[1] = quad_bcast<1>(pw_t); wt[2] = quad_bcast<2>(pw_t); wt[3] = quad_bcast<3>(pw_t); \
+      wb[0] = quad_bcast<0>(pw_b); wb[1] = quad_bcast<1>(pw_b); wb[2] = quad_bcast<2>(pw_b); wb[3] = quad_bcast<3>(pw_b); \
+      _Pragma("unroll") for (int s = 0; s < NB; ++s)                                                    \
+        _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                           \
+          const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);                        \
+          const unsigned l4[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};                 \
+          const unsigned r4[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w}; \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+            const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);                       \
+            const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);                       \
+            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);             \
+            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false);     \
+          }                                                                                             \
+        }                                                                                               \
+    }
+#pragma unroll 1
+    for (int it = 0; it < NPLAIN; ++it) {
+      uint4 raw[NB][4];
+#define MVG_QS(SS)                                                                                      \
+      {                                                                                                 \
+        const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
+        const unsigned dxs = quad_bcast<SS>(co_x);                                                      \
+        raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                    \
+        raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs));                            \
+        raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
+        raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                            \
+      }
+      MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
+#undef MVG_QS
+      const unsigned pw_t = cw_t, pw_b = cw_b;
+      __builtin_amdgcn_sched_barrier(0);
+      gsamp_coords_win<L>(it + 1, sc, mx, lv, sub, w, win_ok, cw_t, cw_b, co_t, co_b, co_x, co_f);
+      __builtin_amdgcn_sched_barrier(0);
+      MVG_BLEND4()
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int it = NPLAIN; it < NIT; ++it) {
+      uint4 raw[NB][4];
+#define MVG_QW(SS)                                                                                      \
+      {                                                                                                 \
+        const unsigned ot = quad_bcast<SS>(co_t), ob = quad_bcast<SS>(co_b);                            \
+        const unsigned dxs = quad_bcast<SS>(co_x), fls = quad_bcast<SS>(co_f);                          \
+        if (fls) {                                                                                      \
+          raw[SS][0] = lds_load16(wl_base + ot);                                                        \
+          raw[SS][1] = lds_load16(wl_base + (ot + dxs));                                                \
+          raw[SS][2] = lds_load16(wl_base + ob);                                                        \
+          raw[SS][3] = lds_load16(wl_base + (ob + dxs));                                                \
+        } else {                                                                                        \
+          raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + lane_off));                     \
+          raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs + lane_off));               \
+          raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + lane_off));                     \
+          raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs + lane_off));               \
+        }                                                                                               \
+      }
+      MVG_QW(0) MVG_QW(1) MVG_QW(2) MVG_QW(3)
+#undef MVG_QW
+      const unsigned pw_t = cw_t, pw_b = cw_b;
+      __builtin_amdgcn_sched_barrier(0);
+      gsamp_coords_win<L>(it + 1 < NIT ? it + 1 : NPLAIN, sc, mx, lv, sub, w, win_ok, cw_t, cw_b, co_t, co_b, co_x, co_f);
+      __builtin_amdgcn_sched_barrier(0);
+      MVG_BLEND4()
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef MVG_BLEND4
   } else {
     // PIPE == 1 (round 3): the same arithmetic in the same order, the gathers double-buffered in half batches of 2 samples
     // (8 loads): while half A is blended, half B's 8 loads -- issued before -- are in flight, and the next half A is issued

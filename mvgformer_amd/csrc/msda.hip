@@ -639,6 +639,83 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   msda_gsamp_body<L, NT>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
 }
 
+// msda_gsamp_win_kernel (round 3; VERDICT r2 item 4, the north_star's "LDS staging of sampling windows"): the same work
+// decomposition and arithmetic as msda_gsamp_kernel, plus one LDS window per workgroup for the COARSEST level.  The 64 pairs of a
+// workgroup are neighbours in the image (Morton order), so their coarsest-level samples fall into a small rectangle of the
+// (image, head) plane: bounding box of the pairs' reference pixels, centred in a GSAMP_WIN x GSAMP_WIN window (16 x 16 pixels x 64 B
+// at an 80-byte pitch = 20 KB next to the 20 KB of quad scratch: still four workgroups per CU).  Samples whose 2 x 2 footprint
+// is inside the window are read with ds_read_b128, the others gathered from global memory: bit-identical results.
+template <int L, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_gsamp_win_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                                            const float* __restrict__ xw, const float* __restrict__ r,
+                                                            LevelTable lv, bf16_t* __restrict__ samp,
+                                                            const uint8_t* __restrict__ pair_mask, const int* __restrict__ order,
+                                                            int n_pairs, int Lq, int S, int B, int map_ch) {
+  constexpr int SCP = 3 * L * 8 + 8;
+  __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
+  __shared__ __attribute__((aligned(16))) unsigned char winbuf[GSAMP_WIN * GSAMP_WIN * GSAMP_WIN_PITCH];
+  __shared__ int bbox[5];                                   // min x, min y, max x, max y (coarsest-level pixels), min image
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane & 3, pl = lane >> 2;
+  int m, pblk;
+  if (map_ch == 0) {
+    m = blockIdx.x & 7;
+    pblk = blockIdx.x >> 3;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    m = j & 7;
+    const int t = j >> 3;
+    pblk = ((t / map_ch) * 8 + xcd) * map_ch + t % map_ch;
+  }
+  if (threadIdx.x < 5) bbox[threadIdx.x] = threadIdx.x < 2 || threadIdx.x == 4 ? 0x7fffffff : -1;
+  const int slot = pblk * (NT / 4) + wave * 16 + pl;
+  const bool in_range = slot < n_pairs;
+  const int pair = in_range ? (order ? order[slot] : slot) : 0;
+  const bool act = in_range && !(pair_mask && !pair_mask[pair]);
+  if (in_range && !act) *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
+  constexpr int lw = L - 1;
+  const int Hc = lv.H[lw], Wc = lv.W[lw];
+  const int n = pair / Lq;
+  __syncthreads();
+  if (act && sub == 0) {
+    const float2 rr = *reinterpret_cast<const float2*>(r + ((long)pair * L + lw) * 2);
+    const int px = min(max((int)floorf(index_safe(rr.x * (float)Wc - 0.5f, (float)Wc)), 0), Wc - 1);
+    const int py = min(max((int)floorf(index_safe(rr.y * (float)Hc - 0.5f, (float)Hc)), 0), Hc - 1);
+    atomicMin(&bbox[0], px);
+    atomicMin(&bbox[1], py);
+    atomicMax(&bbox[2], px);
+    atomicMax(&bbox[3], py);
+    atomicMin(&bbox[4], n);
+  }
+  __syncthreads();
+  if (bbox[2] < 0) return;                                  // no pair of this workgroup samples anything (uniform)
+  GsampWin w;
+  w.wx = min(GSAMP_WIN, Wc);
+  w.wy = min(GSAMP_WIN, Hc);
+  w.n = bbox[4];
+  // the window is centred on the bounding box of the reference pixels (of all images the workgroup touches: a workgroup
+  // spans two images only at an image boundary of the processing order, and only the first image's pairs use the window)
+  w.x0 = min(max((bbox[0] + bbox[2] + 1) / 2 - (w.wx / 2 - 1), 0), Wc - w.wx);
+  w.y0 = min(max((bbox[1] + bbox[3] + 1) / 2 - (w.wy / 2 - 1), 0), Hc - w.wy);
+  w.base = (lds_bytes_t)winbuf;
+  {
+    // stage: 4 chunks of 16 B per pixel, consecutive threads -> consecutive chunks of a window row (wx * 64 contiguous bytes)
+    const char* plane = reinterpret_cast<const char*>(vp) + (((long)w.n * 8 + m) * S + lv.start[lw]) * 64;
+    const int nchunk = w.wx * w.wy * 4;
+    for (int i = threadIdx.x; i < nchunk; i += NT) {
+      const int c = i & 3, p = i >> 2;
+      const int y = p / w.wx, x = p - y * w.wx;
+      const uint4 v = *reinterpret_cast<const uint4*>(plane + ((long)(w.y0 + y) * Wc + (w.x0 + x)) * 64 + c * 16);
+      *reinterpret_cast<uint4*>(&winbuf[p * GSAMP_WIN_PITCH + c * 16]) = v;
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  float acc[8];
+  gsamp_unit<L, 2>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc, &w);
+  store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
+}
+
 // PIPE = 1: the gathers double-buffered in half batches (gsamp_dev.h) -- same results bit for bit
 template <int L, int NT>
 __global__ __launch_bounds__(NT) void msda_gsamp_pipe_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
@@ -901,7 +978,11 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
       hipLaunchKernelGGL((msda_gsamp_occ5_kernel<LL, 256>), dim3(8 * npb), dim3(256), 0, st, (const bf16_t*)vp,   \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
-    else if (g_gsamp_pipe)                                                                                        \
+    else if (g_gsamp_pipe == 2 && NT == 256)                                                                      \
+      hipLaunchKernelGGL((msda_gsamp_win_kernel<LL, 256>), dim3(8 * npb), dim3(256), 0, st, (const bf16_t*)vp,    \
+                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
+                         B, map);                                                                                 \
+    else if (g_gsamp_pipe == 1)                                                                                   \
       hipLaunchKernelGGL((msda_gsamp_pipe_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,     \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
@@ -955,7 +1036,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
-  if (!strcmp(key, "gsamp_pipe") && (value == 0 || value == 1)) { g_gsamp_pipe = value; return 0; }
+  if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }
