@@ -69,6 +69,7 @@ for k in acc:
         # what the figure was measured on: bench.py quotes it only for the same kernel sources and configuration
         rec = {"kernel": k, "config": os.environ.get("MVG_PROF_CONFIG", "cfg2"), "dtype": os.environ.get("MVG_PROF_DTYPE", "bf16"),
                "queries": int(os.environ.get("MVG_PROF_QUERIES", "1024")), "valid_fraction": None,
+               "inside": os.environ.get("MVG_PROF_INSIDE", "grid"),
                "src_sha256": sampler_source_hash(),
                "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
                "fetch_correction": 2.0,
