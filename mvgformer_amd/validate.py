@@ -128,15 +128,17 @@ def main(argv=None):
     frames = list(npz_frames(args.frames_npz) if args.frames_npz else synthetic_frames(cfg, args.frames, args.seed))
     results = []
     for thr in cfg.DECODER.inference_conf_thr:                                   # validate_3d.py:185
-        preds, gts, gts_vis, t_dec = [], [], [], 0.0
-        for src, meta, gt in frames:
+        preds, gts, gts_vis, t_dec, n_timed = [], [], [], 0.0, 0
+        for fi, (src, meta, gt) in enumerate(frames):
             src = [s.to(dev) for s in src]
             meta = to_device(meta, dev)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             _, pred = head(src, meta, threshold=thr)                             # function.py:372-396
             torch.cuda.synchronize()
-            t_dec += time.perf_counter() - t0
+            if fi > 0 or len(frames) == 1:          # the first frame builds the weight caches (one-time)
+                t_dec += time.perf_counter() - t0
+                n_timed += 1
             preds.extend(p for p in pred)
             if gt is not None:
                 gts.append(gt[0])
@@ -145,7 +147,7 @@ def main(argv=None):
         row = {"inference_conf_thr": thr, "frames": len(preds),
                "candidates_above_thr": int(sum(int((p[:, 0, 3] >= 0).sum()) for p in preds)),
                "poses_after_nms": int(sum(len(k) for k in kept)),
-               "decoder_ms_per_frame": round(1e3 * t_dec / max(len(preds), 1), 3)}
+               "decoder_ms_per_frame": round(1e3 * t_dec / max(n_timed, 1), 3)}     # eager launches, host-timed
         if gts and getattr(cfg.DECODER, "convert_joint_format_indices", None) is None:
             aps, recs, mpjpe, recall500 = E.evaluate_panoptic(kept, gts, gts_vis)   # panoptic.py:493-574
             row.update(AP={str(t): round(100 * a, 2) for t, a in zip(E.MPJPE_THRESHOLDS, aps)},
