@@ -66,6 +66,14 @@ CONFIGS = {
     "mini5": dict(V=5, NQ=12, layers=2, img_wh=(320, 192), orig_wh=(640, 360), focal=480.0,
                   space_size=(4000.0, 4000.0, 2000.0), space_center=(0.0, -200.0, 800.0),
                   k=(-0.12, 0.06, 0.01), p=(2e-3, -1.5e-3), radius=3200.0),
+    # Shelf-like: 3 views, no distortion (data/Shelf/calibration_shelf.json), 4 : 3.04 network image
+    "mini3s": dict(V=3, NQ=10, layers=2, img_wh=(400, 304), orig_wh=(516, 388), focal=530.0,
+                   space_size=(4000.0, 4000.0, 2000.0), space_center=(450.0, -320.0, 800.0),
+                   k=(0.0, 0.0, 0.0), p=(0.0, 0.0), radius=3600.0),
+    # 9 views: more than the 8 lanes a (query, joint) problem has in the view softmax / triangulation / next projection
+    "mini9": dict(V=9, NQ=8, layers=2, img_wh=(320, 192), orig_wh=(640, 360), focal=480.0,
+                  space_size=(4000.0, 4000.0, 2000.0), space_center=(0.0, -200.0, 800.0),
+                  k=(-0.12, 0.06, 0.01), p=(2e-3, -1.5e-3), radius=3200.0),
 }
 CONFIGS["cfg3"] = CONFIGS["cfg2"]  # same workload, queries sharded over 8 GPUs
 

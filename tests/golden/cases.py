@@ -15,6 +15,10 @@ LAYER_CASES = {
     "mini5_b2": dict(config="mini5", seed=13, layers=2, B=2, NQ=6, valid_fraction=0.5),
     # BASELINE.json configs[0]: 1 sample, 2 views 256x256, 64 queries, 1 layer
     "cfg1": dict(config="cfg1", seed=0, layers=1),
+    # round 3: Shelf-like geometry (3 views, k = p = 0, 400x304 network image), about half of the queries valid
+    "mini3_shelf": dict(config="mini3s", seed=23, layers=2, valid_fraction=0.5, triangulation=True),
+    # round 3: 9 views (> the 8 lanes per problem of the triangulation kernel), all queries valid
+    "mini9": dict(config="mini9", seed=19, layers=2, triangulation=True),
 }
 
 

@@ -137,8 +137,12 @@ def gen_triangulation(ref, case):
 def main():
     ref = load_reference()
     torch.manual_seed(0)
-    gen_msda(ref)
+    only = sys.argv[1:]                  # optional: names of the layer cases to (re)generate; default everything
+    if not only:
+        gen_msda(ref)
     for cname, spec in LAYER_CASES.items():
+        if only and cname not in only:
+            continue
         case, out = run_layers(ref, cname, spec)
         if spec.get("triangulation", False):
             out.update({"tri_" + k: v for k, v in gen_triangulation(ref, case).items()})
