@@ -147,6 +147,12 @@ int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype,
                const float* bias, void* out, int out_dtype, int ldc,
                const uint8_t* rowmask, int relu, int M, int N, int K, void* stream);
 
+/* mvg_linear with the activation formed as A + A2 on load (A2: fp32, same shape and leading dimension as A, or NULL):
+ * the query term of the first layer, Linear(tgt + query_pos) (dq_decoder.py:580 `with_pos_embed` + projattn.py:180-181),
+ * without a separate elementwise pass over the two (B*Lq, 256) tensors. */
+int mvg_linear_sum(const void* A, const void* A2, int a_dtype, int lda, const void* W, int w_dtype, const float* bias,
+                   void* out, int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream);
+
 /* A.3 steps 3-6 fused (projattn.py:180-200): oa (V*B*Lq*L, 192) f32 = Linear outputs
  * [sampling_offsets(128) | attention_weights(64)] per level row; reinterpretation,
  * softmax(L*P), locations (ref_lvl (V*B*Lq,L,2) + offset/(W,H)) and multi-scale sampling of

@@ -1,6 +1,6 @@
 // Dense projections of the decoder layer on the gfx950 matrix cores.
 //
-//   out[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) * rowmask[M]
+//   out[M,N] = act((A[M,K] (+ A2[M,K])) @ W[N,K]^T + bias[N]) * rowmask[M]
 //
 // A is activations (row-major, K contiguous), W an nn.Linear weight (row-major (N,K), K
 // contiguous) -- both operands are "K-major", so both are staged the same way.
@@ -62,7 +62,8 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
 
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
 template <typename TA, bool BF16, typename TO>
-__global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, long lda, const void* __restrict__ Wv,
+__global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
+                                                     const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
                                                      int K) {
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const TA* Ab = A + (long)m0 * lda;
+  const TA* A2b = A2 ? A2 + (long)m0 * lda : nullptr;      // optional addend (fp32 storage only): A + A2 formed on load
   const TW* Wb = W + (long)n0 * K;
   const int mrows = min(BM, M - m0), nrows = min(BN, N - n0);
 
@@ -94,6 +96,13 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i;
       ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
+      if constexpr (sizeof(TA) == 4) {
+        if (A2b) {
+          const Chunk c2 = load_chunk<TA, BF16>(A2b, lda, c >> 3, mrows, k0, c & 7);
+          ca[i].lo += c2.lo;
+          ca[i].hi += c2.hi;
+        }
+      }
       cb[i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
     }
   };
@@ -195,20 +204,31 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, l
 }
 
 template <typename TA, bool BF16, typename TO>
-int launch_linear(const void* A, long lda, const void* W, const float* bias, void* out, long ldc,
+int launch_linear(const void* A, const void* A2, long lda, const void* W, const float* bias, void* out, long ldc,
                   const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO>), grid, dim3(256), 0, st, (const TA*)A, lda, W, bias, (TO*)out, ldc,
-                     rowmask, relu, M, N, K);
+  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2, lda, W, bias,
+                     (TO*)out, ldc, rowmask, relu, M, N, K);
   MVG_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
 
+extern "C" int mvg_linear_sum(const void* A, const void* A2, int a_dtype, int lda, const void* W, int w_dtype, const float* bias,
+                              void* out, int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K,
+                              void* stream);
+
 extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
                           int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {
+  return mvg_linear_sum(A, nullptr, a_dtype, lda, W, w_dtype, bias, out, out_dtype, ldc, rowmask, relu, M, N, K, stream);
+}
+
+extern "C" int mvg_linear_sum(const void* A, const void* A2, int a_dtype, int lda, const void* W, int w_dtype, const float* bias,
+                              void* out, int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K,
+                              void* stream) {
   if (!A || !W || !out || M < 0 || N <= 0 || K <= 0) return MVG_E_BADARG;
+  if (A2 && (a_dtype != MVG_F32 || (reinterpret_cast<uintptr_t>(A2) % 16) != 0)) return MVG_E_BADARG;
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool bf = (w_dtype == MVG_BF16);
@@ -220,16 +240,16 @@ extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, in
   if ((((long)ldc * o_el) % 16) != 0 || (reinterpret_cast<uintptr_t>(out) % 16) != 0) return MVG_E_BADARG;
   if (!bf) {
     if (a_dtype != MVG_F32) return MVG_E_BADARG;   // fp32 MFMA path takes fp32 activations
-    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
-    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_F32) return launch_linear<float, false, float>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, false, bf16_t>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
     return MVG_E_BADARG;
   }
   if (a_dtype == MVG_BF16) {
-    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
-    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_F32) return launch_linear<bf16_t, true, float>(A, nullptr, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<bf16_t, true, bf16_t>(A, nullptr, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
   } else if (a_dtype == MVG_F32) {
-    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
-    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_F32) return launch_linear<float, true, float>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    if (out_dtype == MVG_BF16) return launch_linear<float, true, bf16_t>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
   }
   return MVG_E_BADARG;
 }

@@ -403,6 +403,9 @@ class DQDecoderLayer(MvPDecoderLayer):
         else:
             r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
         x = lambda: self.with_pos_embed(tgt.float(), None if query_pos is None else query_pos.float()).contiguous()
+        if (os.environ.get("MVG_LINEAR_SUM", "1") != "0" and query_pos is not None and tgt.dtype == torch.float32 and query_pos.dtype == torch.float32 and tgt.is_contiguous()
+                and query_pos.is_contiguous() and query_pos.shape == tgt.shape):
+            x.parts = (tgt, query_pos)          # lets the fast path fold the add into the query-term GEMM
         xw_in, self._xw_in = self._xw_in, None     # query term computed by the previous layer's chain B (or None)
         if xw_in is not None and tuple(xw_in.shape) != (B * Lq, 192):
             xw_in = None

@@ -233,8 +233,9 @@ def gather_ref(feat, r, x, levels, V, B):
     return ain
 
 
-def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None):
-    """out = act(a @ w.T + bias) (* rowmask).  a (M,K) f32|bf16; w (N,K) f32|bf16 (compute type)."""
+def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None, add=None):
+    """out = act((a [+ add]) @ w.T + bias) (* rowmask).  a (M,K) f32|bf16; w (N,K) f32|bf16 (compute type); add: optional fp32
+    tensor of a's shape and strides, summed with a on load (mvg_linear_sum)."""
     M, K = a.shape
     N = w.shape[0]
     out_dtype = out_dtype or (torch.float32 if w.dtype == torch.float32 else torch.bfloat16)
@@ -242,10 +243,13 @@ def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None):
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     if a.stride(1) != 1 or not w.is_contiguous() or out.stride(1) != 1:
         raise RuntimeError("mvg_linear: K-contiguous operands required")
+    if add is not None and (add.dtype != torch.float32 or a.dtype != torch.float32 or add.shape != a.shape
+                            or add.stride() != a.stride()):
+        raise RuntimeError("mvg_linear_sum: the addend must be an fp32 tensor with a's shape and strides")
     with _timed("linear_%dx%dx%d" % (M, N, K)):
-      L.check(L.load().mvg_linear(L.ptr(a), L.dtype_code(a.dtype), a.stride(0), L.ptr(w), L.dtype_code(w.dtype),
-                                L.ptr(bias), L.ptr(out), L.dtype_code(out.dtype), out.stride(0), L.ptr(rowmask),
-                                1 if relu else 0, M, N, K, L.stream_ptr()), "mvg_linear")
+      L.check(L.load().mvg_linear_sum(L.ptr(a), L.ptr(add), L.dtype_code(a.dtype), a.stride(0), L.ptr(w),
+                                    L.dtype_code(w.dtype), L.ptr(bias), L.ptr(out), L.dtype_code(out.dtype), out.stride(0),
+                                    L.ptr(rowmask), 1 if relu else 0, M, N, K, L.stream_ptr()), "mvg_linear_sum")
     return out
 
 

@@ -237,7 +237,8 @@ class ProjAttn(nn.Module):
         dt = feat.dtype
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
-        if callable(x) and not (self.uses_fast_path(dt) and xw is not None):
+        parts = getattr(x, "parts", None)        # (tgt, query_pos) when the caller has not formed tgt + query_pos yet
+        if callable(x) and not (self.uses_fast_path(dt) and (xw is not None or parts is not None)):
             x = x()
         if self.uses_fast_path(dt):
             # Linear(bilinear(feat) + x) = bilinear(Linear(feat)) + Linear(x): project the pyramid once (G), compute
@@ -247,7 +248,10 @@ class ProjAttn(nn.Module):
                 order = ops.bin_pairs(r, pair_mask, levels)
             if xw is None:      # else: already computed by the previous layer's fused chain B
                 Wq, bq = self._fast_query_weights(dt)
-                xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
+                if parts is not None:   # first layer: tgt + query_pos formed inside the GEMM's loader (mvg_linear_sum)
+                    xw = ops.linear(parts[0].reshape(-1, Cc), Wq, bq, out_dtype=torch.float32, add=parts[1].reshape(-1, Cc))
+                else:
+                    xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
             vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
         use_g = self.g_sampling_f32 if self.g_sampling_f32 != "auto" else r.shape[1] * levels.L >= S

@@ -173,6 +173,11 @@ def test_linear_mfma_fp32_and_bf16():
         assert _relerr(got, want) < 2e-6, (M, N, K)            # exact-fp32 MFMA, K <= 1024
         got = ops.linear(a, w, b, relu=True, rowmask=mask)
         assert _relerr(got, torch.relu(want) * mask[:, None].double()) < 2e-6
+        # A + A2 formed on load (mvg_linear_sum: the first layer's Linear(tgt + query_pos)): bit-identical to the GEMM of the sum
+        a2 = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV)
+        assert torch.equal(ops.linear(a, w, b, add=a2), ops.linear(a + a2, w, b))
+        assert torch.equal(ops.linear(a, w.bfloat16(), b, out_dtype=torch.float32, add=a2),
+                           ops.linear(a + a2, w.bfloat16(), b, out_dtype=torch.float32))
         # bf16 compute: compare against the same product of bf16-rounded operands
         a16, w16 = a.bfloat16(), w.bfloat16()
         want16 = a16.double() @ w16.double().t() + b.double()
