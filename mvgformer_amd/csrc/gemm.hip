@@ -17,9 +17,14 @@
 // Global->register prefetch of slab t+1 overlaps the MFMAs of slab t.
 #include "common.h"
 
+int g_linear_tiles = 1;     // tuning knob "linear_tiles": 0 = always 128 x 128 tiles (rounds 1-2)
+
 namespace {
 
-constexpr int BM = 128, BN = 128, PITCH = 144;   // bytes per LDS row (128 data + 16 pad)
+constexpr int PITCH = 144;   // bytes per LDS row (128 data + 16 pad)
+// Tile shapes (round 3): 128 x 128 (default), 128 x 192 for N = 192 (the [offsets | logits] projections: two 128-column tiles
+// left a quarter of the MFMAs on padding), 64 x 128 when 128-row tiles would not give every CU a workgroup (the FFN's second
+// GEMM at 7 680 rows: 120 workgroups on 256 CUs).  Always 4 wavefronts as 2 x 2; a wavefront owns (BM/2) x (BN/2).
 
 struct Chunk {
   f32x4 lo, hi;   // hi only used when converting an fp32 source to bf16 (8 values)
@@ -61,7 +66,7 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
 }
 
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
-template <typename TA, bool BF16, typename TO>
+template <typename TA, bool BF16, typename TO, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
                                                      const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
@@ -70,7 +75,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
   using TW = typename std::conditional<BF16, bf16_t, float>::type;
   const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
-  __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * PITCH];
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NJ = WN / 32;      // per-wavefront tile and its 32 x 32 MFMA blocks
+  constexpr int EPB = (int)sizeof(TO) * BN + 16;                           // epilogue staging pitch (bytes)
+  constexpr int LDS_BYTES = (BM + BN) * PITCH > 64 * EPB ? (BM + BN) * PITCH : 64 * EPB;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* ldsA = lds;
   char* ldsB = lds + BM * PITCH;
 
@@ -82,18 +90,19 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
   const TW* Wb = W + (long)n0 * K;
   const int mrows = min(BM, M - m0), nrows = min(BN, N - n0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  Chunk ca[4], cb[4];
+  constexpr int NCA = BM / 32, NCB = BN / 32;          // 16-byte chunks per thread and slab (a tile row = 8 chunks)
+  Chunk ca[NCA], cb[NCB];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
       ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
       if constexpr (sizeof(TA) == 4) {
@@ -103,14 +112,22 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
           ca[i].hi += c2.hi;
         }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = tid + 256 * i;
       cb[i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
       store_chunk<TA, BF16>(ldsA, c >> 3, c & 7, ca[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = tid + 256 * i;
       store_chunk<TW, BF16>(ldsB, c >> 3, c & 7, cb[i]);
     }
   };
@@ -124,18 +141,17 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
     if (kt + 1 < nk) gload((kt + 1) * KSLAB);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 a[2], b[2];
+      f32x4 a[MI], b[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const f32x4*>(ldsA + (wm * 64 + i * 32 + rl) * PITCH + 32 * g + 16 * h);
-        b[i] = *reinterpret_cast<const f32x4*>(ldsB + (wn * 64 + i * 32 + rl) * PITCH + 32 * g + 16 * h);
-      }
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(ldsA + (wm * WM + i * 32 + rl) * PITCH + 32 * g + 16 * h);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(ldsB + (wn * WN + j * 32 + rl) * PITCH + 32 * g + 16 * h);
       // D' = W_tile * A_tile^T: the MFMA "row" index (registers) runs over output COLUMNS n, the
       // lane index over output ROWS m, so a lane ends up with groups of 4 consecutive n.
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if constexpr (BF16) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
                                                                 __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
@@ -153,23 +169,23 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
     }
   }
 
-  // ---- epilogue.  acc[i][j][e] = out[m0 + wm*64 + i*32 + rl][n0 + wn*64 + j*32 + (e&3) + 8*(e>>2) + 4*h].
-  // Two phases (i = 0, 1) of 64 rows x 128 columns: bias / ReLU / row mask in registers, the tile is
+  // ---- epilogue.  acc[i][j][e] = out[m0 + wm*WM + i*32 + rl][n0 + wn*WN + j*32 + (e&3) + 8*(e>>2) + 4*h].
+  // MI phases of 64 rows x BN columns: bias / ReLU / row mask in registers, the tile is
   // transposed through LDS (16-byte writes of 4 consecutive columns), then stored with 16-byte
-  // vectors, 256 (bf16) or 512 (fp32) contiguous bytes per row.
-  constexpr int EP = (int)sizeof(TO) * BN + 16;     // staging pitch in bytes
-  static_assert(64 * EP <= (BM + BN) * PITCH, "staging tile must fit the main-loop LDS");
+  // vectors, 2 * BN (bf16) or 4 * BN (fp32) contiguous bytes per row.
+  constexpr int EP = EPB;                           // staging pitch in bytes
   constexpr int CPV = 16 / (int)sizeof(TO);         // columns per 16-byte vector
   constexpr int VPR = BN / CPV;                     // vectors per staged row
+  static_assert((64 * VPR) % 256 == 0, "the staged tile is stored in whole passes of the workgroup");
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int grow = m0 + wm * 64 + i * 32 + rl;
+  for (int i = 0; i < MI; ++i) {
+    const int grow = m0 + wm * WM + i * 32 + rl;
     const bool keep = rowmask ? (grow < M && rowmask[grow] != 0) : true;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = wn * 64 + j * 32 + 8 * g + 4 * h;
+        const int nl = wn * WN + j * 32 + 8 * g + 4 * h;
         f32x4 v;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
     for (int c0 = 0; c0 < 64 * VPR; c0 += 256) {
       const int c = c0 + tid;
       const int srow = c / VPR, vcol = c % VPR;            // staged row (0..63), vector column
-      const int row = m0 + (srow >> 5) * 64 + i * 32 + (srow & 31);
+      const int row = m0 + (srow >> 5) * WM + i * 32 + (srow & 31);
       const int col = n0 + vcol * CPV;
       if (row < M && col < N) {
         *reinterpret_cast<f32x4*>(out + (long)row * ldc + col) =
@@ -203,14 +219,27 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
   }
 }
 
-template <typename TA, bool BF16, typename TO>
-int launch_linear(const void* A, const void* A2, long lda, const void* W, const float* bias, void* out, long ldc,
-                  const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
+template <typename TA, bool BF16, typename TO, int BM, int BN>
+int launch_linear_tile(const void* A, const void* A2, long lda, const void* W, const float* bias, void* out, long ldc,
+                       const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2, lda, W, bias,
+  hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, BM, BN>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2, lda, W, bias,
                      (TO*)out, ldc, rowmask, relu, M, N, K);
   MVG_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename TA, bool BF16, typename TO>
+int launch_linear(const void* A, const void* A2, long lda, const void* W, const float* bias, void* out, long ldc,
+                  const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
+  if (g_linear_tiles) {
+    if (N % 192 == 0 && N % 128 != 0)        // N = 192, 576, ...: no padded column tile
+      return launch_linear_tile<TA, BF16, TO, 128, 192>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+    const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128);
+    if (tiles128 < 384 && M > 64)            // fewer than 1.5 workgroups per CU of an MI355X: halve the row tile
+      return launch_linear_tile<TA, BF16, TO, 64, 128>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
+  }
+  return launch_linear_tile<TA, BF16, TO, 128, 128>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
 }
 
 }  // namespace
