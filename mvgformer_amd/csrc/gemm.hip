@@ -67,7 +67,7 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
 
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
 template <typename TA, bool BF16, typename TO, int BM = 128, int BN = 128>
-__global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
+__global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
                                                      const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
