@@ -506,50 +506,74 @@ __global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __
   float acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
-  // ---- pass 2: batches of NB samples, their 4 * NB gathers issued back to back (as msda_fused_kernel)
+  // ---- pass 2 (round 3).  The first form computed every sample's coordinates, zero padding and softmax weight on all 8 lanes of
+  // the head (PMC: 2 425 VALU instructions per wavefront, the VALU 57 % busy -- the kernel's bound).  Now lane `sub` computes ONE of
+  // the 8 samples of a level (P = 8) and the 8 lanes exchange the results with ds_swizzle (crossbar only, no LDS memory): 4 corner
+  // weights + 3 element offsets per sample; two half batches of 4 samples = 16 gathers in flight as before.  Same operations in
+  // the same order for every sample and every accumulation: bit-identical to the first form.
+  static_assert(P == 8 && NB == 4, "one sample per lane of the head's 8");
+#define MVG_SW8(K, X) __builtin_amdgcn_ds_swizzle((X), 24 | ((K) << 5))      /* value of lane K of every group of 8 lanes */
 #pragma unroll 1
-  for (int it = 0; it < LP / NB; ++it) {
-    const int l = (it * NB) / P;
+  for (int l = 0; l < L; ++l) {
     const int H = lv.H[l], W = lv.W[l];
     const float Wf = (float)W, Hf = (float)H;
     const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
-    const float invW = lv.invW[l], invH = lv.invH[l];
     const float* lvl = vbase + (long)lv.start[l] * C;
-    const f32x4 lg = *reinterpret_cast<const f32x4*>(sc + it * NB);
-    const f32x4 o4a = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2), o4b = *reinterpret_cast<const f32x4*>(sc + LP + it * NB * 2 + 4);
-    const float ox[NB] = {o4a[0], o4a[2], o4b[0], o4b[2]}, oy[NB] = {o4a[1], o4a[3], o4b[1], o4b[3]};
-    float cw[NB][4];
-    typename RV::type raw[NB][4];
-#pragma unroll
-    for (int s_ = 0; s_ < NB; ++s_) {
-      const float lx = refx + ox[s_] * invW;                           // projattn.py:186-191
-      const float ly = refy + oy[s_] * invH;
-      const float h_raw = ly * Hf - 0.5f;                              // cuh:295-296
+    int my_w[4], my_t, my_b, my_x;
+    {
+      const float lgs = sc[l * P + sub];
+      const float2 of = *reinterpret_cast<const float2*>(sc + LP + (l * P + sub) * 2);
+      const float lx = refx + of.x * lv.invW[l];                         // projattn.py:186-191
+      const float ly = refy + of.y * lv.invH[l];
+      const float h_raw = ly * Hf - 0.5f;                                // cuh:295-296
       const float w_raw = lx * Wf - 0.5f;
       const bool inside = (h_raw > -1.f) && (w_raw > -1.f) && (h_raw < Hf) && (w_raw < Wf);   // cuh:298
       const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
       const float hl_f = floorf(h_im), wl_f = floorf(w_im);
       const int h_low = (int)hl_f, w_low = (int)wl_f;
       const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-      const float a = inside ? __expf(lg[s_] - mx) : 0.f;              // softmax weight (projattn.py:184)
+      const float a = inside ? __expf(lgs - mx) : 0.f;                   // softmax weight (projattn.py:184)
       const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-      cw[s_][0] = (hl_ok && wl_ok) ? hh * hw * a : 0.f;                // cuh:66-88 zero padding
-      cw[s_][1] = (hl_ok && wh_ok) ? hh * lw * a : 0.f;
-      cw[s_][2] = (hh_ok && wl_ok) ? lh * hw * a : 0.f;
-      cw[s_][3] = (hh_ok && wh_ok) ? lh * lw * a : 0.f;
+      my_w[0] = __float_as_int((hl_ok && wl_ok) ? hh * hw * a : 0.f);   // cuh:66-88 zero padding
+      my_w[1] = __float_as_int((hl_ok && wh_ok) ? hh * lw * a : 0.f);
+      my_w[2] = __float_as_int((hh_ok && wl_ok) ? lh * hw * a : 0.f);
+      my_w[3] = __float_as_int((hh_ok && wh_ok) ? lh * lw * a : 0.f);
       const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
       const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
-      raw[s_][0] = RV::load(lvl + (hl_c * W + wl_c) * C);
-      raw[s_][1] = RV::load(lvl + (hl_c * W + wh_c) * C);
-      raw[s_][2] = RV::load(lvl + (hh_c * W + wl_c) * C);
-      raw[s_][3] = RV::load(lvl + (hh_c * W + wh_c) * C);
+      my_t = (hl_c * W + wl_c) * C;
+      my_b = (hh_c * W + wl_c) * C;
+      my_x = (wh_c - wl_c) * C;
     }
-    __builtin_amdgcn_sched_barrier(0);   // all 4*NB loads are issued before the first blend
 #pragma unroll
-    for (int s_ = 0; s_ < NB; ++s_)
+    for (int half = 0; half < 2; ++half) {
+      float cw[NB][4];
+      typename RV::type raw[NB][4];
+#define MVG_GS8(S_, K)                                                                                \
+      {                                                                                               \
+        const int et = MVG_SW8(K, my_t), eb = MVG_SW8(K, my_b), ex = MVG_SW8(K, my_x);                \
+        cw[S_][0] = __int_as_float(MVG_SW8(K, my_w[0]));                                              \
+        cw[S_][1] = __int_as_float(MVG_SW8(K, my_w[1]));                                              \
+        cw[S_][2] = __int_as_float(MVG_SW8(K, my_w[2]));                                              \
+        cw[S_][3] = __int_as_float(MVG_SW8(K, my_w[3]));                                              \
+        raw[S_][0] = RV::load(lvl + et);                                                              \
+        raw[S_][1] = RV::load(lvl + (et + ex));                                                       \
+        raw[S_][2] = RV::load(lvl + eb);                                                              \
+        raw[S_][3] = RV::load(lvl + (eb + ex));                                                       \
+      }
+      if (half == 0) {
+        MVG_GS8(0, 0) MVG_GS8(1, 1) MVG_GS8(2, 2) MVG_GS8(3, 3)
+      } else {
+        MVG_GS8(0, 4) MVG_GS8(1, 5) MVG_GS8(2, 6) MVG_GS8(3, 7)
+      }
+#undef MVG_GS8
+      __builtin_amdgcn_sched_barrier(0);   // all 16 loads are issued before the first blend
 #pragma unroll
-      for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s_][k], cw[s_][k]);
+      for (int s_ = 0; s_ < NB; ++s_)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s_][k], cw[s_][k]);
+    }
   }
+#undef MVG_SW8
   if (live) store_acc<float, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
 }
 
