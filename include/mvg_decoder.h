@@ -147,6 +147,14 @@ int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype,
                const float* bias, void* out, int out_dtype, int ldc,
                const uint8_t* rowmask, int relu, int M, int N, int K, void* stream);
 
+/* mvg_linear (fp32) over rows in a processing order, skipping tiles the consumer masks: tile row i works on row order[m0 + i] of
+ * A / out; a tile none of whose rows has inside[row] != 0 writes `masked_row` (N floats, what the same kernel computes for such
+ * a row) to all its rows without arithmetic.  The per-view output projection and pose MLP of the fp32 path (projattn.py:203,
+ * dq_decoder.py:585-586, 673-690): pairs outside the image -- a third of them at cfg-2 -- cost a broadcast instead of three GEMMs. */
+int mvg_linear_ordered(const float* A, int lda, const float* W, const float* bias, float* out, int ldc,
+                       const uint8_t* rowmask, int relu, int M, int N, int K, const int32_t* order,
+                       const uint8_t* inside, const float* masked_row, void* stream);
+
 /* mvg_linear with the activation formed as A + A2 on load (A2: fp32, same shape and leading dimension as A, or NULL):
  * the query term of the first layer, Linear(tgt + query_pos) (dq_decoder.py:580 `with_pos_embed` + projattn.py:180-181),
  * without a separate elementwise pass over the two (B*Lq, 256) tensors. */

@@ -66,12 +66,18 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
 }
 
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
-template <typename TA, bool BF16, typename TO, int BM = 128, int BN = 128>
+// IDX (round 3, fp32 path): tile row i works on global row order[m0 + i] of A / out (the sampler's processing order: rows whose
+// reference point is outside the image come last, mvg_bin_pairs).  A tile without a single row of `inside` does no arithmetic: all
+// of its output rows equal `masked_row` (N floats: what this very kernel computes for such a row -- zeros behind a row mask,
+// act(bias) for a zero input row, a cached constant further down a chain), which it broadcasts and leaves.
+template <typename TA, bool BF16, typename TO, int BM = 128, int BN = 128, bool IDX = false>
 __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
                                                      const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
-                                                     int K) {
+                                                     int K, const int* __restrict__ order = nullptr,
+                                                     const uint8_t* __restrict__ inside = nullptr,
+                                                     const float* __restrict__ masked_row = nullptr) {
   using TW = typename std::conditional<BF16, bf16_t, float>::type;
   const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
@@ -89,6 +95,35 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const T
   const TA* A2b = A2 ? A2 + (long)m0 * lda : nullptr;      // optional addend (fp32 storage only): A + A2 formed on load
   const TW* Wb = W + (long)n0 * K;
   const int mrows = min(BM, M - m0), nrows = min(BN, N - n0);
+  __shared__ int rid[IDX ? BM : 1];                         // IDX: global row of every tile row (-1: past the end)
+  if constexpr (IDX) {
+    bool mine = false;
+    if (tid < BM) {
+      const int slot = m0 + tid;
+      const int g = slot < M ? order[slot] : -1;
+      rid[tid] = g;
+      mine = g >= 0 && inside[g] != 0;
+    }
+    if (__syncthreads_or(mine) == 0) {                      // nothing of this tile is inside an image: constant rows
+      constexpr int VPT = BN / 4;                           // 16-byte vectors per output row of the tile
+      for (int c = tid; c < BM * VPT; c += 256) {
+        const int row = c / VPT, col = n0 + (c % VPT) * 4;
+        const int g = rid[row];
+        if (g >= 0 && col < N) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(masked_row + col);
+          if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<f32x4*>(out + (long)g * ldc + col) = v;
+          } else {
+            uint2 pk;
+            pk.x = pack_bf16(v[0], v[1]);
+            pk.y = pack_bf16(v[2], v[3]);
+            *reinterpret_cast<uint2*>(out + (long)g * ldc + col) = pk;
+          }
+        }
+      }
+      return;
+    }
+  }
 
   f32x16 acc[MI][NJ];
 #pragma unroll
@@ -104,7 +139,12 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const T
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
-      ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
+      if constexpr (IDX) {            // row pointer through the processing order; rows past the end read as zeros
+        const int g = rid[c >> 3];
+        ca[i] = load_chunk<TA, BF16>(A + (long)max(g, 0) * lda, lda, 0, g >= 0 ? 1 : 0, k0, c & 7);
+      } else {
+        ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
+      }
       if constexpr (sizeof(TA) == 4) {
         if (A2b) {
           const Chunk c2 = load_chunk<TA, BF16>(A2b, lda, c >> 3, mrows, k0, c & 7);
@@ -179,8 +219,9 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const T
   static_assert((64 * VPR) % 256 == 0, "the staged tile is stored in whole passes of the workgroup");
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int grow = m0 + wm * WM + i * 32 + rl;
-    const bool keep = rowmask ? (grow < M && rowmask[grow] != 0) : true;
+    int grow = m0 + wm * WM + i * 32 + rl;
+    if constexpr (IDX) grow = rid[wm * WM + i * 32 + rl];
+    const bool keep = rowmask ? (grow >= 0 && grow < M && rowmask[grow] != 0) : true;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -208,9 +249,10 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const T
     for (int c0 = 0; c0 < 64 * VPR; c0 += 256) {
       const int c = c0 + tid;
       const int srow = c / VPR, vcol = c % VPR;            // staged row (0..63), vector column
-      const int row = m0 + (srow >> 5) * WM + i * 32 + (srow & 31);
+      int row = m0 + (srow >> 5) * WM + i * 32 + (srow & 31);
+      if constexpr (IDX) row = rid[(srow >> 5) * WM + i * 32 + (srow & 31)];
       const int col = n0 + vcol * CPV;
-      if (row < M && col < N) {
+      if (row >= 0 && row < M && col < N) {
         *reinterpret_cast<f32x4*>(out + (long)row * ldc + col) =
             *reinterpret_cast<const f32x4*>(lds + srow * EP + vcol * 16);
       }
@@ -225,6 +267,18 @@ int launch_linear_tile(const void* A, const void* A2, long lda, const void* W, c
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
   hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, BM, BN>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2, lda, W, bias,
                      (TO*)out, ldc, rowmask, relu, M, N, K);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp32 indexed form (mvg_linear_ordered)
+template <int BM>
+int launch_linear_idx(const float* A, long lda, const float* W, const float* bias, float* out, long ldc, const uint8_t* rowmask,
+                      int relu, int M, int N, int K, const int* order, const uint8_t* inside, const float* masked_row,
+                      hipStream_t st) {
+  dim3 grid((N + 127) / 128, (M + BM - 1) / BM);
+  hipLaunchKernelGGL((linear_kernel<float, false, float, BM, 128, true>), grid, dim3(256), 0, st, A, (const float*)nullptr, lda,
+                     (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row);
   MVG_LAUNCH_CHECK();
   return 0;
 }
@@ -247,6 +301,22 @@ int launch_linear(const void* A, const void* A2, long lda, const void* W, const 
 extern "C" int mvg_linear_sum(const void* A, const void* A2, int a_dtype, int lda, const void* W, int w_dtype, const float* bias,
                               void* out, int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K,
                               void* stream);
+
+extern "C" int mvg_linear_ordered(const float* A, int lda, const float* W, const float* bias, float* out, int ldc,
+                                  const uint8_t* rowmask, int relu, int M, int N, int K, const int32_t* order,
+                                  const uint8_t* inside, const float* masked_row, void* stream) {
+  if (!A || !W || !out || !order || !inside || !masked_row || M < 0 || N <= 0 || K <= 0) return MVG_E_BADARG;
+  if (M == 0) return 0;
+  if (K % 32 != 0 || N % 8 != 0 || (lda % 4) != 0 || (ldc % 4) != 0) return MVG_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(out) |
+       reinterpret_cast<uintptr_t>(masked_row)) % 16 != 0)
+    return MVG_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128);
+  if (g_linear_tiles && tiles128 < 384 && M > 64)
+    return launch_linear_idx<64>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, st);
+  return launch_linear_idx<128>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, st);
+}
 
 extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
                           int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {

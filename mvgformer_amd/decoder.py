@@ -175,6 +175,8 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.compute_dtype = torch.float32
         self.use_fused_chains = True    # bf16 inference: LDS-resident Linear chains (csrc/chain.hip)
         self.fuse_boundary = True       # the triangulation launch also projects the new points for the next layer
+        # fp32 path: output projection + pose MLP skip the tiles whose pairs are all outside their image (round 3)
+        self.skip_masked_f32 = os.environ.get("MVG_SKIP_MASKED_F32", "1") != "0"
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
@@ -243,6 +245,22 @@ class DQDecoderLayer(MvPDecoderLayer):
             o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
         return wts, o_masked
 
+    def _pose_masked_rows(self, dt):
+        """what the hidden pose-MLP layers give for a pair outside its image (attn row = 0): layer i's output row, computed by the
+        GEMM kernel itself on a one-row input so that rows of all-masked tiles (broadcast) and masked rows inside computed tiles
+        agree bit for bit.  Cached per weight version."""
+        f32 = torch.float32
+        layers = self.pose_embed.MLP.layers[:-1]
+        params = tuple(p for lin in layers for p in (lin.weight, lin.bias))
+
+        def build(*_):
+            rows, cur = [], torch.zeros((1, layers[0].weight.shape[1]), dtype=f32, device=layers[0].weight.device)
+            for lin in layers:
+                cur = ops.linear(cur, lin.weight.detach().to(f32).contiguous(), lin.bias.detach().to(f32).contiguous(), relu=True)
+                rows.append(cur[0])
+            return torch.stack(rows)
+        return self._w("pose_masked_rows", params, f32, build)
+
     def _chain_b_weights(self, dt):
         f32 = torch.float32
         sw = lambda w: ops.swizzle_weight(w.to(dt))
@@ -276,6 +294,9 @@ class DQDecoderLayer(MvPDecoderLayer):
             self.proj_attn.prepare_fast_path(dt)
         else:
             self.proj_attn.weights(dt)
+            if dt == torch.float32 and self.skip_masked_f32:
+                self._pose_masked_rows(dt)
+                self.proj_attn._wc.get("zero_row", (self.proj_attn.output_proj.bias,), torch.float32, lambda b: torch.zeros_like(b))
             if dt == torch.float32 and self.proj_attn.g_sampling_f32 is not False and \
                     self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192:
                 self.proj_attn._fast_query_weights(dt)      # the fp32 G-sampling branch of native_sample (Woa_perm / boa_perm)
@@ -435,7 +456,15 @@ class DQDecoderLayer(MvPDecoderLayer):
                 wts, o_masked = self._chain_a_weights(dt)
                 attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
-            attn = self.proj_attn.native_forward(x(), ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1))
+            # fp32 (reference arithmetic): the per-view output projection and pose MLP run over the pairs in processing order and
+            # skip the tiles whose pairs are all outside their image (their rows are zero / a cached constant either way).
+            # Worth 1.7 % at cfg-2 (41 % of the tiles skipped at layer 0, but the GEMM is power-limited: tiles of zero rows were
+            # cheap already); below 8192 tokens per image (cfg-4) the extra binning launch costs more than it saves.
+            order32 = None
+            if (dt == torch.float32 and self.skip_masked_f32 and C == 256 and 8192 <= Lq <= 65536
+                    and self.proj_attn.sort_pairs):
+                order32 = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
+            attn = self.proj_attn.native_forward(x(), ref_lvl, ctx.feat, ctx.levels, V, B, rowmask=inside.view(-1), order=order32)
 
         # 2.+3. update the query features (update_feature 'MLP', dq_decoder.py:763-778 + forward_ffn),
         #       class head + filter (dq_decoder.py:889-908)
@@ -483,9 +512,13 @@ class DQDecoderLayer(MvPDecoderLayer):
         # 4. 2D offsets from the per-view attention features (calculate_2d_offsets, dq_decoder.py:659-717)
         if o is None:
             hcur = attn
+            masked = self._pose_masked_rows(dt) if (not fuse_a and order32 is not None) else None
             for i, lin in enumerate(pose_layers[:-1]):
-                hcur = ops.linear(hcur, self._w("Wpe%d" % i, (lin.weight,), dt), self._w("bpe%d" % i, (lin.bias,), f32),
-                                  out_dtype=dt, relu=True)
+                Wi, bi = self._w("Wpe%d" % i, (lin.weight,), dt), self._w("bpe%d" % i, (lin.bias,), f32)
+                if masked is not None:
+                    hcur = ops.linear_ordered(hcur, Wi, bi, order32, inside.view(-1), masked[i], relu=True)
+                else:
+                    hcur = ops.linear(hcur, Wi, bi, out_dtype=dt, relu=True)
             o = ops.rowdot3(hcur, self._w("Wpe_last", (pose_layers[-1].weight,), f32),
                             self._w("bpe_last", (pose_layers[-1].bias,), f32))
 

@@ -253,6 +253,22 @@ def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None, add=N
     return out
 
 
+def linear_ordered(a, w, bias, order, inside, masked_row, relu=False, rowmask=None, out=None):
+    """fp32 ``linear`` over the rows in processing order ``order`` (mvg_linear_ordered): tiles without a row of ``inside`` write
+    ``masked_row`` (N,) to all their rows instead of computing them.  Rows keep their places in a / out."""
+    M, K = a.shape
+    N = w.shape[0]
+    if a.dtype != torch.float32 or w.dtype != torch.float32 or a.stride(1) != 1 or not w.is_contiguous():
+        raise RuntimeError("mvg_linear_ordered: fp32 K-contiguous operands required")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with _timed("linear_ordered_%dx%dx%d" % (M, N, K)):
+      L.check(L.load().mvg_linear_ordered(L.ptr(a), a.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), out.stride(0),
+                                        L.ptr(rowmask), 1 if relu else 0, M, N, K, L.ptr(order), L.ptr(inside),
+                                        L.ptr(masked_row), L.stream_ptr()), "mvg_linear_ordered")
+    return out
+
+
 def msda_fused(value, oa, r, levels):
     """r: per-level reference points (n_img, Lq, L, 2)."""
     n_img, S, Cc = value.shape

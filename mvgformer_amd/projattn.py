@@ -199,12 +199,16 @@ class ProjAttn(nn.Module):
         ops.value_proj_planes_ws(feat, Wv_f, bv, vp)
         return vp
 
-    def native_forward(self, x, r, feat, levels, V, B, rowmask=None):
+    def native_forward(self, x, r, feat, levels, V, B, rowmask=None, order=None):
         """Inference path on packed inputs.  x (B,Lq,C) f32 = tgt+query_pos; r (V*B,Lq,L,2) the
         per-level reference points; feat (V*B,S,C) channels-last pyramid in the compute dtype.
-        Returns (V*B*Lq, C)."""
-        samp = self.native_sample(x, r, feat, levels, V, B, pair_mask=rowmask)
+        Returns (V*B*Lq, C).  order (with rowmask, fp32): the pairs' processing order (ops.bin_pairs: masked pairs last) --
+        tiles of the output projection without an unmasked row are not computed (their rows are zero either way)."""
+        samp = self.native_sample(x, r, feat, levels, V, B, pair_mask=rowmask, order=order)
         _, _, _, _, Wp, bp = self.weights(feat.dtype)
+        if order is not None and rowmask is not None and feat.dtype == torch.float32:
+            zero = self._wc.get("zero_row", (self.output_proj.bias,), torch.float32, lambda b: torch.zeros_like(b))
+            return ops.linear_ordered(samp, Wp, bp, order, rowmask, zero, rowmask=rowmask)
         return ops.linear(samp, Wp, bp, out_dtype=feat.dtype, rowmask=rowmask)   # projattn.py:203 (+ dq_decoder.py:585)
 
     def uses_fast_path(self, dt):

@@ -68,6 +68,29 @@ def test_deform_forward_known_answers():
     assert float(y[0, 2].abs().max()) < 1e-5
 
 
+def test_linear_ordered_skips_masked_tiles_and_equals_the_plain_gemm():
+    """mvg_linear_ordered (fp32 path, round 3): rows visited in a processing order, tiles without an unmasked row broadcast the
+    cached constant row instead of computing -- bit-identical to the plain GEMM + row mask, for sorted and shuffled orders,
+    ragged sizes, ReLU, and a non-zero constant row (the pose MLP's hidden layers)."""
+    from mvgformer_amd import ops
+    rs = np.random.RandomState(11)
+    for M, frac, shuffled in ((5000, 0.4, False), (5000, 0.4, True), (129, 1.0, False), (777, 0.0, True), (20000, 0.7, False)):
+        a = torch.from_numpy(rs.standard_normal((M, 256)).astype(np.float32)).to(DEV)
+        w = torch.from_numpy((rs.standard_normal((256, 256)) / 16).astype(np.float32)).to(DEV)
+        b = torch.from_numpy(rs.standard_normal(256).astype(np.float32)).to(DEV)
+        perm = torch.from_numpy(rs.permutation(M) if shuffled else np.arange(M)).to(DEV)
+        inside = torch.ones(M, dtype=torch.uint8, device=DEV)
+        nm = int(M * frac)
+        if nm:
+            inside[perm[M - nm:]] = 0
+        a = a * inside[:, None].float()                                  # masked rows are zero rows (what the sampler writes)
+        order = perm.to(torch.int32)
+        zero = torch.zeros(256, device=DEV)
+        assert torch.equal(ops.linear_ordered(a, w, b, order, inside, zero, rowmask=inside), ops.linear(a, w, b, rowmask=inside))
+        const = ops.linear(torch.zeros(1, 256, device=DEV), w, b, relu=True)[0]          # a zero row through the same kernel
+        assert torch.equal(ops.linear_ordered(a, w, b, order, inside, const, relu=True), ops.linear(a, w, b, relu=True))
+
+
 def test_deform_forward_bf16_and_ragged_batch():
     from mvgformer_amd import deformable
     c = {k: v.to(DEV) for k, v in msda_case("small_f32").items()}
