@@ -664,21 +664,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 }
 
 // msda_gsamp_win_kernel (round 3; VERDICT r2 item 4, the north_star's "LDS staging of sampling windows"): the same work
-// decomposition and arithmetic as msda_gsamp_kernel, plus one LDS window per workgroup for the COARSEST level.  The 64 pairs of a
-// workgroup are neighbours in the image (Morton order), so their coarsest-level samples fall into a small rectangle of the
-// (image, head) plane: bounding box of the pairs' reference pixels, centred in a GSAMP_WIN x GSAMP_WIN window (16 x 16 pixels x 64 B
-// at an 80-byte pitch = 20 KB next to the 20 KB of quad scratch: still four workgroups per CU).  Samples whose 2 x 2 footprint
-// is inside the window are read with ds_read_b128, the others gathered from global memory: bit-identical results.
+// decomposition and arithmetic as msda_gsamp_kernel plus one LDS window per workgroup for the COARSEST level: a GSAMP_WIN x GSAMP_WIN
+// rectangle of the (image, head) plane (16 x 16 pixels x 64 B at an 80-byte pitch = 20 KB next to the 20 KB of quad scratch: still
+// four workgroups per CU); samples whose 2 x 2 footprint is inside it are read with ds_read_b128, the others gathered from global
+// memory -- bit-identical results.  (A first form with a bounding-box pass, three barriers and the staging waited for up front was
+// 35 us per launch slower than the plain kernel; this one is 7.)  The window is centred on the reference pixel of the workgroup's FIRST slot (read by every wavefront itself:
+// no exchange; the 64 pairs of a workgroup are Morton neighbours), its 16 KB are requested before anything else and parked in
+// LDS right after the wavefront's own phase-A loads have returned (in-order vmcnt: they have arrived by then), the levels above
+// the coarsest run the plain loop, and ONE barrier sits in front of the coarsest level's two batches.
 template <int L, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void msda_gsamp_win_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
-                                                            const float* __restrict__ xw, const float* __restrict__ r,
-                                                            LevelTable lv, bf16_t* __restrict__ samp,
-                                                            const uint8_t* __restrict__ pair_mask, const int* __restrict__ order,
-                                                            int n_pairs, int Lq, int S, int B, int map_ch) {
+__global__ __launch_bounds__(NT) void msda_gsamp_win_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
+                                                             const float* __restrict__ xw, const float* __restrict__ r,
+                                                             LevelTable lv, bf16_t* __restrict__ samp,
+                                                             const uint8_t* __restrict__ pair_mask, const int* __restrict__ order,
+                                                             int n_pairs, int Lq, int S, int B, int map_ch) {
   constexpr int SCP = 3 * L * 8 + 8;
+  constexpr int NST = GSAMP_WIN * GSAMP_WIN * 4 / NT;       // staged 16-byte chunks per thread (4 at 256 threads)
+  static_assert(GSAMP_WIN * GSAMP_WIN * 4 % NT == 0, "whole passes of the workgroup");
   __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
   __shared__ __attribute__((aligned(16))) unsigned char winbuf[GSAMP_WIN * GSAMP_WIN * GSAMP_WIN_PITCH];
-  __shared__ int bbox[5];                                   // min x, min y, max x, max y (coarsest-level pixels), min image
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane & 3, pl = lane >> 2;
   int m, pblk;
@@ -691,52 +695,69 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int t = j >> 3;
     pblk = ((t / map_ch) * 8 + xcd) * map_ch + t % map_ch;
   }
-  if (threadIdx.x < 5) bbox[threadIdx.x] = threadIdx.x < 2 || threadIdx.x == 4 ? 0x7fffffff : -1;
-  const int slot = pblk * (NT / 4) + wave * 16 + pl;
+  const int slot0 = pblk * (NT / 4);
+  if (slot0 >= n_pairs) return;                              // uniform: nothing in this workgroup
+  const int slot = slot0 + wave * 16 + pl;
   const bool in_range = slot < n_pairs;
   const int pair = in_range ? (order ? order[slot] : slot) : 0;
   const bool act = in_range && !(pair_mask && !pair_mask[pair]);
   if (in_range && !act) *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
+  // window: coarsest level, centred on the first slot's reference pixel (uniform over the workgroup)
   constexpr int lw = L - 1;
   const int Hc = lv.H[lw], Wc = lv.W[lw];
-  const int n = pair / Lq;
-  __syncthreads();
-  if (act && sub == 0) {
-    const float2 rr = *reinterpret_cast<const float2*>(r + ((long)pair * L + lw) * 2);
-    const int px = min(max((int)floorf(index_safe(rr.x * (float)Wc - 0.5f, (float)Wc)), 0), Wc - 1);
-    const int py = min(max((int)floorf(index_safe(rr.y * (float)Hc - 0.5f, (float)Hc)), 0), Hc - 1);
-    atomicMin(&bbox[0], px);
-    atomicMin(&bbox[1], py);
-    atomicMax(&bbox[2], px);
-    atomicMax(&bbox[3], py);
-    atomicMin(&bbox[4], n);
+  const int pair0 = order ? order[slot0] : slot0;
+  if (pair_mask && !pair_mask[pair0]) {                      // masked pairs come last: the whole workgroup is (almost always) masked
+    if (!act) return;                                        // no window for the few that are not: plain path below
   }
-  __syncthreads();
-  if (bbox[2] < 0) return;                                  // no pair of this workgroup samples anything (uniform)
   GsampWin w;
   w.wx = min(GSAMP_WIN, Wc);
   w.wy = min(GSAMP_WIN, Hc);
-  w.n = bbox[4];
-  // the window is centred on the bounding box of the reference pixels (of all images the workgroup touches: a workgroup
-  // spans two images only at an image boundary of the processing order, and only the first image's pairs use the window)
-  w.x0 = min(max((bbox[0] + bbox[2] + 1) / 2 - (w.wx / 2 - 1), 0), Wc - w.wx);
-  w.y0 = min(max((bbox[1] + bbox[3] + 1) / 2 - (w.wy / 2 - 1), 0), Hc - w.wy);
-  w.base = (lds_bytes_t)winbuf;
+  w.n = pair0 / Lq;
   {
-    // stage: 4 chunks of 16 B per pixel, consecutive threads -> consecutive chunks of a window row (wx * 64 contiguous bytes)
-    const char* plane = reinterpret_cast<const char*>(vp) + (((long)w.n * 8 + m) * S + lv.start[lw]) * 64;
-    const int nchunk = w.wx * w.wy * 4;
-    for (int i = threadIdx.x; i < nchunk; i += NT) {
-      const int c = i & 3, p = i >> 2;
-      const int y = p / w.wx, x = p - y * w.wx;
-      const uint4 v = *reinterpret_cast<const uint4*>(plane + ((long)(w.y0 + y) * Wc + (w.x0 + x)) * 64 + c * 16);
-      *reinterpret_cast<uint4*>(&winbuf[p * GSAMP_WIN_PITCH + c * 16]) = v;
-    }
+    const float2 rr = *reinterpret_cast<const float2*>(r + ((long)pair0 * L + lw) * 2);
+    const int px = min(max((int)floorf(index_safe(rr.x * (float)Wc - 0.5f, (float)Wc)), 0), Wc - 1);
+    const int py = min(max((int)floorf(index_safe(rr.y * (float)Hc - 0.5f, (float)Hc)), 0), Hc - 1);
+    w.x0 = min(max(px - (w.wx / 2 - 1), 0), Wc - w.wx);
+    w.y0 = min(max(py - (w.wy / 2 - 1), 0), Hc - w.wy);
   }
-  __syncthreads();
+  w.base = (lds_bytes_t)winbuf;
+  const bool use_win = !(pair_mask && !pair_mask[pair0]);    // uniform
+  // staging loads first (NST x 16 B per thread, consecutive threads -> consecutive chunks of a window row)
+  static_assert(NST == 4, "four staged chunks per thread, kept in named registers (an indexed array went to scratch)");
+  uint4 stg0 = uint4{0u, 0u, 0u, 0u}, stg1 = stg0, stg2 = stg0, stg3 = stg0;
+  const int nchunk = w.wx * w.wy * 4;
+  if (use_win) {
+    const char* plane = reinterpret_cast<const char*>(vp) + (((long)w.n * 8 + m) * S + lv.start[lw]) * 64;
+#define MVG_STG(K, DST)                                                                                   \
+    {                                                                                                     \
+      const int i = min((int)threadIdx.x + K * NT, nchunk - 1);                                           \
+      const int c = i & 3, p = i >> 2;                                                                    \
+      const int y = p / w.wx, x = p - y * w.wx;                                                           \
+      DST = *reinterpret_cast<const uint4*>(plane + ((long)(w.y0 + y) * Wc + (w.x0 + x)) * 64 + c * 16);  \
+    }
+    MVG_STG(0, stg0) MVG_STG(1, stg1) MVG_STG(2, stg2) MVG_STG(3, stg3)
+#undef MVG_STG
+  } else {
+    w.wx = 0;                                                // nothing is "inside" an empty window
+    w.wy = 0;
+  }
+  float acc[8], mx = 0.f;
+  unsigned cw_t = 0, cw_b = 0, co_t = 0, co_b = 0, co_x = 0, co_f = 0;
+  float* sc = &scratch[wave][pl][0];
+  if (act) mx = gsamp_prepare<L>(G, xw, r, lv, sc, pair, m, sub, Lq, S, B);
+  if (use_win) {
+#define MVG_STW(K, SRC)                                                                                   \
+    {                                                                                                     \
+      const int i = (int)threadIdx.x + K * NT;                                                            \
+      if (i < nchunk) *reinterpret_cast<uint4*>(&winbuf[(i >> 2) * GSAMP_WIN_PITCH + (i & 3) * 16]) = SRC; \
+    }
+    MVG_STW(0, stg0) MVG_STW(1, stg1) MVG_STW(2, stg2) MVG_STW(3, stg3)
+#undef MVG_STW
+  }
+  if (act) gsamp_plain_levels<L>(vp, lv, sc, pair, m, sub, Lq, S, w, acc, mx, cw_t, cw_b, co_t, co_b, co_x, co_f);
+  if (use_win) __syncthreads();
   if (!act) return;
-  float acc[8];
-  gsamp_unit<L, 2>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc, &w);
+  gsamp_window_level<L>(vp, lv, sc, pair, m, sub, Lq, S, w, acc, mx, cw_t, cw_b, co_t, co_b, co_x, co_f);
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
