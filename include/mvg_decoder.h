@@ -125,6 +125,10 @@ int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, co
 int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W,
                    int S, int start, void* stream);
 
+/* all L levels in one launch: src_nchw_host = HOST array of L device pointers to the (N_img,C,H_l,W_l) maps */
+int mvg_pack_pyramid(const float* const* src_nchw_host, void* feat, int dtype, int N_img, int C, const int64_t* shapes_host,
+                     const int64_t* starts_host, int L, int S, void* stream);
+
 /* A.1 + A.2 projection (dq_decoder.py:331-397,570-573; cameras.py:167-217): X (B,Lq,3) mm,
  * cams (V*B, MVG_CAM_STRIDE) -> r (V*B,Lq,2) normalised network-image coords,
  * ref_lvl (V*B,Lq,L,2) = r * (W_l,H_l)/(W_l-1,H_l-1), inside (V*B,Lq) uint8.

@@ -30,6 +30,7 @@ SIGNATURES = {
     "mvg_msda_forward_f64": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_backward_f64": [_vp] * 9 + [_i] * 7 + [_vp],
     "mvg_pack_level": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvg_pack_pyramid": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "mvg_project": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_gather_ref": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvg_linear": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],

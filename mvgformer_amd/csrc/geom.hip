@@ -9,11 +9,10 @@
 // pitch: conflict-free both ways): reads are 256-byte runs of one channel plane, writes 128-byte (bf16) /
 // 256-byte (fp32) runs of one pixel row, 4 channels per lane.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_level_kernel(const float* __restrict__ src, T* __restrict__ feat, int C,
-                                                         int HW, int S, int start) {
-  __shared__ float tile[64][65];
+__device__ __forceinline__ void pack_tile(const float* __restrict__ src, T* __restrict__ feat, int C, int HW, int S, int start,
+                                          int bx, float (&tile)[64][65]) {
   const int n = blockIdx.z, tid = threadIdx.x;
-  const int hw0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int hw0 = bx * 64, c0 = blockIdx.y * 64;
   const int tx = tid & 63, ty = tid >> 6;
   const float* sp = src + (long)n * C * HW;
   float v[16];
@@ -42,6 +41,29 @@ __global__ __launch_bounds__(256) void pack_level_kernel(const float* __restrict
       for (int k = 0; k < 4 && c + k < C; ++k) store1<T>(dst + k, a[k]);
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_level_kernel(const float* __restrict__ src, T* __restrict__ feat, int C,
+                                                         int HW, int S, int start) {
+  __shared__ float tile[64][65];
+  pack_tile<T>(src, feat, C, HW, S, start, blockIdx.x, tile);
+}
+
+// all levels of the pyramid in ONE launch (round 3): blockIdx.x walks the 64-pixel tiles of level 0, then level 1, ...
+struct PackLevels {
+  const float* src[MVG_MAX_LEVELS];
+  int hw[MVG_MAX_LEVELS], start[MVG_MAX_LEVELS], tile0[MVG_MAX_LEVELS + 1];
+  int L;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_pyramid_kernel(PackLevels pl, T* __restrict__ feat, int C, int S) {
+  __shared__ float tile[64][65];
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < MVG_MAX_LEVELS; ++k)
+    if (k < pl.L && (int)blockIdx.x >= pl.tile0[k]) l = k;
+  pack_tile<T>(pl.src[l], feat, C, pl.hw[l], S, pl.start[l], (int)blockIdx.x - pl.tile0[l], tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -779,6 +801,34 @@ int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int 
     hipLaunchKernelGGL((pack_level_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src_nchw, (float*)feat, C, HW, S, start);
   else if (dtype == MVG_BF16)
     hipLaunchKernelGGL((pack_level_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, src_nchw, (bf16_t*)feat, C, HW, S, start);
+  else
+    return MVG_E_BADARG;
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_pack_pyramid(const float* const* src_nchw_host, void* feat, int dtype, int N_img, int C, const int64_t* shapes_host,
+                     const int64_t* starts_host, int L, int S, void* stream) {
+  if (!src_nchw_host || !feat || !shapes_host || !starts_host || N_img <= 0 || C <= 0 || L < 1 || L > MVG_MAX_LEVELS)
+    return MVG_E_BADARG;
+  PackLevels pl;
+  pl.L = L;
+  int t = 0;
+  for (int l = 0; l < L; ++l) {
+    const long hw = (long)shapes_host[2 * l] * shapes_host[2 * l + 1];
+    if (!src_nchw_host[l] || hw <= 0 || starts_host[l] < 0 || starts_host[l] + hw > S) return MVG_E_BADARG;
+    pl.src[l] = src_nchw_host[l];
+    pl.hw[l] = (int)hw;
+    pl.start[l] = (int)starts_host[l];
+    pl.tile0[l] = t;
+    t += (int)((hw + 63) / 64);
+  }
+  pl.tile0[L] = t;
+  dim3 grid(t, (C + 63) / 64, N_img);
+  if (dtype == MVG_F32)
+    hipLaunchKernelGGL((pack_pyramid_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, pl, (float*)feat, C, S);
+  else if (dtype == MVG_BF16)
+    hipLaunchKernelGGL((pack_pyramid_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, pl, (bf16_t*)feat, C, S);
   else
     return MVG_E_BADARG;
   MVG_LAUNCH_CHECK();

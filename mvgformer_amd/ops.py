@@ -16,6 +16,8 @@ from . import _lib as L
 # fp32-atomics form of round 1 (the reference's own scheme)
 BACKWARD_MODE = __import__("os").environ.get("MVG_BACKWARD", "det")
 
+ONE_LAUNCH_PACK = __import__("os").environ.get("MVG_ONE_LAUNCH_PACK", "1") != "0"
+
 # ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) -----
 PROFILE = None   # None (off) or dict name -> list[(start_event, end_event)]
 
@@ -192,6 +194,15 @@ def pack_pyramid(src_views, levels, dtype, out=None):
     if tuple(feat.shape) != (n_img, levels.S, Cc) or feat.dtype != dtype or not feat.is_contiguous():
         raise RuntimeError("pack_pyramid: out must be a contiguous (%d,%d,%d) %s tensor" % (n_img, levels.S, Cc, dtype))
     dst_views = pyramid_level_views(feat, levels)
+    if (ONE_LAUNCH_PACK and all(s.dtype == torch.float32 and s.is_contiguous() and s.is_cuda and tuple(s.shape) ==
+                                (n_img, Cc, int(levels.shapes[l, 0]), int(levels.shapes[l, 1])) and s.data_ptr() != dst_views[l].data_ptr()
+                                for l, s in enumerate(src_views)) and len(src_views) == levels.L):
+        # the reference's hand-over format on every level: one launch for the whole pyramid
+        ptrs = (C.c_void_p * levels.L)(*[s.data_ptr() for s in src_views])
+        with _timed("pack_level"):
+            L.check(lib.mvg_pack_pyramid(ptrs, L.ptr(feat), L.dtype_code(dtype), n_img, Cc, levels.shapes_c, levels.starts_c,
+                                         levels.L, levels.S, L.stream_ptr()), "mvg_pack_pyramid")
+        return feat
     for l, src in enumerate(src_views):
         L.require_cuda(src)
         H, W = int(levels.shapes[l, 0]), int(levels.shapes[l, 1])
