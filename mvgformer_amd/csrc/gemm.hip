@@ -5,6 +5,11 @@
 // A is activations (row-major, K contiguous), W an nn.Linear weight (row-major (N,K), K
 // contiguous) -- both operands are "K-major", so both are staged the same way.
 //   fp32 compute : v_mfma_f32_32x32x2_f32   (exact fp32 fmaf chain; 157 TF peak)
+//   fp32 "split" : every fp32 operand value x = h + m + l with h, m, l bf16 (round-to-nearest at each step: 8 + 8 + 8 significand
+//                  bits, exact), the product as the six bf16 MFMAs  h*h + h*m + m*h + m*m + h*l + l*h  accumulated in fp32
+//                  (the three dropped terms are below 2^-25 |a b|, under the rounding of one fp32 product): 6 x 32 cycles of
+//                  v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 x 64 cycles of 32x32x2_f32 -- gfx950 has no tf32 / xf32.
+//                  Knob "f32_split" (mvg_set_tuning); the split happens when a tile is staged (5.5 VALU per value).
 //   bf16 compute : v_mfma_f32_32x32x16_bf16 (fp32 accumulate; 2.5 PF peak)
 // Tile 128x128 per 256-thread workgroup (4 wavefronts as 2x2, 64x64 per wavefront = 2x2 MFMA
 // tiles, 64 accumulator registers).  K is consumed in slabs of 128 BYTES per row (32 fp32 or
@@ -17,11 +22,22 @@
 // Global->register prefetch of slab t+1 overlaps the MFMAs of slab t.
 #include "common.h"
 
+#include <type_traits>
+
 int g_linear_tiles = 1;     // tuning knob "linear_tiles": 0 = always 128 x 128 tiles (rounds 1-2)
+int g_f32_split = 0;        // tuning knob "f32_split": 1 = fp32 GEMMs as six bf16 MFMAs on 3-way split operands (see above)
 
 namespace {
 
 constexpr int PITCH = 144;   // bytes per LDS row (128 data + 16 pad)
+// split form: a row of the slab is [32 x h | 32 x m | 32 x l] bf16 = 3 x 64 bytes, no padding; the four 16-byte slots of a
+// plane are permuted by bits 2-3 of the row (slot ^ ((row >> 2) & 3)).  Reads: the 16 rows of a ds_read_b128 lane group start
+// at slot columns 12 r mod 16 = {0, 12, 8, 4} repeating every 4 rows, and the permutation moves each group of 4 rows to a
+// different slot: 16 distinct slots.  Writes: a half wavefront's ds_write_b64 covers 4 rows x 64 contiguous bytes at 48 r
+// dwords = {0, 48, 32, 16}: disjoint banks.  (A padded 208-byte pitch was read conflict-free but cost 31 % bank-conflict
+// cycles on the 8-byte writes.)
+constexpr int SPITCH = 192;
+__device__ __forceinline__ int split_slot(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 16; }
 // Tile shapes (round 3): 128 x 128 (default), 128 x 192 for N = 192 (the [offsets | logits] projections: two 128-column tiles
 // left a quarter of the MFMAs on padding), 64 x 128 when 128-row tiles would not give every CU a workgroup (the FFN's second
 // GEMM at 7 680 rows: 120 workgroups on 256 CUs).  Always 4 wavefronts as 2 x 2; a wavefront owns (BM/2) x (BN/2).
@@ -30,23 +46,22 @@ struct Chunk {
   f32x4 lo, hi;   // hi only used when converting an fp32 source to bf16 (8 values)
 };
 
-// load one 16-byte LDS chunk worth of K-values for (row, col16) of the current slab
+// load one 16-byte LDS chunk worth of K-values for (row, col16) of the current slab.  Rows past the end of the tile are read
+// from the tile's last row (an unconditional load -- no exec-mask region per chunk): row i of A only reaches row i of the
+// product and row j of W only column j, and the epilogue stores neither.
 template <typename TSRC, bool BF16>
 __device__ __forceinline__ Chunk load_chunk(const TSRC* __restrict__ base, long ld, int row, int nrows, int k0,
                                             int col16) {
   Chunk c;
-  c.lo = f32x4{0.f, 0.f, 0.f, 0.f};
-  c.hi = c.lo;
-  if (row < nrows) {
-    if constexpr (!BF16) {
-      c.lo = *reinterpret_cast<const f32x4*>(base + (long)row * ld + k0 + col16 * 4);
-    } else if constexpr (sizeof(TSRC) == 2) {
-      c.lo = *reinterpret_cast<const f32x4*>(base + (long)row * ld + k0 + col16 * 8);   // 8 bf16 = 16 B, raw
-    } else {
-      const TSRC* p = base + (long)row * ld + k0 + col16 * 8;
-      c.lo = *reinterpret_cast<const f32x4*>(p);
-      c.hi = *reinterpret_cast<const f32x4*>(p + 4);
-    }
+  c.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  const TSRC* p = base + (long)min(row, nrows - 1) * ld + k0;
+  if constexpr (!BF16) {
+    c.lo = *reinterpret_cast<const f32x4*>(p + col16 * 4);
+  } else if constexpr (sizeof(TSRC) == 2) {
+    c.lo = *reinterpret_cast<const f32x4*>(p + col16 * 8);   // 8 bf16 = 16 B, raw
+  } else {
+    c.lo = *reinterpret_cast<const f32x4*>(p + col16 * 8);
+    c.hi = *reinterpret_cast<const f32x4*>(p + col16 * 8 + 4);
   }
   return c;
 }
@@ -65,13 +80,32 @@ __device__ __forceinline__ void store_chunk(char* lds, int row, int col16, const
   *reinterpret_cast<f32x4*>(lds + row * PITCH + col16 * 16) = v;
 }
 
+// split form: 4 fp32 values -> their h / m / l bf16 parts, 8 bytes each into the row's three planes
+__device__ __forceinline__ void store_chunk_split(char* lds, int row, int col16, const f32x4& x) {
+  uint2 p[3];
+  f32x4 r = x;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    p[s].x = pack_bf16(r[0], r[1]);
+    p[s].y = pack_bf16(r[2], r[3]);
+    if (s < 2) {
+      r[0] -= __uint_as_float(p[s].x << 16);
+      r[1] -= __uint_as_float(p[s].x & 0xffff0000u);
+      r[2] -= __uint_as_float(p[s].y << 16);
+      r[3] -= __uint_as_float(p[s].y & 0xffff0000u);
+    }
+    *reinterpret_cast<uint2*>(lds + row * SPITCH + 64 * s + split_slot(row, col16 >> 1) + (col16 & 1) * 8) = p[s];
+  }
+}
+
 // TA: storage type of A in global memory; BF16: compute type; TW = BF16 ? bf16 : float; TO: output storage
 // IDX (round 3, fp32 path): tile row i works on global row order[m0 + i] of A / out (the sampler's processing order: rows whose
 // reference point is outside the image come last, mvg_bin_pairs).  A tile without a single row of `inside` does no arithmetic: all
 // of its output rows equal `masked_row` (N floats: what this very kernel computes for such a row -- zeros behind a row mask,
 // act(bias) for a zero input row, a cached constant further down a chain), which it broadcasts and leaves.
-template <typename TA, bool BF16, typename TO, int BM = 128, int BN = 128, bool IDX = false>
-__global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
+// SPLIT (fp32 operands only): the split form described at the top of the file.
+template <typename TA, bool BF16, typename TO, int BM = 128, int BN = 128, bool IDX = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ A2, long lda,
                                                      const void* __restrict__ Wv,
                                                      const float* __restrict__ bias, TO* __restrict__ out, long ldc,
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
@@ -83,10 +117,12 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const T
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NJ = WN / 32;      // per-wavefront tile and its 32 x 32 MFMA blocks
   constexpr int EPB = (int)sizeof(TO) * BN + 16;                           // epilogue staging pitch (bytes)
-  constexpr int LDS_BYTES = (BM + BN) * PITCH > 64 * EPB ? (BM + BN) * PITCH : 64 * EPB;
+  static_assert(!SPLIT || (!BF16 && sizeof(TA) == 4), "the split form takes fp32 operands");
+  constexpr int RP = SPLIT ? SPITCH : PITCH;                               // LDS row pitch of the staged slab
+  constexpr int LDS_BYTES = (BM + BN) * RP > 64 * EPB ? (BM + BN) * RP : 64 * EPB;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* ldsA = lds;
-  char* ldsB = lds + BM * PITCH;
+  char* ldsB = lds + BM * RP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -134,78 +170,141 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : 1)) void linear_kernel(const T
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   constexpr int NCA = BM / 32, NCB = BN / 32;          // 16-byte chunks per thread and slab (a tile row = 8 chunks)
-  Chunk ca[NCA], cb[NCB];
-  auto gload = [&](int k0) {
+  // register buffers for slabs in flight: one (the next slab) for the plain forms; two for the split form, whose MFMA phase per
+  // slab (6 x 32 cycles per block) is shorter than a round trip to memory
+  constexpr int NBUF = 1;     // 2: measured slower (222 registers + 64 accumulators: one wavefront per SIMD, or spills under a cap)
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, NBUF - 1>;
+  Chunk ca[NBUF][NCA], cb[NBUF][NCB];
+  auto gload = [&](auto bi, int k0) {
+    constexpr int BI = decltype(bi)::value;
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
-      if constexpr (IDX) {            // row pointer through the processing order; rows past the end read as zeros
+      if constexpr (IDX) {            // row pointer through the processing order; slots past the end read row order[..] = 0
         const int g = rid[c >> 3];
-        ca[i] = load_chunk<TA, BF16>(A + (long)max(g, 0) * lda, lda, 0, g >= 0 ? 1 : 0, k0, c & 7);
+        ca[BI][i] = load_chunk<TA, BF16>(A + (long)max(g, 0) * lda, lda, 0, 1, k0, c & 7);
       } else {
-        ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
+        ca[BI][i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
       }
       if constexpr (sizeof(TA) == 4) {
         if (A2b) {
           const Chunk c2 = load_chunk<TA, BF16>(A2b, lda, c >> 3, mrows, k0, c & 7);
-          ca[i].lo += c2.lo;
-          ca[i].hi += c2.hi;
+          ca[BI][i].lo += c2.lo;
+          ca[BI][i].hi += c2.hi;
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int c = tid + 256 * i;
-      cb[i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
+      cb[BI][i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](auto bi) {
+    constexpr int BI = decltype(bi)::value;
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
-      store_chunk<TA, BF16>(ldsA, c >> 3, c & 7, ca[i]);
+      if constexpr (SPLIT) store_chunk_split(ldsA, c >> 3, c & 7, ca[BI][i].lo);
+      else store_chunk<TA, BF16>(ldsA, c >> 3, c & 7, ca[BI][i]);
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int c = tid + 256 * i;
-      store_chunk<TW, BF16>(ldsB, c >> 3, c & 7, cb[i]);
+      if constexpr (SPLIT) store_chunk_split(ldsB, c >> 3, c & 7, cb[BI][i].lo);
+      else store_chunk<TW, BF16>(ldsB, c >> 3, c & 7, cb[BI][i]);
     }
   };
 
   const int nk = K / KSLAB;
-  gload(0);
-  lstore();
-  __syncthreads();
   const int rl = lane & 31, h = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * KSLAB);
+  // the MFMAs of the slab staged in LDS
+  auto compute = [&]() {
+    if constexpr (SPLIT) {
+      // 32 k per slab = 2 MFMA k-steps; lane (rl, h) holds k = 16 g + 8 h .. + 7 of its row in each of the three planes
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a[MI], b[NJ];
+      for (int g = 0; g < 2; ++g) {
+        bf16x8 a[MI][3], b[NJ][3];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(ldsA + (wm * WM + i * 32 + rl) * PITCH + 32 * g + 16 * h);
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(ldsB + (wn * WN + j * 32 + rl) * PITCH + 32 * g + 16 * h);
-      // D' = W_tile * A_tile^T: the MFMA "row" index (registers) runs over output COLUMNS n, the
-      // lane index over output ROWS m, so a lane ends up with groups of 4 consecutive n.
+          for (int i = 0; i < MI; ++i)
+            a[i][s] = *reinterpret_cast<const bf16x8*>(ldsA + (wm * WM + i * 32 + rl) * SPITCH + 64 * s + split_slot(rl, 2 * g + h));
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if constexpr (BF16) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
-                                                                __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][t], a[i][t], acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < NJ; ++j)
+            b[j][s] = *reinterpret_cast<const bf16x8*>(ldsB + (wn * WN + j * 32 + rl) * SPITCH + 64 * s + split_slot(rl, 2 * g + h));
         }
+        // smallest terms first; (plane of W, plane of A)
+        constexpr int TB[6] = {2, 0, 1, 1, 0, 0}, TA_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][TB[t]], a[i][TA_[t]], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a[MI], b[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(ldsA + (wm * WM + i * 32 + rl) * PITCH + 32 * g + 16 * h);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(ldsB + (wn * WN + j * 32 + rl) * PITCH + 32 * g + 16 * h);
+        // D' = W_tile * A_tile^T: the MFMA "row" index (registers) runs over output COLUMNS n, the
+        // lane index over output ROWS m, so a lane ends up with groups of 4 consecutive n.
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if constexpr (BF16) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]),
+                                                                  __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][t], a[i][t], acc[i][j], 0, 0, 0);
+            }
+          }
+      }
     }
+  };
+
+  if constexpr (NBUF == 2) {
+    // slab kt in LDS, slabs kt + 1 and kt + 2 in flight (buffers alternate)
+    gload(B0{}, 0);
+    if (nk > 1) gload(B1{}, KSLAB);
+    lstore(B0{});
     __syncthreads();
-    if (kt + 1 < nk) {
-      lstore();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) gload(B0{}, (kt + 2) * KSLAB);
+      compute();
       __syncthreads();
+      if (kt + 1 >= nk) break;
+      lstore(B1{});
+      __syncthreads();
+      if (kt + 3 < nk) gload(B1{}, (kt + 3) * KSLAB);
+      compute();
+      __syncthreads();
+      if (kt + 2 < nk) {
+        lstore(B0{});
+        __syncthreads();
+      }
+    }
+  } else {
+    gload(B0{}, 0);
+    lstore(B0{});
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload(B0{}, (kt + 1) * KSLAB);
+      compute();
+      __syncthreads();
+      if (kt + 1 < nk) {
+        lstore(B0{});
+        __syncthreads();
+      }
     }
   }
 
@@ -265,6 +364,14 @@ template <typename TA, bool BF16, typename TO, int BM, int BN>
 int launch_linear_tile(const void* A, const void* A2, long lda, const void* W, const float* bias, void* out, long ldc,
                        const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+  if constexpr (!BF16 && sizeof(TA) == 4) {
+    if (g_f32_split) {
+      hipLaunchKernelGGL((linear_kernel<TA, false, TO, BM, BN, false, true>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2,
+                         lda, W, bias, (TO*)out, ldc, rowmask, relu, M, N, K);
+      MVG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, BM, BN>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2, lda, W, bias,
                      (TO*)out, ldc, rowmask, relu, M, N, K);
   MVG_LAUNCH_CHECK();
@@ -277,6 +384,12 @@ int launch_linear_idx(const float* A, long lda, const float* W, const float* bia
                       int relu, int M, int N, int K, const int* order, const uint8_t* inside, const float* masked_row,
                       hipStream_t st) {
   dim3 grid((N + 127) / 128, (M + BM - 1) / BM);
+  if (g_f32_split) {
+    hipLaunchKernelGGL((linear_kernel<float, false, float, BM, 128, true, true>), grid, dim3(256), 0, st, A, (const float*)nullptr,
+                       lda, (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row);
+    MVG_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL((linear_kernel<float, false, float, BM, 128, true>), grid, dim3(256), 0, st, A, (const float*)nullptr, lda,
                      (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row);
   MVG_LAUNCH_CHECK();
