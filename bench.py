@@ -148,6 +148,10 @@ def main():
                          "(SURVEY 8(d); ~1/3 of the (view, query) pairs project outside their image and are skipped); all = the "
                          "grid shrunk to 30 %% of the space so that > 99 %% of the pairs are inside every view (nothing skipped: "
                          "the regime of a trained model's later layers)")
+    ap.add_argument("--f32-gemm", default="split", choices=["split", "exact"],
+                    help="--dtype fp32 only: split = every fp32 operand value as three bf16 parts, six v_mfma_f32_32x32x16_bf16 "
+                         "products per 16 k, fp32 accumulation (error against fp64 not above the exact form's, "
+                         "profiles/r03_f32_split_gemm.txt); exact = v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -188,6 +192,7 @@ def main():
     from mvgformer_amd.synthetic import build_case
 
     arch, cus = _lib.device_info()
+    _lib.check(_lib.load().mvg_set_tuning(b"f32_split", 1 if args.f32_gemm == "split" else 0), "mvg_set_tuning(f32_split)")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     elem = 2 if args.dtype == "bf16" else 4
     thr = 0.1
@@ -433,7 +438,7 @@ def main():
                     break
         if traffic is None and mode == "live":
             tail = ["--config", args.config, "--dtype", args.dtype, "--producer", args.producer, "--cpu-baseline", "0",
-                    "--inside", args.inside]
+                    "--inside", args.inside, "--f32-gemm", args.f32_gemm]
             if args.queries is not None:
                 tail += ["--queries", str(args.queries)]
             if args.valid_fraction is not None:
@@ -529,6 +534,9 @@ def main():
                    "initial_poses": {"grid": "'sample_space' grid over the whole space (SURVEY 8(d))",
                                      "all": "grid over 30 % of the space: > 99 % of the (view, query) pairs inside their image"}[args.inside],
                    "samples_in_flight": args.inflight,
+                   **({"fp32_gemm": {"split": "operands split into 3 bf16 parts, 6 bf16 MFMA products, fp32 accumulate",
+                                     "exact": "v_mfma_f32_32x32x2_f32 (fmaf chain)"}[args.f32_gemm]}
+                      if args.dtype == "fp32" else {}),
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
         "roofline": roof, "cpu_baseline": cpu, "rank_time_split": split, "kernels": kern,
     }

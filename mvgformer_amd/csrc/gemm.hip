@@ -22,10 +22,9 @@
 // Global->register prefetch of slab t+1 overlaps the MFMAs of slab t.
 #include "common.h"
 
-#include <type_traits>
-
 int g_linear_tiles = 1;     // tuning knob "linear_tiles": 0 = always 128 x 128 tiles (rounds 1-2)
-int g_f32_split = 0;        // tuning knob "f32_split": 1 = fp32 GEMMs as six bf16 MFMAs on 3-way split operands (see above)
+int g_linear_xcd = 1;       // tuning knob "linear_xcd": 1 = the column tiles of one row tile run on the same XCD (shared L2)
+int g_f32_split = 1;        // tuning knob "f32_split": 1 = fp32 GEMMs as six bf16 MFMAs on 3-way split operands (see above)
 
 namespace {
 
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
                                                      int K, const int* __restrict__ order = nullptr,
                                                      const uint8_t* __restrict__ inside = nullptr,
-                                                     const float* __restrict__ masked_row = nullptr) {
+                                                     const float* __restrict__ masked_row = nullptr, int xcd_map = 0) {
   using TW = typename std::conditional<BF16, bf16_t, float>::type;
   const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
@@ -126,7 +125,18 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Workgroups go to the 8 XCDs round-robin by linear id, and every XCD has its own L2: with the plain (x = column tile) order
+  // the column tiles of one row tile land on different XCDs and each fetches the same rows of A from HBM.  xcd_map: ids
+  // i, i + 8, i + 16, ... (same XCD, dispatched back to back) are the column tiles of one row tile.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_map) {
+    const int NT = gridDim.x, MT = gridDim.y, id = by * NT + bx;
+    const int group = id / (8 * NT), within = id - group * 8 * NT;
+    const int R = min(8, MT - group * 8);                   // row tiles of this group (the last group may be partial)
+    bx = within / R;
+    by = group * 8 + (within - bx * R);
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const TA* Ab = A + (long)m0 * lda;
   const TA* A2b = A2 ? A2 + (long)m0 * lda : nullptr;      // optional addend (fp32 storage only): A + A2 formed on load
   const TW* Wb = W + (long)n0 * K;
@@ -170,50 +180,45 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   constexpr int NCA = BM / 32, NCB = BN / 32;          // 16-byte chunks per thread and slab (a tile row = 8 chunks)
-  // register buffers for slabs in flight: one (the next slab) for the plain forms; two for the split form, whose MFMA phase per
-  // slab (6 x 32 cycles per block) is shorter than a round trip to memory
-  constexpr int NBUF = 1;     // 2: measured slower (222 registers + 64 accumulators: one wavefront per SIMD, or spills under a cap)
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, NBUF - 1>;
-  Chunk ca[NBUF][NCA], cb[NBUF][NCB];
-  auto gload = [&](auto bi, int k0) {
-    constexpr int BI = decltype(bi)::value;
+  // one slab in flight in registers (two, for the split form, measured slower: 222 registers + 64 accumulators leave one
+  // wavefront per SIMD, or spill under a cap; the loop does not wait on memory -- profiles/r03_experiments.txt)
+  Chunk ca[NCA], cb[NCB];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
       if constexpr (IDX) {            // row pointer through the processing order; slots past the end read row order[..] = 0
         const int g = rid[c >> 3];
-        ca[BI][i] = load_chunk<TA, BF16>(A + (long)max(g, 0) * lda, lda, 0, 1, k0, c & 7);
+        ca[i] = load_chunk<TA, BF16>(A + (long)max(g, 0) * lda, lda, 0, 1, k0, c & 7);
       } else {
-        ca[BI][i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
+        ca[i] = load_chunk<TA, BF16>(Ab, lda, c >> 3, mrows, k0, c & 7);
       }
       if constexpr (sizeof(TA) == 4) {
         if (A2b) {
           const Chunk c2 = load_chunk<TA, BF16>(A2b, lda, c >> 3, mrows, k0, c & 7);
-          ca[BI][i].lo += c2.lo;
-          ca[BI][i].hi += c2.hi;
+          ca[i].lo += c2.lo;
+          ca[i].hi += c2.hi;
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int c = tid + 256 * i;
-      cb[BI][i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
+      cb[i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
     }
   };
-  auto lstore = [&](auto bi) {
-    constexpr int BI = decltype(bi)::value;
+  auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
       const int c = tid + 256 * i;
-      if constexpr (SPLIT) store_chunk_split(ldsA, c >> 3, c & 7, ca[BI][i].lo);
-      else store_chunk<TA, BF16>(ldsA, c >> 3, c & 7, ca[BI][i]);
+      if constexpr (SPLIT) store_chunk_split(ldsA, c >> 3, c & 7, ca[i].lo);
+      else store_chunk<TA, BF16>(ldsA, c >> 3, c & 7, ca[i]);
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int c = tid + 256 * i;
-      if constexpr (SPLIT) store_chunk_split(ldsB, c >> 3, c & 7, cb[BI][i].lo);
-      else store_chunk<TW, BF16>(ldsB, c >> 3, c & 7, cb[BI][i]);
+      if constexpr (SPLIT) store_chunk_split(ldsB, c >> 3, c & 7, cb[i].lo);
+      else store_chunk<TW, BF16>(ldsB, c >> 3, c & 7, cb[i]);
     }
   };
 
@@ -272,39 +277,16 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
     }
   };
 
-  if constexpr (NBUF == 2) {
-    // slab kt in LDS, slabs kt + 1 and kt + 2 in flight (buffers alternate)
-    gload(B0{}, 0);
-    if (nk > 1) gload(B1{}, KSLAB);
-    lstore(B0{});
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * KSLAB);
+    compute();
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) gload(B0{}, (kt + 2) * KSLAB);
-      compute();
+    if (kt + 1 < nk) {
+      lstore();
       __syncthreads();
-      if (kt + 1 >= nk) break;
-      lstore(B1{});
-      __syncthreads();
-      if (kt + 3 < nk) gload(B1{}, (kt + 3) * KSLAB);
-      compute();
-      __syncthreads();
-      if (kt + 2 < nk) {
-        lstore(B0{});
-        __syncthreads();
-      }
-    }
-  } else {
-    gload(B0{}, 0);
-    lstore(B0{});
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) gload(B0{}, (kt + 1) * KSLAB);
-      compute();
-      __syncthreads();
-      if (kt + 1 < nk) {
-        lstore(B0{});
-        __syncthreads();
-      }
     }
   }
 
@@ -367,13 +349,13 @@ int launch_linear_tile(const void* A, const void* A2, long lda, const void* W, c
   if constexpr (!BF16 && sizeof(TA) == 4) {
     if (g_f32_split) {
       hipLaunchKernelGGL((linear_kernel<TA, false, TO, BM, BN, false, true>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2,
-                         lda, W, bias, (TO*)out, ldc, rowmask, relu, M, N, K);
+                         lda, W, bias, (TO*)out, ldc, rowmask, relu, M, N, K, nullptr, nullptr, nullptr, g_linear_xcd);
       MVG_LAUNCH_CHECK();
       return 0;
     }
   }
   hipLaunchKernelGGL((linear_kernel<TA, BF16, TO, BM, BN>), grid, dim3(256), 0, st, (const TA*)A, (const TA*)A2, lda, W, bias,
-                     (TO*)out, ldc, rowmask, relu, M, N, K);
+                     (TO*)out, ldc, rowmask, relu, M, N, K, nullptr, nullptr, nullptr, g_linear_xcd);
   MVG_LAUNCH_CHECK();
   return 0;
 }
@@ -386,12 +368,12 @@ int launch_linear_idx(const float* A, long lda, const float* W, const float* bia
   dim3 grid((N + 127) / 128, (M + BM - 1) / BM);
   if (g_f32_split) {
     hipLaunchKernelGGL((linear_kernel<float, false, float, BM, 128, true, true>), grid, dim3(256), 0, st, A, (const float*)nullptr,
-                       lda, (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row);
+                       lda, (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, g_linear_xcd);
     MVG_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL((linear_kernel<float, false, float, BM, 128, true>), grid, dim3(256), 0, st, A, (const float*)nullptr, lda,
-                     (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row);
+                     (const void*)W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, g_linear_xcd);
   MVG_LAUNCH_CHECK();
   return 0;
 }
@@ -403,7 +385,7 @@ int launch_linear(const void* A, const void* A2, long lda, const void* W, const 
     if (N % 192 == 0 && N % 128 != 0)        // N = 192, 576, ...: no padded column tile
       return launch_linear_tile<TA, BF16, TO, 128, 192>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
     const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128);
-    if (tiles128 < 384 && M > 64)            // fewer than 1.5 workgroups per CU of an MI355X: halve the row tile
+    if ((tiles128 < 384 && M > 64) || g_linear_tiles == 2)   // fewer than 1.5 workgroups per CU of an MI355X: halve the row tile
       return launch_linear_tile<TA, BF16, TO, 64, 128>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);
   }
   return launch_linear_tile<TA, BF16, TO, 128, 128>(A, A2, lda, W, bias, out, ldc, rowmask, relu, M, N, K, st);

@@ -193,7 +193,7 @@ def test_linear_mfma_fp32_and_bf16():
         mask = torch.from_numpy((rs.rand(M) > 0.3).astype(np.uint8)).to(DEV)
         want = (a.double() @ w.double().t() + b.double())
         got = ops.linear(a, w, b)
-        assert _relerr(got, want) < 2e-6, (M, N, K)            # exact-fp32 MFMA, K <= 1024
+        assert _relerr(got, want) < 2e-6, (M, N, K)            # fp32-equivalent products (split or exact form), K <= 1024
         got = ops.linear(a, w, b, relu=True, rowmask=mask)
         assert _relerr(got, torch.relu(want) * mask[:, None].double()) < 2e-6
         # A + A2 formed on load (mvg_linear_sum: the first layer's Linear(tgt + query_pos)): bit-identical to the GEMM of the sum
@@ -208,6 +208,108 @@ def test_linear_mfma_fp32_and_bf16():
         assert _relerr(got16, want16) < 1e-5, (M, N, K)       # fp32 accumulation of exact bf16 products
         got16b = ops.linear(a, w16, b, out_dtype=torch.bfloat16)   # fp32 A converted on load
         assert _relerr(got16b.float(), want16) < 1e-2
+
+
+def _f32_gemm(form):
+    """select the fp32 GEMM form of csrc/gemm.hip: "split" (default) or "exact" """
+    from mvgformer_amd import _lib
+    assert _lib.load().mvg_set_tuning(b"f32_split", 1 if form == "split" else 0) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 200, 256), (128, 256, 32), (4097, 192, 1024), (77, 8, 64), (20000, 256, 256)])
+def test_linear_f32_split_form_is_as_close_to_fp64_as_the_exact_form(M, N, K):
+    """fp32 GEMMs run on the bf16 matrix pipe by default: every operand value as three bf16 parts (exact: 8 + 8 + 8 significand
+    bits), six of the nine partial products, fp32 accumulation (csrc/gemm.hip).  Against the fp64 product of the same fp32
+    operands its error must not exceed that of the exact form (v_mfma_f32_32x32x2_f32 = an fmaf chain) -- normal operands,
+    all-positive operands (no cancellation) and operands spread over 40 binades; unit = sum_k |a||w| + |b|."""
+    from mvgformer_amd import ops
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N + K)
+    try:
+        for kind in ("normal", "positive", "wide"):
+            a = torch.randn(M, K, device=DEV, generator=g)
+            w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+            if kind == "wide":
+                a = a * torch.exp2(torch.randint(-20, 21, (M, K), device=DEV, generator=g).float())
+                w = w * torch.exp2(torch.randint(-20, 21, (N, K), device=DEV, generator=g).float())
+            elif kind == "positive":
+                a, w = a.abs(), w.abs()
+            b = torch.randn(N, device=DEV, generator=g)
+            ref = a.double() @ w.double().t() + b.double()
+            unit = a.double().abs() @ w.double().abs().t() + b.double().abs()
+            err = {}
+            for form in ("exact", "split"):
+                _f32_gemm(form)
+                e = (ops.linear(a, w, b).double() - ref).abs() / unit
+                err[form] = (float(e.max()), float(e.mean()))
+            assert err["split"][0] <= 1.5 * err["exact"][0] + 2.0 ** -24, (kind, err)
+            assert err["split"][1] <= 1.25 * err["exact"][1] + 2.0 ** -28, (kind, err)
+            assert err["split"][0] < 2.0 ** -24 * (8 + K ** 0.5), (kind, err)        # a few units of fp32 rounding, growing like a random walk
+    finally:
+        _f32_gemm("split")
+
+
+def test_linear_f32_split_form_edges():
+    """zeros, powers of two, values that need all three parts, tiny and large magnitudes, ReLU / row mask / A + A2 on load, the
+    processing-order form; a non-finite input value stays in its own row."""
+    from mvgformer_amd import ops
+    rs = np.random.RandomState(5)
+    M, N, K = 300, 64, 64
+    a = rs.standard_normal((M, K)).astype(np.float32)
+    a[0] = 0.0
+    a[1] = 2.0 ** rs.randint(-30, 30, K)
+    a[2] = np.float32(1.0) + np.float32(2.0 ** -23)                   # 1 + ulp: hi = 1, mid = 0, lo = 2^-23
+    a[3] = rs.standard_normal(K) * 1e-30
+    a[4] = rs.standard_normal(K) * 1e30
+    a[5] = np.float32(16777215.0)                                     # 2^24 - 1: all 24 significand bits set
+    w = (rs.standard_normal((N, K)) / 8).astype(np.float32)
+    w[0] = 0.0
+    w[1] = 1.0
+    b = rs.standard_normal(N).astype(np.float32)
+    A, W, Bv = (torch.from_numpy(x).to(DEV) for x in (a, w, b))
+    want = A.double() @ W.double().t() + Bv.double()
+    unit = A.double().abs() @ W.double().abs().t() + Bv.double().abs()
+    got = ops.linear(A, W, Bv)
+    assert float(((got.double() - want).abs() / unit).max()) < 1e-6
+    assert torch.equal(got[0], Bv) and torch.equal(got[:, 0], Bv[0].expand(M))             # zero row / zero weight row: the bias, exactly
+    mask = torch.from_numpy((rs.rand(M) > 0.5).astype(np.uint8)).to(DEV)
+    r = ops.linear(A, W, Bv, relu=True, rowmask=mask)
+    assert torch.equal(r, torch.relu(got) * mask[:, None].float())
+    A2 = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV)
+    assert torch.equal(ops.linear(A, W, Bv, add=A2), ops.linear(A + A2, W, Bv))
+    bad = A.clone()
+    bad[7, 3] = float("inf")
+    bad[9, 0] = float("nan")
+    gb = ops.linear(bad, W, Bv)
+    rows = torch.ones(M, dtype=torch.bool, device=DEV)
+    rows[7] = rows[9] = False
+    assert torch.equal(gb[rows], got[rows]) and not torch.isfinite(gb[7]).any() and not torch.isfinite(gb[9, 1:]).any()
+
+
+@pytest.mark.parametrize("cname", ["mini5_all", "mini5_b2", "mini9"])
+def test_fp32_decoder_on_split_gemms_vs_exact_gemms(cname):
+    """the whole fp32 decoder on the two GEMM forms: the outputs differ by fp32 rounding (the forms round differently, neither is
+    the more accurate one) -- far inside the bars against the reference's own arrays."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    case = _case(cname)
+    dec = build_decoder_for_case(case, DEV)
+    gc = case_to_device(case, DEV)
+    run = lambda: dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes, gc.level_start_index, None,
+                      query_pos=gc.query_pos, threshold=0.1)
+    try:
+        with torch.no_grad():
+            _f32_gemm("exact")
+            hs0, refs0, r2d0, p2d0, cls0 = run()
+            _f32_gemm("split")
+            hs1, refs1, r2d1, p2d1, cls1 = run()
+    finally:
+        _f32_gemm("split")
+    assert _relerr(hs1, hs0) < 2e-5
+    assert float((torch.stack(cls1) - torch.stack(cls0)).abs().max()) < 2e-6
+    valid = (refs0[1:].abs().sum(-1) > 0) & (refs1[1:].abs().sum(-1) > 0)
+    assert torch.equal(refs0[1:].abs().sum(-1) > 0, refs1[1:].abs().sum(-1) > 0)           # same valid pattern
+    d = (refs1[1:] - refs0[1:]).norm(dim=-1)[valid]
+    assert d.numel() > 0 and float(d.median()) < 0.01 and float(d.max()) < 2.0             # mm; the DLT amplifies rounding
 
 
 @pytest.mark.parametrize("cname", ["mini5_all", "mini5_b2", "cfg1"])
@@ -1443,12 +1545,12 @@ def test_differentiable_dlt_matches_svd_autograd():
     assert torch.allclose(w.sort(-1).values, torch.linalg.eigvalsh(S.cpu()).to(DEV), rtol=1e-12, atol=1e-12 * float(S.abs().max()))
 
 
-_KNOBS = [("gsamp_pipe", 1, True), ("gsamp_pipe", 2, True), ("linear_tiles", 0, True), ("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
+_KNOBS = [("gsamp_pipe", 1, True), ("gsamp_pipe", 2, True), ("linear_tiles", 0, True), ("linear_tiles", 2, True), ("linear_xcd", 0, True), ("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
           ("gsamp_map", 8, True), ("bin_multi", 0, True), ("auto_small", 0, True), ("wreg_grid", 256, True),
           ("wreg_grid", 64, True), ("auto_small_b", 0, False), ("auto_small_a", 0, True), ("chain_rm", 64, True), ("chain_rm", 256, False),
           ("chain_a_waves", 8, False), ("chain_waves", 4, False), ("chain_split", 0, False), ("chain_ring", 8, False),
           ("chain_ring", 16, False), ("sampchain_map", 1, True), ("sampchain_map", 16, True)]
-_KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
+_KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, linear_xcd=1, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
                       chain_a_waves=4, chain_waves=8, chain_split=1, chain_ring=4, sampchain_map=4)
 # knobs of the fused sampler + chain A kernel (csrc/sampchain.hip, MVG_FUSE_SAMPLER=1); the default is the two-kernel form
 _FUSED_KERNEL_KNOBS = ("sampchain_map",)
