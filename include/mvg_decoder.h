@@ -145,7 +145,9 @@ int mvg_gather_ref(const void* feat, int dtype, const float* ref_lvl, const floa
 
 /* Dense projection out[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) (* rowmask[M]) on MFMA.
  * a_dtype / w_dtype / out_dtype: MVG_F32 or MVG_BF16 (weights must match the compute
- * dtype: f32 weights -> fp32 MFMA, bf16 weights -> bf16 MFMA; A is converted on load).
+ * dtype: bf16 weights -> bf16 MFMA, A converted on load; f32 weights -> fp32 products, formed either as six bf16 MFMAs on
+ * operands split into three bf16 parts (default; fp32 accuracy, not bitwise an fmaf chain; Inf / > 3.39e38 inputs give NaN)
+ * or as v_mfma_f32_32x32x2_f32 (mvg_set_tuning("f32_split", 0): bitwise an fp32 fmaf chain)).
  * relu: 0/1.  rowmask: NULL or uint8 (M).  lda/ldc in elements. */
 int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype,
                const float* bias, void* out, int out_dtype, int ldc,
