@@ -298,6 +298,12 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
   constexpr int CPV = 16 / (int)sizeof(TO);         // columns per 16-byte vector
   constexpr int VPR = BN / CPV;                     // vectors per staged row
   static_assert((64 * VPR) % 256 == 0, "the staged tile is stored in whole passes of the workgroup");
+  // the tile's bias values go through LDS (columns past N read as 0; they are not stored).  As a conditional global load per
+  // element inside the loop below each of a lane's 32 was its own exec region with its own wait: 8 900 cycles per phase, a
+  // quarter of a workgroup's lifetime (s_memtime, profiles/r03_experiments.txt).
+  __shared__ __attribute__((aligned(16))) float sbias[BN];
+  if (tid < BN) sbias[tid] = (bias && n0 + tid < N) ? bias[n0 + tid] : 0.f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     int grow = m0 + wm * WM + i * 32 + rl;
@@ -308,10 +314,11 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = wn * WN + j * 32 + 8 * g + 4 * h;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(sbias + nl);
         f32x4 v;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          float x = acc[i][j][4 * g + t] + ((bias && n0 + nl + t < N) ? bias[n0 + nl + t] : 0.f);
+          float x = acc[i][j][4 * g + t] + bq[t];
           if (relu) x = fmaxf(x, 0.f);
           v[t] = keep ? x : 0.f;
         }
