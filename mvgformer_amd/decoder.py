@@ -579,6 +579,7 @@ class DQDecoder(MvPDecoder):
         # branch of the captured HIP graph).  They fill in next to the latency-bound query-side kernels:
         # cfg-2 bf16 1.43 -> 1.30 ms per sample on MI355X.  MVG_OVERLAP_PYRAMID=0 runs them inline.
         self.overlap_pyramid = os.environ.get("MVG_OVERLAP_PYRAMID", "1") != "0"
+        self.overlap_pyramid_f32 = os.environ.get("MVG_OVERLAP_PYRAMID_F32", "1") != "0"
         self._side_stream = None
         # layer l's fused chain B also computes layer l+1's query term xw = (tgt' + query_pos) W^T + b (bf16 path)
         self.fuse_next_query_term = True
@@ -588,13 +589,20 @@ class DQDecoder(MvPDecoder):
             layer.set_compute_dtype(dtype)
         return self
 
-    def fork_side_stream(self, device):
+    def fork_side_stream(self, device, f32_shape=None):
         """The side stream of the forward, forked from the current stream -- or None when the query-independent work
-        runs inline (fp32 / generic path, share_layer_weights -- one buffer for all layers --, training, CPU,
-        MVG_OVERLAP_PYRAMID=0)."""
+        runs inline (generic path, share_layer_weights -- one buffer for all layers --, training, CPU,
+        MVG_OVERLAP_PYRAMID=0).  f32_shape = (Lq, L, S): needed for the fp32 path, whose pyramid products exist only in its
+        G-sampling form (ProjAttn.f32_g_form)."""
         distinct = len({id(l.proj_attn) for l in self.layers}) == len(self.layers)
+
+        def ahead(l):
+            if l.compute_dtype == torch.float32:
+                return (self.overlap_pyramid_f32 and f32_shape is not None and l.proj_attn.rayconv.weight.shape[0] == 256
+                        and l.proj_attn.f32_g_form(*f32_shape))
+            return l.proj_attn.uses_fast_path(l.compute_dtype) and l.use_fused_chains
         if not (self.overlap_pyramid and distinct and device.type == "cuda" and not torch.is_grad_enabled()
-                and all(l.proj_attn.uses_fast_path(l.compute_dtype) and l.use_fused_chains for l in self.layers)):
+                and all(ahead(l) for l in self.layers)):
             return None
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
@@ -645,7 +653,7 @@ class DQDecoder(MvPDecoder):
         output = tgt
         layer0 = self.layers[0]
         ctx = context
-        side = self.fork_side_stream(tgt.device)
+        side = None
         hs_buf = flags = geo_buf = None
         try:
             if ctx is None:
@@ -660,6 +668,7 @@ class DQDecoder(MvPDecoder):
             ctx.order = None
             inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
             ref_points_2d = None
+            side = self.fork_side_stream(tgt.device, (tgt.shape[1], ctx.levels.L, ctx.levels.S))
             if side is not None:
                 self.launch_pyramid_projections(ctx, side)
             # the fused chain writes every layer's hidden state straight into its slice of the stacked output

@@ -150,7 +150,7 @@ class ProjAttn(nn.Module):
     def _plane_buffer(self, n_img, S, device):
         """value planes buffer (every line is fully rewritten by each projection); kept across calls."""
         shape = (n_img, 8, S, 32)
-        if self._vp is None or tuple(self._vp.shape) != shape or self._vp.device != device:
+        if self._vp is None or self._vp.dtype != torch.bfloat16 or tuple(self._vp.shape) != shape or self._vp.device != device:
             self._vp = torch.empty(shape, dtype=torch.bfloat16, device=device)
         return self._vp
 
@@ -162,6 +162,12 @@ class ProjAttn(nn.Module):
         self._wc.get("Wv_frag", (self.rayconv.weight,), dtype, lambda w: ops.swizzle_weight(w.to(dtype)))
         self.query_term_weights(dtype)
         self._fast_query_weights(dtype)
+
+    def f32_g_form(self, Lq, L, S):
+        """fp32 path: G-sampling (the offsets / logits Linear applied to the pyramid) rather than gather-then-Linear -- by
+        MVG_G_SAMPLING_F32, else whenever the gathered rows (Lq * L per image) outnumber the pyramid's (S)"""
+        use_g = self.g_sampling_f32 if self.g_sampling_f32 != "auto" else Lq * L >= S
+        return bool(use_g) and self.sampling_offsets.out_features + self.attention_weights.out_features == 192
 
     def _wait_pyramid(self):
         """both pyramid projections were produced ahead of time on a side stream (DQDecoder.launch_pyramid_projections)."""
@@ -176,12 +182,24 @@ class ProjAttn(nn.Module):
         every layer on a side stream next to the latency-bound query-side kernels (record_event=True: the
         consumer waits on the event); both land in buffers kept across calls."""
         dt = feat.dtype
-        n_img, S, _ = feat.shape
+        n_img, S, Cc = feat.shape
+        if dt == torch.float32:      # fp32 G-sampling form: plain (rows, 256) / (rows, 192) fp32 products, kept across calls
+            Wv, bv = self.weights(dt)[:2]
+            Wq, _ = self._fast_query_weights(dt)
+            if self._vp is None or self._vp.dtype != dt or tuple(self._vp.shape) != (n_img, S, Cc) or self._vp.device != feat.device:
+                self._vp = torch.empty((n_img, S, Cc), dtype=dt, device=feat.device)
+                self._G = torch.empty((n_img * S, 192), dtype=dt, device=feat.device)
+            ops.linear(feat.view(n_img * S, Cc), Wv, bv, out=self._vp.view(n_img * S, Cc))       # projattn.py:169
+            ops.linear(feat.view(n_img * S, Cc), Wq, None, out=self._G)
+            if record_event:
+                self._vp_event = torch.cuda.Event()
+                self._vp_event.record()
+            return self._vp, self._G
         # the 103-MB value write first, G (gathered at random by the sampler) last: G is then the fresher
         # resident of the 256-MB Infinity Cache when the sampler starts
         vp = self.project_values(feat)
         shape = (n_img * S, 192)
-        if self._G is None or tuple(self._G.shape) != shape or self._G.device != feat.device:
+        if self._G is None or self._G.dtype != torch.bfloat16 or tuple(self._G.shape) != shape or self._G.device != feat.device:
             self._G = torch.empty(shape, dtype=torch.bfloat16, device=feat.device)
         ops.feat_linear_ws(feat, self.query_term_weights(dt)[0], 192, out=self._G)
         if record_event:
@@ -258,17 +276,16 @@ class ProjAttn(nn.Module):
                     xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
             vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
-        use_g = self.g_sampling_f32 if self.g_sampling_f32 != "auto" else r.shape[1] * levels.L >= S
-        if dt == torch.float32 and use_g and Woa.shape[0] == 192 and Cc == 256:
+        if dt == torch.float32 and Cc == 256 and self.f32_g_form(r.shape[1], levels.L, S):
             # fp32, reference arithmetic, same re-association as the bf16 fast path: the offsets / logits Linear applied to
             # the pyramid once (G) instead of to V*Lq*L gathered rows -- no `ain` (236 MB) / `oa` (177 MB) per layer
             Wq, bq = self._fast_query_weights(dt)
-            G32 = ops.linear(feat.view(n_img * S, Cc), Wq, None, out_dtype=dt)
             xw32 = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=dt)
-            value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)     # projattn.py:169
             if order is None and self.sort_pairs and r.shape[1] <= 65536:
                 order = ops.bin_pairs(r, pair_mask, levels)
-            return ops.msda_gfused_f32(value.view(n_img, S, Cc), G32, xw32, r, levels, B, pair_mask=pair_mask, order=order)
+            # the two pyramid products: computed here, or ahead of time on the side stream (DQDecoder.launch_pyramid_projections)
+            value, G32 = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
+            return ops.msda_gfused_f32(value, G32, xw32, r, levels, B, pair_mask=pair_mask, order=order)
         ain = ops.gather_ref(feat, r, x, levels, V, B)                       # projattn.py:148-153,180 (+query)
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
         value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
