@@ -155,6 +155,10 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   char* hbuf = smem + RM * ACT_PITCH;     // RM x 256 bf16 : FFN hidden chunk
   char* xb = hbuf + RM * ACT_PITCH;       // RM x 256 fp32 : pre-LN sums / t1 / tgt'
   float* pr = reinterpret_cast<float*>(xb + RM * XP);   // RM x 2 per-row class probabilities
+  // LayerNorm scales / shifts and the class head's two rows, staged once: [g2 | be2 | g3 | be3 | Wc0 | Wc1] (6 x 256 fp32).
+  // As global loads inside the row phases they sat on the tile's critical path -- in LN3 behind the tgt' stores, which the
+  // in-order vmcnt makes a load wait for (s_memtime: LN3 + class head 12 400 cycles against 3 800 for LN2).
+  float* lnp = pr + RM * 2;
   constexpr int MT = (JN == 1) ? RM / 32 : (RM / 32) / (NT / 256), NW = NT / 64;   // JN = 1: every wave covers all row blocks
   static_assert(MT >= 1, "tile too small for this wave mapping");
   static_assert(JN == 2 || NT == 512, "column-split mapping needs 8 wavefronts");
@@ -177,6 +181,14 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   // cross-lane latencies.  tgt is fetched here, long before its use.
   constexpr int RPASS = (RM + 8 * NW - 1) / (8 * NW);   // 1 with 8 wavefronts, 2 with 4; RM = 32: wavefronts 4..7 have no rows
   const int rgrp = lane >> 3, part = lane & 7;
+  constexpr int NLNP = (1536 + NT - 1) / NT;
+  float lnv[NLNP];
+#pragma unroll
+  for (int i = 0; i < NLNP; ++i) {
+    const int e = min(i * NT + tid, 1535), seg = e >> 8, o = e & 255;
+    const float* src = seg == 0 ? g2 : seg == 1 ? be2 : seg == 2 ? (has_ffn ? g3 : g2) : seg == 3 ? (has_ffn ? be3 : be2) : Wc + (seg - 4) * 256;
+    lnv[i] = src[o];
+  }
   f32x4 tg[RPASS][8];
 #pragma unroll
   for (int ps = 0; ps < RPASS; ++ps)
@@ -239,6 +251,9 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < NLNP; ++i)
+    if (i * NT + tid < 1536) lnp[i * NT + tid] = lnv[i];
   __syncthreads();
 
   // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c4 = part + 8 * i;
-      const f32x4 y = v[i] * rstd * *reinterpret_cast<const f32x4*>(g2 + c4 * 4) + *reinterpret_cast<const f32x4*>(be2 + c4 * 4);
+      const f32x4 y = v[i] * rstd * *reinterpret_cast<const f32x4*>(lnp + c4 * 4) + *reinterpret_cast<const f32x4*>(lnp + 256 + c4 * 4);
       *reinterpret_cast<f32x4*>(xb + row * XP + c4 * 16) = y;                         // t1 (fp32, residual)
       uint2 pk;
       pk.x = pack_bf16(y[0], y[1]);
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c4 = part + 8 * i;
-        y[i] = y[i] * rstd * *reinterpret_cast<const f32x4*>(g3 + c4 * 4) + *reinterpret_cast<const f32x4*>(be3 + c4 * 4);
+        y[i] = y[i] * rstd * *reinterpret_cast<const f32x4*>(lnp + 512 + c4 * 4) + *reinterpret_cast<const f32x4*>(lnp + 768 + c4 * 4);
       }
     }
     float a0 = 0.f, a1 = 0.f;
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
         pk.y = pack_bf16(x[2], x[3]);
         *reinterpret_cast<uint2*>(act + row * ACT_PITCH + c4 * 8) = pk;
       }
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + c4 * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + c4 * 4);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(lnp + 1024 + c4 * 4), w1 = *reinterpret_cast<const f32x4*>(lnp + 1280 + c4 * 4);
       a0 += y[i][0] * w0[0] + y[i][1] * w0[1] + y[i][2] * w0[2] + y[i][3] * w0[3];
       a1 += y[i][0] * w1[0] + y[i][1] * w1[1] + y[i][2] * w1[2] + y[i][3] * w1[3];
     }
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       pr[2 * row + 1] = 1.f / (1.f + expf(-a1));
     }
   }
-  __syncthreads();
+  lds_barrier();        // pr / act are LDS; the tgt' stores above are read by nobody here and are not waited for
   if (tid < qpt && q0 + tid < nq_total) {
     float p0 = 0.f, p1 = 0.f;
     for (int j = 0; j < J; ++j) {
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     stage_gemm<MT, 16, BRING, JN, false, true>(act, Wn, acc, tid, true, rot + 7, 16 * 1024, nullptr, acc2);
     merge_acc<MT, JN>(acc, acc2);
     acc_to_x<MT, JN>(xb, acc, bn, false, tid);
-    __syncthreads();
+    lds_barrier();
     for (int row = wave; row < nrow; row += NW)
       if (lane * 4 < n_next)
         *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + row) * n_next + lane * 4) =
@@ -477,11 +492,11 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
                      (nq_total + (64 / J) - 1) / (64 / J) <= 128;
   const int RMr = small ? 32 : 64;
   const int qpt = RMr / J;
-  const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float);
+  const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float) + 1536 * sizeof(float);
   static bool configured[MVG_MAX_DEVICES] = {};   // per device, see launch_chain_a
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
-  const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float);
+  const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float) + 1536 * sizeof(float);
   if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
