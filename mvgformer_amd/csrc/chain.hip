@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       pr[2 * row + 1] = 1.f / (1.f + expf(-a1));
     }
   }
-  lds_barrier();        // pr / act are LDS; the tgt' stores above are read by nobody here and are not waited for
+  __syncthreads();
   if (tid < qpt && q0 + tid < nq_total) {
     float p0 = 0.f, p1 = 0.f;
     for (int j = 0; j < J; ++j) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     stage_gemm<MT, 16, BRING, JN, false, true>(act, Wn, acc, tid, true, rot + 7, 16 * 1024, nullptr, acc2);
     merge_acc<MT, JN>(acc, acc2);
     acc_to_x<MT, JN>(xb, acc, bn, false, tid);
-    lds_barrier();
+    __syncthreads();
     for (int row = wave; row < nrow; row += NW)
       if (lane * 4 < n_next)
         *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + row) * n_next + lane * 4) =

@@ -8,10 +8,6 @@ namespace {
 
 constexpr int ACT_PITCH = 528;   // bytes per activation row in LDS (256 bf16 + 16 pad)
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for this wavefront's outstanding GLOBAL
-// stores (vmcnt(0): its fence covers global memory), i.e. for the write acknowledgements of outputs that no thread of the
-// workgroup reads again.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Stage GEMM  acc[m][n] = sum_k act[m][k] * W[n][k]  for one 256-column block of W.
 // Weights are NOT staged through LDS: they are pre-swizzled on the host into MFMA-fragment order
