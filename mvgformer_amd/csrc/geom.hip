@@ -284,16 +284,19 @@ __global__ __launch_bounds__(256) void rowdot3_kernel(const T* __restrict__ h, c
 //    smallest eigenvector (= smallest right singular vector of A, torch.linalg.svd's Vh[3]) is
 //    found with cyclic Jacobi rotations in fp64.  Squaring the condition number in fp64
 //    (eps 1.1e-16) leaves far more headroom than an fp32 SVD of A (eps 6e-8) has.
+__device__ __forceinline__ void jacobi_angle3(const double app, const double aqq, const double apq, double& c, double& s);
 __device__ __forceinline__ void jacobi_angle(const double (&a)[4][4], const int p, const int q, double& c, double& s) {
+  jacobi_angle3(a[p][p], a[q][q], a[p][q], c, s);
+}
+__device__ __forceinline__ void jacobi_angle3(const double app, const double aqq, const double apq, double& c, double& s) {
   c = 1.0;
   s = 0.0;
-  const double apq = a[p][q];
   if (fabs(apq) < 1e-300) return;
   // The rotation ANGLE only steers convergence, so it is computed in fp32 (one fast division, one sqrt); what
   // must hold to fp64 precision is c^2 + s^2 = 1 (the similarity transform stays orthogonal): c = rsqrt(1+t^2)
   // starts from the fp32 rsqrt and takes two Newton steps in fp64.  (IEEE fp64 div/sqrt sequences were ~80 % of
   // this kernel's time.)
-  const float theta = (float)(a[q][q] - a[p][p]) / (2.f * (float)apq);
+  const float theta = (float)(aqq - app) / (2.f * (float)apq);
   if (!(fabsf(theta) <= 3.0e38f)) return;     // a[p][q] is negligible against the diagonal gap (or 0/0): nothing to rotate
   const float tf = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
   const double t = (double)tf;
@@ -305,25 +308,30 @@ __device__ __forceinline__ void jacobi_angle(const double (&a)[4][4], const int 
   s = t * cc;
 }
 
+// The two halves of a plane rotation with their roundings pinned (one product rounded, then one fma), so that the one-lane
+// Jacobi below and the lane-parallel one of triangulate_kernel give the same bits:  x' = c x - s y,  y' = s x + c y.
+__device__ __forceinline__ double rot_lo(double c, double x, double s, double y) { return __builtin_fma(c, x, -(s * y)); }
+__device__ __forceinline__ double rot_hi(double c, double x, double s, double y) { return __builtin_fma(s, x, c * y); }
+
 __device__ __forceinline__ void jacobi_apply(double (&a)[4][4], double (&v)[4][4], const int p, const int q, const double c,
                                              const double s) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {   // columns p,q of A
     const double akp = a[k][p], akq = a[k][q];
-    a[k][p] = c * akp - s * akq;
-    a[k][q] = s * akp + c * akq;
+    a[k][p] = rot_lo(c, akp, s, akq);
+    a[k][q] = rot_hi(c, akp, s, akq);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {   // rows p,q of A
     const double apk = a[p][k], aqk = a[q][k];
-    a[p][k] = c * apk - s * aqk;
-    a[q][k] = s * apk + c * aqk;
+    a[p][k] = rot_lo(c, apk, s, aqk);
+    a[q][k] = rot_hi(c, apk, s, aqk);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const double vkp = v[k][p], vkq = v[k][q];
-    v[k][p] = c * vkp - s * vkq;
-    v[k][q] = s * vkp + c * vkq;
+    v[k][p] = rot_lo(c, vkp, s, vkq);
+    v[k][q] = rot_hi(c, vkp, s, vkq);
   }
 }
 
@@ -362,6 +370,74 @@ __device__ __forceinline__ float add8(float v) {
   return v;
 }
 
+// ---- lane-parallel Jacobi (round 3): the 8 lanes that built a problem's DLT rows also diagonalise its Gram matrix.  Lane
+// j < 4 holds COLUMN j of the symmetric 4 x 4 matrix, lane 4 + j column j of the accumulated rotations V.  A round of the
+// cyclic order rotates the two disjoint pairs (0, M) and the other two, M = 1, 2, 3: the partner's column is one quad_perm
+// exchange away (lane ^ M, in the A quad and in the V quad alike), a column update is then local to the two lanes of a
+// pair, a row update local to every lane.  The operations and their order per matrix element are those of jacobi_rotate2
+// (both angles from the matrix as the round finds it; rotation 1: columns, rows, V; rotation 2: columns, rows, V; roundings
+// pinned by rot_lo / rot_hi), so the result is the one-lane Jacobi's bit for bit (tests: knob tri_lanes) -- on 8 wavefronts
+// instead of one, and a wavefront stops when its own 8 problems have converged.
+// MEASURED SLOWER and not the default: cfg-2 forward 1.279 -> 1.309 ms.  The one-lane form is 19 200 of the kernel's 32 900
+// cycles (s_memtime) at 8.5 cycles per dependent fp64 instruction, but only ~150 instructions per round for 64 problems; this
+// form needs ~200 per round and wavefront (two 32-bit DPP moves per exchanged double, selects between the p / q forms,
+// the pair-1 / pair-2 / A-only steps each issued for the whole wavefront) on 8 wavefronts = two per SIMD: 1 600 cycles of
+// fp64 issue per round and SIMD against 1 280 of latency.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void row_rot(double (&x)[4], const int p, const int q, const double c, const double s) {
+  const double xp = x[p], xq = x[q];
+  x[p] = rot_lo(c, xp, s, xq);
+  x[q] = rot_hi(c, xp, s, xq);
+}
+template <int M>
+__device__ __forceinline__ void jacobi_round_lanes(double (&col)[4], const int jj, const bool isA) {
+  constexpr int XORC = M == 1 ? 0xB1 : (M == 2 ? 0x4E : 0x1B);          // quad_perm of lane ^ M
+  constexpr int P1 = 0, Q1 = M, P2 = (M == 1 ? 2 : 1), Q2 = (M == 3 ? 2 : 3);
+  double pc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pc[k] = dpp_f64<XORC>(col[k]);
+  const bool is_p = jj < (jj ^ M);                                       // the lower index of its pair
+  const bool pair1 = jj == 0 || jj == M;
+  // rotation angle of the lane's own pair, from the columns as the round finds them (A lanes; V lanes take the A lanes')
+  double cp[4], cq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cp[k] = is_p ? col[k] : pc[k];
+    cq[k] = is_p ? pc[k] : col[k];
+  }
+  double c, s;
+  jacobi_angle3(pair1 ? cp[P1] : cp[P2], pair1 ? cq[Q1] : cq[Q2], pair1 ? cq[P1] : cq[P2], c, s);
+  double c1 = dpp_f64<P1 * 0x55>(c), s1 = dpp_f64<P1 * 0x55>(s), c2 = dpp_f64<P2 * 0x55>(c), s2 = dpp_f64<P2 * 0x55>(s);
+  {
+    const double c1v = dpp_f64<0x114>(c1), s1v = dpp_f64<0x114>(s1), c2v = dpp_f64<0x114>(c2), s2v = dpp_f64<0x114>(s2);   // row_shr:4
+    if (!isA) { c1 = c1v; s1 = s1v; c2 = c2v; s2 = s2v; }
+  }
+  // rotation 1: columns P1, Q1 (of A and of V) ...
+  if (pair1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) col[k] = is_p ? rot_lo(c1, col[k], s1, pc[k]) : rot_hi(c1, pc[k], s1, col[k]);
+  }
+  // ... rows P1, Q1 of A: of the lane's own column and of its copy of the partner's (the pair-2 lanes rotate with it next)
+  if (isA) {
+    row_rot(col, P1, Q1, c1, s1);
+    row_rot(pc, P1, Q1, c1, s1);
+  }
+  // rotation 2: columns P2, Q2, then rows P2, Q2 of A
+  if (!pair1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) col[k] = is_p ? rot_lo(c2, col[k], s2, pc[k]) : rot_hi(c2, pc[k], s2, col[k]);
+  }
+  if (isA) row_rot(col, P2, Q2, c2, s2);
+}
+
+int g_tri_lanes = 0;    // tuning knob "tri_lanes": 1 = lane-parallel Jacobi in triangulate_kernel (measured slower), 0 = one lane per problem
+
+template <bool LANES>
 __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restrict__ r, const float* __restrict__ o,
                                                           const float* __restrict__ cams,
                                                           const uint8_t* __restrict__ valid,
@@ -475,6 +551,71 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
     for (int e = 0; e < 10; ++e) gram[e][pl][sub] = G[e];
   }
   __syncthreads();
+  if constexpr (LANES) {
+    // ---- phase 2, lane-parallel: see jacobi_round_lanes
+    const long idx = min((long)blockIdx.x * TRI_PROBS + pl, nprob - 1);
+    const bool live = (long)blockIdx.x * TRI_PROBS + pl < nprob;
+    const int q = (int)(idx % Lq), b = (int)(idx / Lq);
+    const int i = q / J;
+    bool ok = valid[b * NQ + i] != 0;
+    if (!ok && any_valid[0] == 0 && b == 0 && i == 0) ok = true;
+    const bool isA = sub < 4;
+    const int jj = sub & 3;
+    double col[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lo = min(k, jj), hi = max(k, jj);
+      const int e = lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo);           // entry (lo, hi) of the upper triangle, as phase 1 numbered it
+      double g = 0.0;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) g += gram[e][pl][s8];                // Gram matrix over all views
+      col[k] = isA ? g : (k == jj ? 1.0 : 0.0);
+    }
+    int act = 1;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      if (act) {
+        const double dj = jj == 0 ? col[0] : (jj == 1 ? col[1] : (jj == 2 ? col[2] : col[3]));
+        const double g01 = dpp_f64<0x55>(col[0]), g02 = dpp_f64<0xAA>(col[0]), g03 = dpp_f64<0xFF>(col[0]);
+        const double g12 = dpp_f64<0xAA>(col[1]), g13 = dpp_f64<0xFF>(col[1]), g23 = dpp_f64<0xFF>(col[2]);
+        const double d0 = dpp_f64<0x00>(dj), d1 = dpp_f64<0x55>(dj), d2 = dpp_f64<0xAA>(dj), d3 = dpp_f64<0xFF>(dj);
+        const double off = fabs(g01) + fabs(g02) + fabs(g03) + fabs(g12) + fabs(g13) + fabs(g23);
+        const double lg = fmax(fmax(fabs(d0), fabs(d1)), fmax(fabs(d2), fabs(d3)));
+        int go = (off <= 2e-16 * lg) ? 0 : 1;    // off-diagonals at the fp64 rounding floor of the matrix: converged
+        const int gov = __builtin_amdgcn_update_dpp(0, go, 0x114, 0xf, 0xf, false);
+        act = isA ? go : gov;
+      }
+      if (act) {
+        jacobi_round_lanes<1>(col, jj, isA);
+        jacobi_round_lanes<2>(col, jj, isA);
+        jacobi_round_lanes<3>(col, jj, isA);
+      }
+      if (!__any(act)) break;
+    }
+    // eigenvector of the smallest eigenvalue (the first one on ties): column cstar of V, i.e. lane 4 + cstar
+    int cstar = 0;
+    {
+      const double dj = jj == 0 ? col[0] : (jj == 1 ? col[1] : (jj == 2 ? col[2] : col[3]));
+      const double d0 = dpp_f64<0x00>(dj), d1 = dpp_f64<0x55>(dj), d2 = dpp_f64<0xAA>(dj), d3 = dpp_f64<0xFF>(dj);
+      double best = d0;
+      if (d1 < best) { best = d1; cstar = 1; }
+      if (d2 < best) { best = d2; cstar = 2; }
+      if (d3 < best) { best = d3; cstar = 3; }
+      const int cv = __builtin_amdgcn_update_dpp(0, cstar, 0x114, 0xf, 0xf, false);
+      if (!isA) cstar = cv;
+    }
+    if (!isA && jj == cstar && live) {
+      const float X0 = ok ? (float)(col[0] / col[3]) : 0.f;                             // multiview.py:220-221
+      const float X1 = ok ? (float)(col[1] / col[3]) : 0.f;
+      const float X2 = ok ? (float)(col[2] / col[3]) : 0.f;
+      float* nr = new_ref + ((long)b * Lq + q) * 3;
+      nr[0] = X0;
+      nr[1] = X1;
+      nr[2] = X2;
+      xnew[pl][0] = X0;
+      xnew[pl][1] = X1;
+      xnew[pl][2] = X2;
+    }
+  } else
   // ---- phase 2: one lane per problem
   if (tid < TRI_PROBS && (long)blockIdx.x * TRI_PROBS + tid < nprob) {
   const long idx = (long)blockIdx.x * TRI_PROBS + tid;
@@ -982,8 +1123,12 @@ static int launch_triangulate(const float* r, const float* o, const float* cams,
   if (!r || !o || !cams || !valid || !any_valid || !new_ref || !ref2d || !proj2d || V <= 0) return MVG_E_BADARG;
   const long nprob = (long)B * NQ * J;            // 64 problems per 512-thread workgroup (8 lanes each in phase 1)
   if (nprob == 0) return 0;
-  hipLaunchKernelGGL(triangulate_kernel, dim3(mvg_ceil_div(nprob, TRI_PROBS)), dim3(512), 0, (hipStream_t)stream, r, o, cams,
-                     valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, r_next, ref_lvl_next, inside_next);
+  if (g_tri_lanes)
+    hipLaunchKernelGGL(triangulate_kernel<true>, dim3(mvg_ceil_div(nprob, TRI_PROBS)), dim3(512), 0, (hipStream_t)stream, r, o,
+                       cams, valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, r_next, ref_lvl_next, inside_next);
+  else
+    hipLaunchKernelGGL(triangulate_kernel<false>, dim3(mvg_ceil_div(nprob, TRI_PROBS)), dim3(512), 0, (hipStream_t)stream, r, o,
+                       cams, valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, r_next, ref_lvl_next, inside_next);
   MVG_LAUNCH_CHECK();
   return 0;
 }

@@ -1545,12 +1545,12 @@ def test_differentiable_dlt_matches_svd_autograd():
     assert torch.allclose(w.sort(-1).values, torch.linalg.eigvalsh(S.cpu()).to(DEV), rtol=1e-12, atol=1e-12 * float(S.abs().max()))
 
 
-_KNOBS = [("gsamp_pipe", 1, True), ("gsamp_pipe", 2, True), ("linear_tiles", 0, True), ("linear_tiles", 2, True), ("linear_xcd", 0, True), ("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
+_KNOBS = [("gsamp_pipe", 1, True), ("gsamp_pipe", 2, True), ("linear_tiles", 0, True), ("linear_tiles", 2, True), ("linear_xcd", 0, True), ("tri_lanes", 1, True), ("gsamp_threads", 128, True), ("gsamp_threads", 512, True), ("gsamp_threads", 1024, True), ("gsamp_map", 0, True),
           ("gsamp_map", 8, True), ("bin_multi", 0, True), ("auto_small", 0, True), ("wreg_grid", 256, True),
           ("wreg_grid", 64, True), ("auto_small_b", 0, False), ("auto_small_a", 0, True), ("chain_rm", 64, True), ("chain_rm", 256, False),
           ("chain_a_waves", 8, False), ("chain_waves", 4, False), ("chain_split", 0, False), ("chain_ring", 8, False),
           ("chain_ring", 16, False), ("sampchain_map", 1, True), ("sampchain_map", 16, True)]
-_KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, linear_xcd=1, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
+_KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, linear_xcd=1, tri_lanes=0, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
                       chain_a_waves=4, chain_waves=8, chain_split=1, chain_ring=4, sampchain_map=4)
 # knobs of the fused sampler + chain A kernel (csrc/sampchain.hip, MVG_FUSE_SAMPLER=1); the default is the two-kernel form
 _FUSED_KERNEL_KNOBS = ("sampchain_map",)
