@@ -289,23 +289,23 @@ __device__ __forceinline__ void jacobi_angle(const double (&a)[4][4], const int 
   jacobi_angle3(a[p][p], a[q][q], a[p][q], c, s);
 }
 __device__ __forceinline__ void jacobi_angle3(const double app, const double aqq, const double apq, double& c, double& s) {
-  c = 1.0;
-  s = 0.0;
-  if (fabs(apq) < 1e-300) return;
   // The rotation ANGLE only steers convergence, so it is computed in fp32 (one fast division, one sqrt); what
   // must hold to fp64 precision is c^2 + s^2 = 1 (the similarity transform stays orthogonal): c = rsqrt(1+t^2)
   // starts from the fp32 rsqrt and takes two Newton steps in fp64.  (IEEE fp64 div/sqrt sequences were ~80 % of
   // this kernel's time.)
+  // Branch-free: "nothing to rotate" (a[p][q] = 0 or negligible against the diagonal gap: theta infinite or 0/0) is a select
+  // at the end.  As two early returns each angle sat in its own exec-mask region and the two angles of a round -- independent
+  // chains of ~30 dependent instructions -- ran one after the other instead of interleaved.
   const float theta = (float)(aqq - app) / (2.f * (float)apq);
-  if (!(fabsf(theta) <= 3.0e38f)) return;     // a[p][q] is negligible against the diagonal gap (or 0/0): nothing to rotate
+  const bool rotate = !(fabs(apq) < 1e-300) && (fabsf(theta) <= 3.0e38f);
   const float tf = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
   const double t = (double)tf;
   const double w = t * t + 1.0;
   double cc = (double)rsqrtf((float)w);
   cc = cc * (1.5 - 0.5 * w * cc * cc);
   cc = cc * (1.5 - 0.5 * w * cc * cc);
-  c = cc;
-  s = t * cc;
+  c = rotate ? cc : 1.0;
+  s = rotate ? t * cc : 0.0;
 }
 
 // The two halves of a plane rotation with their roundings pinned (one product rounded, then one fma), so that the one-lane
