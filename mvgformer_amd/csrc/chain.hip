@@ -155,7 +155,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   char* hbuf = smem + RM * ACT_PITCH;     // RM x 256 bf16 : FFN hidden chunk
   char* xb = hbuf + RM * ACT_PITCH;       // RM x 256 fp32 : pre-LN sums / t1 / tgt'
   float* pr = reinterpret_cast<float*>(xb + RM * XP);   // RM x 2 per-row class probabilities
-  // LayerNorm scales / shifts and the class head's two rows, staged once: [g2 | be2 | g3 | be3 | Wc0 | Wc1] (6 x 256 fp32).
+  // LayerNorm scales / shifts, the class head's two rows and the biases of the fp32 epilogues (acc_to_x), staged once:
+  // [g2 | be2 | g3 | be3 | Wc0 | Wc1 | bu | b2 | bn] (9 x 256 fp32).
   // As global loads inside the row phases they sat on the tile's critical path -- in LN3 behind the tgt' stores, which the
   // in-order vmcnt makes a load wait for (s_memtime: LN3 + class head 12 400 cycles against 3 800 for LN2).
   float* lnp = pr + RM * 2;
@@ -181,13 +182,14 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   // cross-lane latencies.  tgt is fetched here, long before its use.
   constexpr int RPASS = (RM + 8 * NW - 1) / (8 * NW);   // 1 with 8 wavefronts, 2 with 4; RM = 32: wavefronts 4..7 have no rows
   const int rgrp = lane >> 3, part = lane & 7;
-  constexpr int NLNP = (1536 + NT - 1) / NT;
+  constexpr int NLN = 9 * 256, NLNP = (NLN + NT - 1) / NT;
   float lnv[NLNP];
 #pragma unroll
   for (int i = 0; i < NLNP; ++i) {
-    const int e = min(i * NT + tid, 1535), seg = e >> 8, o = e & 255;
-    const float* src = seg == 0 ? g2 : seg == 1 ? be2 : seg == 2 ? (has_ffn ? g3 : g2) : seg == 3 ? (has_ffn ? be3 : be2) : Wc + (seg - 4) * 256;
-    lnv[i] = src[o];
+    const int e = min(i * NT + tid, NLN - 1), seg = e >> 8, o = e & 255;
+    const float* src = seg == 0 ? g2 : seg == 1 ? be2 : seg == 2 ? (has_ffn ? g3 : g2) : seg == 3 ? (has_ffn ? be3 : be2)
+                       : seg < 6 ? Wc + (seg - 4) * 256 : seg == 6 ? bu : seg == 7 ? (has_ffn ? b2 : bu) : (Wn ? bn : bu);
+    lnv[i] = src[o];                                            // (b_next is zero-padded to 256 entries, as W_next's fragments are)
   }
   f32x4 tg[RPASS][8];
 #pragma unroll
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   }
 #pragma unroll
   for (int i = 0; i < NLNP; ++i)
-    if (i * NT + tid < 1536) lnp[i * NT + tid] = lnv[i];
+    if (i * NT + tid < NLN) lnp[i * NT + tid] = lnv[i];
   __syncthreads();
 
   // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   stage_gemm<MT, 16, BRING, JN, false, true>(act, Wu, acc, tid, true, rot, 16 * 1024, nullptr, acc2);
   if (has_ffn) ring_prefetch<16, BRING, JN, MT>(W1, pf, tid, rot);       // first FFN stage, fetched under LN2
   merge_acc<MT, JN>(acc, acc2);
-  acc_to_x<MT, JN>(xb, acc, bu, false, tid);
+  acc_to_x<MT, JN>(xb, acc, lnp + 1536, false, tid);
   __syncthreads();
 #pragma unroll
   for (int ps = 0; ps < RPASS; ++ps) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       __syncthreads();                                                               // hbuf free for the next chunk
     }
     merge_acc<MT, JN>(accy, accy2);
-    acc_to_x<MT, JN>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
+    acc_to_x<MT, JN>(xb, accy, lnp + 1792, true, tid);                                   // x = t1 + Y + b2
     __syncthreads();
   }
 
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     //      elementwise add per layer).  The barrier above ordered the act writes and the last xb reads.
     stage_gemm<MT, 16, BRING, JN, false, true>(act, Wn, acc, tid, true, rot + 7, 16 * 1024, nullptr, acc2);
     merge_acc<MT, JN>(acc, acc2);
-    acc_to_x<MT, JN>(xb, acc, bn, false, tid);
+    acc_to_x<MT, JN>(xb, acc, lnp + 2048, false, tid);
     __syncthreads();
     for (int row = wave; row < nrow; row += NW)
       if (lane * 4 < n_next)
@@ -492,11 +494,11 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
                      (nq_total + (64 / J) - 1) / (64 / J) <= 128;
   const int RMr = small ? 32 : 64;
   const int qpt = RMr / J;
-  const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float) + 1536 * sizeof(float);
+  const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float) + 9 * 256 * sizeof(float);
   static bool configured[MVG_MAX_DEVICES] = {};   // per device, see launch_chain_a
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
-  const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float) + 1536 * sizeof(float);
+  const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float) + 9 * 256 * sizeof(float);
   if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);

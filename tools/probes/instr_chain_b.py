@@ -24,9 +24,9 @@ rep('''  __syncthreads();
   ts[1] = __builtin_amdgcn_s_memtime();
 
   // ---- u = feature_update_mlp(mean)''')
-rep('''  acc_to_x<MT, JN>(xb, acc, bu, false, tid);
+rep('''  acc_to_x<MT, JN>(xb, acc, lnp + 1536, false, tid);
   __syncthreads();
-''','''  acc_to_x<MT, JN>(xb, acc, bu, false, tid);
+''','''  acc_to_x<MT, JN>(xb, acc, lnp + 1536, false, tid);
   __syncthreads();
   ts[2] = __builtin_amdgcn_s_memtime();
 ''')
@@ -48,10 +48,10 @@ rep('''      __syncthreads();                                                   
     }''','''      __syncthreads();                                                               // hbuf free for the next chunk
       if (c == 1) ts[6] = __builtin_amdgcn_s_memtime();
     }''')
-rep('''    acc_to_x<MT, JN>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
+rep('''    acc_to_x<MT, JN>(xb, accy, lnp + 1792, true, tid);                                   // x = t1 + Y + b2
     __syncthreads();
   }
-''','''    acc_to_x<MT, JN>(xb, accy, b2, true, tid);                                           // x = t1 + Y + b2
+''','''    acc_to_x<MT, JN>(xb, accy, lnp + 1792, true, tid);                                   // x = t1 + Y + b2
     __syncthreads();
   }
   ts[7] = __builtin_amdgcn_s_memtime();
