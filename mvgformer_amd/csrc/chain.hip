@@ -43,6 +43,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   char* act = smem;
   int* rid = reinterpret_cast<int*>(smem + RM * ACT_PITCH);  // global row of every tile row (-1: past the end)
   float* w2s = reinterpret_cast<float*>(smem + RM * ACT_PITCH + RM * sizeof(int));   // last pose layer (3 x 256 f32)
+  int* keepf = reinterpret_cast<int*>(w2s + 768);                                    // in-image flag of every tile row
   const int tid = threadIdx.x;
   const int r0 = blockIdx.x * RM;
 
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
     const int g = slot < R ? (order ? order[slot] : slot) : -1;
     rid[tid] = g;
     mine = g >= 0 && inside[g] != 0;
+    keepf[tid] = mine ? 1 : 0;
   }
   const bool any_inside = __syncthreads_or(mine) != 0;
   if (!any_inside && o_masked) {
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
     return;
   }
 
+  f32x4 pf1[4][JN];
+  chain_a_ring1<RM, NT, JN>(Wp, pf1, tid);          // stage 1's first weight fragments, in flight under the tile load
   // samp tile -> LDS (16-byte vectors, rows past R are zero); all loads in flight before the first write
   {
     f32x4 x[RM * 32 / NT];
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
       *reinterpret_cast<f32x4*>(act + row * ACT_PITCH + v16 * 16) = (rid[row] >= 0) ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  chain_a_body<RM, NT, JN>(act, rid, w2s, inside, Wp, bp, W0, b0, W1, b1, b2, attn, o);
+  chain_a_body<RM, NT, JN, true>(act, rid, w2s, inside, Wp, bp, W0, b0, W1, b1, b2, attn, o, pf1, keepf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -434,7 +438,7 @@ template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
                           float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
-  const size_t lds = RM * ACT_PITCH + RM * sizeof(int) + 768 * sizeof(float);
+  const size_t lds = RM * ACT_PITCH + 2 * RM * sizeof(int) + 768 * sizeof(float);
   // the attribute is per DEVICE: a process that drives several GPUs configures the > 64-KB LDS kernels on each of them
   static bool configured[MVG_MAX_DEVICES] = {};
   int dev = 0;

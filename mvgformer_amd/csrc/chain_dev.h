@@ -216,13 +216,24 @@ __device__ __forceinline__ void write_act_pre(char* __restrict__ act, const f32x
 // for the view mean), then the pose MLP -> o (dx, dy, confidence logit).  Called by all threads of the workgroup after a
 // barrier that made the tile visible; used by chain_a_kernel (tile loaded from samp) and by the fused sampler + chain A
 // kernel (tile produced in place by the gather phase, csrc/sampchain.hip).
+// PRE1: the first weight fragments of stage 1 were requested by the caller before it loaded the tile (chain_a_ring1), so that
+// their round trip runs under the tile's (s_memtime: stage 1 took 11 500 cycles against 6 300 - 7 800 for stages 2 and 3,
+// which have always had this prefetch).
 template <int RM, int NT, int JN>
+__device__ __forceinline__ void chain_a_ring1(const bf16_t* __restrict__ Wp, f32x4 (&pf1)[4][JN], int tid) {
+  constexpr int MT = (JN == 1) ? RM / 32 : RM / 32 / (NT / 256);
+  const int rot = ((JN == 1 ? (tid >> 6) : ((tid >> 6) & 3)) * 3) & 15;          // chain_a_body's rotation
+  ring_prefetch<16, 4, JN, MT>(Wp, pf1, tid, rot);
+}
+
+template <int RM, int NT, int JN, bool PRE1 = false>
 __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* __restrict__ rid, const float* __restrict__ w2s,
                                              const uint8_t* __restrict__ inside, const bf16_t* __restrict__ Wp,
                                              const float* __restrict__ bp, const bf16_t* __restrict__ W0,
                                              const float* __restrict__ b0, const bf16_t* __restrict__ W1,
                                              const float* __restrict__ b1, const float* __restrict__ b2,
-                                             bf16_t* __restrict__ attn, float* __restrict__ o) {
+                                             bf16_t* __restrict__ attn, float* __restrict__ o,
+                                             f32x4 (*pf1)[JN] = nullptr, const int* __restrict__ keep_lds = nullptr) {
   constexpr int MT = (JN == 1) ? RM / 32 : RM / 32 / (NT / 256);                  // row tiles per wave
   const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
   const int row0 = (JN == 1) ? 0 : (tid >> 8) * MT * 32;
@@ -235,14 +246,16 @@ __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int g = rid[row0 + mt * 32 + rl];
-    keep[mt] = g >= 0 && inside[max(g, 0)] != 0;                 // dq_decoder.py:585-586
+    // dq_decoder.py:585-586.  keep_lds: the caller already fetched the rows' flags (one per tile row, next to rid) -- as a
+    // global load here, dependent on rid, its round trip sat in front of stage 1's barrier
+    keep[mt] = keep_lds ? keep_lds[row0 + mt * 32 + rl] != 0 : (g >= 0 && inside[max(g, 0)] != 0);
     all[mt] = true;
   }
   __syncthreads();
   // attn = inside * output_proj(samp).  Every stage's bias and the NEXT stage's first weight fragments are requested
   // before the barrier + epilogue that follow its k-loop (ring_prefetch).
   f32x4 pf[4][JN], bvr[JN][4];
-  stage_gemm<MT, 16, 4, JN>(act, Wp, acc, tid, true, rot);
+  stage_gemm<MT, 16, 4, JN, PRE1>(act, Wp, acc, tid, true, rot, 16 * 1024, pf1);
   load_bias<JN>(bp, bvr, tid, MT * 32);
   ring_prefetch<16, 4, JN, MT>(W0, pf, tid, rot + 5);
   __builtin_amdgcn_sched_barrier(0);
