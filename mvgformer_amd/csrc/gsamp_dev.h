@@ -128,60 +128,92 @@ template <int L, int PIPE = 0>
 __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                            const float* __restrict__ xw, const float* __restrict__ r,
                                            const LevelTable& lv, float* __restrict__ sc, int pair, int m, int sub,
-                                           int Lq, int S, int B, float (&acc)[8]) {
+                                           int Lq, int S, int B, float (&acc)[8], const float2* __restrict__ rpre = nullptr) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4;
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
 
-  if (sub < L) *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = *reinterpret_cast<const float2*>(r + ((long)pair * L + sub) * 2);
-  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk
+  // the pair's L reference points: preloaded by the caller (rpre, requested together with the pair's mask byte) or read here
+  float2 rr[L];
 #pragma unroll
-  for (int k = 0; k < (NCHK + 3) / 4; ++k) {
+  for (int l = 0; l < L; ++l) rr[l] = rpre ? rpre[l] : *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
+  if (sub < L) {
+    float2 mine = rr[0];
+#pragma unroll
+    for (int l = 1; l < L; ++l) mine = sub == l ? rr[l] : mine;
+    *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = mine;
+  }
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk.
+  // Round 3: ALL its loads -- 4 G corners + 2 xw vectors for each of the lane's (NCHK + 3) / 4 chunks -- are requested before the
+  // first one is used (lanes without a last chunk fetch chunk NCHK - 1 again and do not store it).  As a loop of "if (chunk <
+  // NCHK) { load, blend, store }" every iteration was its own exec region and round trip: s_memtime showed phase A at 13 400 of
+  // a wavefront's 35 000 cycles, as long as the six gather batches together.  Same arithmetic per chunk: bit-identical.
+  constexpr int NK = (NCHK + 3) / 4;
+  uint4 c00[NK], c10[NK], c01[NK], c11[NK];
+  f32x4 xa[NK], xb[NK];
+  float w00[NK], w10[NK], w01[NK], w11[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int ci = min(sub + 4 * k, NCHK - 1);
+    // G / xw columns are grouped per (16 offsets | 8 logits): group g of a level row = columns [24g, 24g+24) =
+    // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
+    // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
+    const int t = ci / 3, part = ci - 3 * t;
+    const int fg = m * L + t;
+    const int l = fg >> 3;                                               // level row of the reinterpreted view
+    const int col = 24 * (fg & 7) + 8 * part;
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    float refx = rr[0].x, refy = rr[0].y;
+#pragma unroll
+    for (int ll = 1; ll < L; ++ll) {
+      refx = l == ll ? rr[ll].x : refx;
+      refy = l == ll ? rr[ll].y : refy;
+    }
+    const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
+    const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+    const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - x0f, ty = iy - y0f;
+    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+    w00[k] = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
+    w10[k] = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+    w01[k] = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
+    w11[k] = (x1ok && y1ok) ? tx * ty : 0.f;
+    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+    // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
+    const char* g_bytes = reinterpret_cast<const char*>(G);
+    const unsigned gb = ((unsigned)(n * S + lv.start[l]) * 192u + (unsigned)col) * 2u;
+    c00[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x0c) * 384u));
+    c10[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x1c) * 384u));
+    c01[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x0c) * 384u));
+    c11[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x1c) * 384u));
+    const float* xq = xw + ((long)b * Lq + q) * 192 + col;
+    xa[k] = *reinterpret_cast<const f32x4*>(xq);
+    xb[k] = *reinterpret_cast<const f32x4*>(xq + 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
     const int ci = sub + 4 * k;
-    if (ci < NCHK) {
-      // G / xw columns are grouped per (16 offsets | 8 logits): group g of a level row = columns [24g, 24g+24) =
-      // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
-      // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
-      const int t = ci / 3, part = ci - 3 * t;
-      const int fg = m * L + t;
-      const int l = fg >> 3;                                               // level row of the reinterpreted view
-      const int col = 24 * (fg & 7) + 8 * part;
-      const bool is_logit = part == 2;
-      const int H = lv.H[l], W = lv.W[l];
-      const float Wf = (float)W, Hf = (float)H;
-      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
-      const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
-      const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
-      const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
-      const float x0f = floorf(ix), y0f = floorf(iy);
-      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-      const float tx = ix - x0f, ty = iy - y0f;
-      const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
-      const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f, w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
-      const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
-      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
-      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
-      // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
-      const char* g_bytes = reinterpret_cast<const char*>(G);
-      const unsigned gb = ((unsigned)(n * S + lv.start[l]) * 192u + (unsigned)col) * 2u;
-      const uint4 c00 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x0c) * 384u));
-      const uint4 c10 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x1c) * 384u));
-      const uint4 c01 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x0c) * 384u));
-      const uint4 c11 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x1c) * 384u));
-      const float* xq = xw + ((long)b * Lq + q) * 192 + col;
-      const f32x4 xa = *reinterpret_cast<const f32x4*>(xq), xb = *reinterpret_cast<const f32x4*>(xq + 4);
-      const unsigned a4[4] = {c00.x, c00.y, c00.z, c00.w}, b4[4] = {c10.x, c10.y, c10.z, c10.w};
-      const unsigned c4[4] = {c01.x, c01.y, c01.z, c01.w}, d4[4] = {c11.x, c11.y, c11.z, c11.w};
-      float v[8];
+    const int cc = min(ci, NCHK - 1);
+    const int t = cc / 3, part = cc - 3 * t;
+    const bool is_logit = part == 2;
+    const unsigned a4[4] = {c00[k].x, c00[k].y, c00[k].z, c00[k].w}, b4[4] = {c10[k].x, c10[k].y, c10[k].z, c10[k].w};
+    const unsigned c4[4] = {c01[k].x, c01[k].y, c01[k].z, c01[k].w}, d4[4] = {c11[k].x, c11[k].y, c11[k].z, c11[k].w};
+    float v[8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        v[2 * t] = w00 * __uint_as_float(a4[t] << 16) + w10 * __uint_as_float(b4[t] << 16) +
-                   w01 * __uint_as_float(c4[t] << 16) + w11 * __uint_as_float(d4[t] << 16);
-        v[2 * t + 1] = w00 * __uint_as_float(a4[t] & 0xffff0000u) + w10 * __uint_as_float(b4[t] & 0xffff0000u) +
-                       w01 * __uint_as_float(c4[t] & 0xffff0000u) + w11 * __uint_as_float(d4[t] & 0xffff0000u);
-      }
+    for (int u = 0; u < 4; ++u) {
+      v[2 * u] = w00[k] * __uint_as_float(a4[u] << 16) + w10[k] * __uint_as_float(b4[u] << 16) +
+                 w01[k] * __uint_as_float(c4[u] << 16) + w11[k] * __uint_as_float(d4[u] << 16);
+      v[2 * u + 1] = w00[k] * __uint_as_float(a4[u] & 0xffff0000u) + w10[k] * __uint_as_float(b4[u] & 0xffff0000u) +
+                     w01[k] * __uint_as_float(c4[u] & 0xffff0000u) + w11[k] * __uint_as_float(d4[u] & 0xffff0000u);
+    }
+    if (ci < NCHK) {
       float* dst = sc + (is_logit ? 8 * t : LP + 16 * t + 8 * part);
-      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0] + xa[0], v[1] + xa[1], v[2] + xa[2], v[3] + xa[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[0], v[5] + xb[1], v[6] + xb[2], v[7] + xb[3]};
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0] + xa[k][0], v[1] + xa[k][1], v[2] + xa[k][2], v[3] + xa[k][3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[k][0], v[5] + xb[k][1], v[6] + xb[k][2], v[7] + xb[k][3]};
     }
   }
   // quad-private scratch: LDS operations of one wavefront execute in order, only the compiler must not reorder

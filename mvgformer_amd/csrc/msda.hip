@@ -636,12 +636,17 @@ __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, c
   const int slot = pblk * (NT / 4) + wave * 16 + pl;
   if (slot >= n_pairs) return;
   const int pair = order ? order[slot] : slot;
+  // the pair's reference points are requested WITH its mask byte, not after it (one round trip less in front of phase A;
+  // wasted for the masked pairs: 24 bytes each)
+  float2 rpre[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) rpre[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
   if (pair_mask && !pair_mask[pair]) {
     *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
     return;
   }
   float acc[8];
-  gsamp_unit<L, PIPE>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc);
+  gsamp_unit<L, PIPE>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc, rpre);
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
