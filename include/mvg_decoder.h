@@ -66,7 +66,12 @@ const char* mvg_version(void);
  *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
  *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs;
  *   "bin_multi" = 1 | 0 : multi-workgroup binning for large Lq (needs the workspace of mvg_bin_pairs);
- *   "sampchain_map" = n : consecutive 64-row tiles per XCD chunk of the fused sampler + chain A kernel. */
+ *   "sampchain_map" = n : consecutive 64-row tiles per XCD chunk of the fused sampler + chain A kernel;
+ *   "gsamp_pipe" = 0 | 1 | 2 : sampler gather loop (default / double-buffered / LDS window for the coarsest level);
+ *   "f32_split" = 1 | 0 : fp32 GEMMs as six bf16 MFMA products on operands split into three bf16 parts (default) or as
+ *       v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);  "linear_tiles" = 0 | 1 | 2, "linear_xcd" = 1 | 0 : tile shapes and
+ *       XCD-aware tile order of mvg_linear*;  "tri_lanes" = 0 | 1 : one-lane (default) or lane-parallel Jacobi in mvg_triangulate*.
+ * Every knob except f32_split selects bit-identical results (tests/test_hip_parity.py: test_every_kernel_variant_behind_a_tuning_knob). */
 int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
