@@ -71,7 +71,9 @@ const char* mvg_version(void);
  *   "f32_split" = 1 | 0 : fp32 GEMMs as six bf16 MFMA products on operands split into three bf16 parts (default) or as
  *       v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);  "linear_tiles" = 0 | 1 | 2, "linear_xcd" = 1 | 0 : tile shapes and
  *       XCD-aware tile order of mvg_linear*;  "tri_lanes" = 0 | 1 : one-lane (default) or lane-parallel Jacobi in mvg_triangulate*.
- * Every knob except f32_split selects bit-identical results (tests/test_hip_parity.py: test_every_kernel_variant_behind_a_tuning_knob). */
+ * The sampler / binning / GEMM-grid / triangulation knobs select bit-identical results; the chain-geometry knobs change the order
+ * of an fp32 sum (differences at bf16 rounding), f32_split the rounding of the fp32 products (tests/test_hip_parity.py:
+ * test_every_kernel_variant_behind_a_tuning_knob). */
 int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
