@@ -442,43 +442,69 @@ __global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
   float* sc = &scratch[wave][m][0];
 
-  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk, one chunk per lane
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk, one chunk per lane.
+  // All loads of the lane's (NCHK + 7) / 8 chunks are requested before the first is used (lanes without a last chunk fetch
+  // chunk NCHK - 1 again and do not store it), the reference points once per lane: see gsamp_unit (same transformation).
+  constexpr int NK = (NCHK + 7) / 8;
+  float2 rr[L];
 #pragma unroll
-  for (int k = 0; k < (NCHK + 7) / 8; ++k) {
+  for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
+  f32x4 ga[NK][2], gb[NK][2], gc[NK][2], gd[NK][2], gx4[NK][2];
+  float w00[NK], w10[NK], w01[NK], w11[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int ci = min(sub + 8 * k, NCHK - 1);
+    const int t = ci / 3, part = ci - 3 * t;           // group t of the head (= level of its samples), 16 offsets | 8 logits
+    const int fg = m * L + t;
+    const int l = fg >> 3;                             // level row of the reinterpreted view (projattn.py:180-184)
+    const int col = 24 * (fg & 7) + 8 * part;
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    float refx = rr[0].x, refy = rr[0].y;
+#pragma unroll
+    for (int ll = 1; ll < L; ++ll) {
+      refx = l == ll ? rr[ll].x : refx;
+      refy = l == ll ? rr[ll].y : refy;
+    }
+    const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
+    const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+    const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;    // grid_sample, align_corners=False
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - x0f, ty = iy - y0f;
+    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+    w00[k] = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
+    w10[k] = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+    w01[k] = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
+    w11[k] = (x1ok && y1ok) ? tx * ty : 0.f;
+    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+    const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
+    const float* p00 = gp + (long)(y0c * W + x0c) * 192;
+    const float* p10 = gp + (long)(y0c * W + x1c) * 192;
+    const float* p01 = gp + (long)(y1c * W + x0c) * 192;
+    const float* p11 = gp + (long)(y1c * W + x1c) * 192;
+    const float* xq = xw + ((long)b * Lq + q) * 192 + col;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      ga[k][hlf] = *reinterpret_cast<const f32x4*>(p00 + 4 * hlf);
+      gb[k][hlf] = *reinterpret_cast<const f32x4*>(p10 + 4 * hlf);
+      gc[k][hlf] = *reinterpret_cast<const f32x4*>(p01 + 4 * hlf);
+      gd[k][hlf] = *reinterpret_cast<const f32x4*>(p11 + 4 * hlf);
+      gx4[k][hlf] = *reinterpret_cast<const f32x4*>(xq + 4 * hlf);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
     const int ci = sub + 8 * k;
+    const int cc = min(ci, NCHK - 1);
+    const int t = cc / 3, part = cc - 3 * t;
     if (ci < NCHK) {
-      const int t = ci / 3, part = ci - 3 * t;           // group t of the head (= level of its samples), 16 offsets | 8 logits
-      const int fg = m * L + t;
-      const int l = fg >> 3;                             // level row of the reinterpreted view (projattn.py:180-184)
-      const int col = 24 * (fg & 7) + 8 * part;
-      const int H = lv.H[l], W = lv.W[l];
-      const float Wf = (float)W, Hf = (float)H;
-      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
-      const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
-      const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
-      const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;    // grid_sample, align_corners=False
-      const float x0f = floorf(ix), y0f = floorf(iy);
-      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-      const float tx = ix - x0f, ty = iy - y0f;
-      const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
-      const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f, w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
-      const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
-      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
-      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
-      const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
-      const float* p00 = gp + (long)(y0c * W + x0c) * 192;
-      const float* p10 = gp + (long)(y0c * W + x1c) * 192;
-      const float* p01 = gp + (long)(y1c * W + x0c) * 192;
-      const float* p11 = gp + (long)(y1c * W + x1c) * 192;
-      const float* xq = xw + ((long)b * Lq + q) * 192 + col;
       float* dst = sc + (part == 2 ? 8 * t : LP + 16 * t + 8 * part);
 #pragma unroll
-      for (int hlf = 0; hlf < 2; ++hlf) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + 4 * hlf), bq = *reinterpret_cast<const f32x4*>(p10 + 4 * hlf);
-        const f32x4 cq = *reinterpret_cast<const f32x4*>(p01 + 4 * hlf), dq = *reinterpret_cast<const f32x4*>(p11 + 4 * hlf);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xq + 4 * hlf);
-        *reinterpret_cast<f32x4*>(dst + 4 * hlf) = w00 * a + w10 * bq + w01 * cq + w11 * dq + xv;
-      }
+      for (int hlf = 0; hlf < 2; ++hlf)
+        *reinterpret_cast<f32x4*>(dst + 4 * hlf) = w00[k] * ga[k][hlf] + w10[k] * gb[k][hlf] + w01[k] * gc[k][hlf] + w11[k] * gd[k][hlf] + gx4[k][hlf];
     }
   }
   // head-private scratch rows inside one wavefront: LDS operations of a wavefront execute in order
@@ -517,7 +543,12 @@ __global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __
   for (int l = 0; l < L; ++l) {
     const int H = lv.H[l], W = lv.W[l];
     const float Wf = (float)W, Hf = (float)H;
-    const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
+    float refx = rr[0].x, refy = rr[0].y;
+#pragma unroll
+    for (int ll = 1; ll < L; ++ll) {
+      refx = l == ll ? rr[ll].x : refx;
+      refy = l == ll ? rr[ll].y : refy;
+    }
     const float* lvl = vbase + (long)lv.start[l] * C;
     int my_w[4], my_t, my_b, my_x;
     {
