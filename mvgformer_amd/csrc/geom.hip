@@ -228,19 +228,50 @@ __global__ __launch_bounds__(256) void class_head_kernel(const float* __restrict
   if (qi >= nq_total) return;
   const int lane = threadIdx.x & 63;
   float p0 = 0.f, p1 = 0.f;
-  for (int j = 0; j < J; ++j) {
-    const float* t = tgt + ((long)qi * J + j) * C;
-    float a0 = 0.f, a1 = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 tv = *reinterpret_cast<const f32x4*>(t + c);
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + c), w1 = *reinterpret_cast<const f32x4*>(Wc + C + c);
-      a0 += tv[0] * w0[0] + tv[1] * w0[1] + tv[2] * w0[2] + tv[3] * w0[3];
-      a1 += tv[0] * w1[0] + tv[1] * w1[1] + tv[2] * w1[2] + tv[3] * w1[3];
+  if (C == 256) {
+    // the query's J token rows are requested together (16 at a time), then reduced: as one row per iteration this was a chain
+    // of J dependent round trips -- 23 us for 15 joints.  Same sums in the same order per row and per query: bit-identical.
+    constexpr int JB = 16;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + lane * 4), w1 = *reinterpret_cast<const f32x4*>(Wc + C + lane * 4);
+    const float b0 = bc[0], b1 = bc[1];
+    for (int j0 = 0; j0 < J; j0 += JB) {
+      f32x4 tv[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj)
+        tv[jj] = *reinterpret_cast<const f32x4*>(tgt + ((long)qi * J + min(j0 + jj, J - 1)) * C + lane * 4);
+      float a0[JB], a1[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        a0[jj] = 0.f + (tv[jj][0] * w0[0] + tv[jj][1] * w0[1] + tv[jj][2] * w0[2] + tv[jj][3] * w0[3]);
+        a1[jj] = 0.f + (tv[jj][0] * w1[0] + tv[jj][1] * w1[1] + tv[jj][2] * w1[2] + tv[jj][3] * w1[3]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        a0[jj] = wave_sum(a0[jj]) + b0;
+        a1[jj] = wave_sum(a1[jj]) + b1;
+      }
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj)
+        if (j0 + jj < J) {
+          p0 += 1.f / (1.f + expf(-a0[jj]));
+          p1 += 1.f / (1.f + expf(-a1[jj]));
+        }
     }
-    a0 = wave_sum(a0) + bc[0];
-    a1 = wave_sum(a1) + bc[1];
-    p0 += 1.f / (1.f + expf(-a0));
-    p1 += 1.f / (1.f + expf(-a1));
+  } else {
+    for (int j = 0; j < J; ++j) {
+      const float* t = tgt + ((long)qi * J + j) * C;
+      float a0 = 0.f, a1 = 0.f;
+      for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(t + c);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + c), w1 = *reinterpret_cast<const f32x4*>(Wc + C + c);
+        a0 += tv[0] * w0[0] + tv[1] * w0[1] + tv[2] * w0[2] + tv[3] * w0[3];
+        a1 += tv[0] * w1[0] + tv[1] * w1[1] + tv[2] * w1[2] + tv[3] * w1[3];
+      }
+      a0 = wave_sum(a0) + bc[0];
+      a1 = wave_sum(a1) + bc[1];
+      p0 += 1.f / (1.f + expf(-a0));
+      p1 += 1.f / (1.f + expf(-a1));
+    }
   }
   if (lane == 0) {
     p0 /= (float)J;
