@@ -249,6 +249,42 @@ def test_linear_f32_split_form_is_as_close_to_fp64_as_the_exact_form(M, N, K):
         _f32_gemm("split")
 
 
+def test_linear_f32_random_shapes_both_forms():
+    """40 random GEMM shapes (ragged M, any N % 8 == 0, K % 32 == 0 up to 1024, every tile shape of the launcher) with random
+    ReLU / row mask / A + A2: both fp32 forms against the fp64 product."""
+    from mvgformer_amd import ops
+    rs = np.random.RandomState(2024)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7)
+    try:
+        for it in range(40):
+            M = int(rs.choice([1, 7, 63, 64, 65, 127, 129, 500, 1000, 2999, 8191]))
+            N = int(rs.choice([8, 24, 64, 128, 136, 192, 256, 320, 384, 576, 1024]))
+            K = int(rs.choice([32, 64, 96, 256, 512, 1024]))
+            a = torch.randn(M, K, device=DEV, generator=g)
+            a2 = torch.randn(M, K, device=DEV, generator=g) if rs.rand() < 0.3 else None
+            w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+            b = torch.randn(N, device=DEV, generator=g) if rs.rand() < 0.8 else None
+            relu = bool(rs.rand() < 0.5)
+            mask = (torch.rand(M, device=DEV, generator=g) > 0.3).to(torch.uint8) if rs.rand() < 0.5 else None
+            x = a if a2 is None else a + a2
+            ref = x.double() @ w.double().t() + (0 if b is None else b.double())
+            unit = x.double().abs() @ w.double().abs().t() + (0 if b is None else b.double().abs()) + 1e-30
+            if relu:
+                ref = torch.relu(ref)
+            if mask is not None:
+                ref = ref * mask[:, None].double()
+            for form in ("split", "exact"):
+                _f32_gemm(form)
+                got = ops.linear(a, w, b, relu=relu, rowmask=mask, add=a2)
+                err = float(((got.double() - ref).abs() / unit).max())
+                assert err < 2.0 ** -24 * (8 + K ** 0.5), (it, M, N, K, form, err)
+                if mask is not None:
+                    assert float(got[mask == 0].abs().max() if (mask == 0).any() else 0.0) == 0.0
+    finally:
+        _f32_gemm("split")
+
+
 def test_linear_f32_split_form_edges():
     """zeros, powers of two, values that need all three parts, tiny and large magnitudes, ReLU / row mask / A + A2 on load, the
     processing-order form; a non-finite input value stays in its own row."""
