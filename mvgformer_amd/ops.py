@@ -194,9 +194,11 @@ def pack_pyramid(src_views, levels, dtype, out=None):
     if tuple(feat.shape) != (n_img, levels.S, Cc) or feat.dtype != dtype or not feat.is_contiguous():
         raise RuntimeError("pack_pyramid: out must be a contiguous (%d,%d,%d) %s tensor" % (n_img, levels.S, Cc, dtype))
     dst_views = pyramid_level_views(feat, levels)
+    if len(src_views) != levels.L:
+        raise RuntimeError("pack_pyramid: %d feature maps for %d levels" % (len(src_views), levels.L))
     if (ONE_LAUNCH_PACK and all(s.dtype == torch.float32 and s.is_contiguous() and s.is_cuda and tuple(s.shape) ==
                                 (n_img, Cc, int(levels.shapes[l, 0]), int(levels.shapes[l, 1])) and s.data_ptr() != dst_views[l].data_ptr()
-                                for l, s in enumerate(src_views)) and len(src_views) == levels.L):
+                                for l, s in enumerate(src_views))):
         # the reference's hand-over format on every level: one launch for the whole pyramid
         ptrs = (C.c_void_p * levels.L)(*[s.data_ptr() for s in src_views])
         with _timed("pack_level"):
@@ -273,6 +275,20 @@ def linear_ordered(a, w, bias, order, inside, masked_row, relu=False, rowmask=No
         raise RuntimeError("mvg_linear_ordered: fp32 K-contiguous operands required")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    # the kernel indexes a / out through `order` and reads `inside` / `masked_row` unchecked: a stale order (another query count)
+    # would read and write out of bounds
+    if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or out.stride(1) != 1:
+        raise RuntimeError("mvg_linear_ordered: out must be an fp32 (%d, %d) tensor with contiguous rows" % (M, N))
+    if order.dtype != torch.int32 or order.numel() != M or not order.is_contiguous():
+        raise RuntimeError("mvg_linear_ordered: order must be a contiguous int32 tensor with one entry per row (%d)" % M)
+    if inside.dtype != torch.uint8 or inside.numel() != M or not inside.is_contiguous():
+        raise RuntimeError("mvg_linear_ordered: inside must be a contiguous uint8 tensor with one entry per row (%d)" % M)
+    if masked_row.dtype != torch.float32 or masked_row.numel() != N or not masked_row.is_contiguous():
+        raise RuntimeError("mvg_linear_ordered: masked_row must be a contiguous fp32 tensor with %d entries" % N)
+    if rowmask is not None and (rowmask.dtype != torch.uint8 or rowmask.numel() != M or not rowmask.is_contiguous()):
+        raise RuntimeError("mvg_linear_ordered: rowmask must be a contiguous uint8 tensor with one entry per row (%d)" % M)
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise RuntimeError("mvg_linear_ordered: bias must be fp32 with %d entries" % N)
     with _timed("linear_ordered_%dx%dx%d" % (M, N, K)):
       L.check(L.load().mvg_linear_ordered(L.ptr(a), a.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), out.stride(0),
                                         L.ptr(rowmask), 1 if relu else 0, M, N, K, L.ptr(order), L.ptr(inside),

@@ -4,7 +4,11 @@ The reference runs ``model(views, meta)`` eagerly per frame (lib/core/function.p
 several host synchronisations.  Here the whole ``DQDecoder.forward`` -- pyramid packing, the side-stream GEMM train, all layers,
 triangulation, output stacking -- has static shapes and no host synchronisation, so it is captured once and replayed per frame:
 one graph launch on the host (what ``bench.py`` times).  The graph holds raw pointers into its input buffers, the decoder's
-weight caches and its per-layer value / G buffers: ``GraphedDecoder`` owns the inputs and keeps everything alive.
+weight caches and its per-layer value / G buffers: ``GraphedDecoder`` owns the inputs and, from the capture on, holds a
+reference to every one of those tensors (``_pinned``) -- an eager call of the same decoder with another batch, resolution or
+compute dtype re-allocates ``ProjAttn._vp / _G`` and rebuilds cache entries, and without the references the graph would go on
+reading and writing recycled memory.  ``replay()`` also compares the buffers' addresses with the captured ones and re-captures
+when the decoder has moved on to other buffers.
 
     runner = GraphedDecoder(decoder, meta, spatial_shapes, level_start_index, batch=1, num_queries=1024, threshold=0.1)
     for frame in stream:
@@ -52,6 +56,7 @@ class GraphedDecoder:
             self.src_views = [torch.zeros((self.V * batch, C, h, w), dtype=torch.float32, device=dev) for h, w in shapes]
             self.pyramid_views = None
         self.graph, self.outputs = None, None
+        self._pinned, self._captured_ptrs = [], None
 
     # ------------------------------------------------------------------ inputs (device-side copies on the current stream)
     def load(self, src_views=None, tgt=None, query_pos=None, reference_points=None):
@@ -90,7 +95,22 @@ class GraphedDecoder:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.outputs = self._forward()
+        # everything the graph addresses by raw pointer and does not own: the per-layer pyramid products and the cached operands
+        self._pinned = self._graph_operands()
+        self._captured_ptrs = self._buffer_ptrs()
         return self
+
+    def _buffer_ptrs(self):
+        return tuple((None if t is None else (t.data_ptr(), t.dtype, tuple(t.shape)))
+                     for l in self.dec.layers for t in (l.proj_attn._vp, l.proj_attn._G))
+
+    def _graph_operands(self):
+        keep = [self.ctx.cams, self.ctx.feat, getattr(self.ctx, "_buffer", None)]
+        for l in self.dec.layers:
+            keep += [l.proj_attn._vp, l.proj_attn._G]
+            for wc in (l._wc, l.proj_attn._wc):
+                keep += [entry[1] for entry in wc._store.values()]
+        return [t for t in keep if t is not None]
 
     def refresh_weights(self):
         """after the decoder's parameters changed: cached operands are version-checked, the graph is re-captured"""
@@ -99,7 +119,9 @@ class GraphedDecoder:
 
     def replay(self):
         """one decoder forward on the loaded inputs; returns the graph's static output tensors (overwritten by the next replay)"""
-        if self.graph is None:
+        if self.graph is None or self._buffer_ptrs() != self._captured_ptrs:
+            # never captured, or the decoder was run with other shapes / another dtype since (its per-layer buffers were
+            # re-allocated): the old graph is still safe to replay (its buffers are pinned) but no longer the decoder's state
             self.capture()
         self.graph.replay()
         return self.outputs

@@ -11,7 +11,7 @@ The backbone (PoseResNet-50) and the dataset loaders are out of scope (SURVEY.md
 ``--frames-npz`` file holding what the backbone hands to the decoder (``feat0..feat{L-1}`` (F, V, C, H_l, W_l), the per-view
 camera arrays of ``meta`` and optionally ``joints_3d`` / ``joints_3d_vis``), or seeded synthetic frames of the YAML's
 geometry (``mvgformer_amd.synthetic``).  ``--cfg extract:<relative path>`` reads the values of the reference's YAML from
-``tests/golden/yaml_extract.json`` where the reference tree does not exist.
+``mvgformer_amd/data/yaml_extract.json`` where the reference tree does not exist.
 """
 from __future__ import annotations
 
@@ -33,7 +33,7 @@ def load_config(spec):
     from .factory import load_yaml_config
     if not spec.startswith("extract:"):
         return load_yaml_config(spec)
-    with open(os.path.join(ROOT, "tests", "golden", "yaml_extract.json")) as f:
+    with open(os.path.join(ROOT, "mvgformer_amd", "data", "yaml_extract.json")) as f:
         val = json.load(f)[spec[len("extract:"):]]
     return SimpleNamespace(DECODER=SimpleNamespace(**val["DECODER"]), NETWORK=SimpleNamespace(IMAGE_SIZE=val["IMAGE_SIZE"]),
                            MULTI_PERSON=SimpleNamespace(SPACE_SIZE=val["SPACE_SIZE"], SPACE_CENTER=val["SPACE_CENTER"]),

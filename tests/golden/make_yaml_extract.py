@@ -1,6 +1,6 @@
 """Build container only: read every YAML entry point of the reference (configs/**/*.yaml) through
 mvgformer_amd.factory.load_yaml_config and record the hot-path hyper-parameters it yields as
-tests/golden/yaml_extract.json -- values only (no reference text), so that the GPU box, which has no /root/reference,
+mvgformer_amd/data/yaml_extract.json -- values only (no reference text), so that the GPU box, which has no /root/reference,
 can still build the decoders these files describe.  tests/test_abi.py opens the real files when they exist and
 compares them with this extract."""
 import glob
@@ -24,7 +24,7 @@ def main():
     out = {}
     for path in sorted(glob.glob(os.path.join(REF, "configs", "**", "*.yaml"), recursive=True)):
         out[os.path.relpath(path, REF)] = flatten(load_yaml_config(path))
-    with open(os.path.join(ROOT, "tests", "golden", "yaml_extract.json"), "w") as f:
+    with open(os.path.join(ROOT, "mvgformer_amd", "data", "yaml_extract.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("%d YAML entry points" % len(out))
 

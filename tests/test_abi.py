@@ -91,14 +91,14 @@ def test_every_reference_yaml_entry_point_builds_a_decoder():
     """The reference's REAL YAML entry points (configs/panoptic/knn5-lr4-q1024-g8.yaml and the 11 others).  In the build
     container they are opened where they lie under /root/reference and must (a) load through factory.load_yaml_config, (b)
     build a decoder on the supported hot path and (c) equal the committed extract of their values
-    (tests/golden/yaml_extract.json, made by tests/golden/make_yaml_extract.py); on the GPU box, where the reference does
+    (mvgformer_amd/data/yaml_extract.json, made by tests/golden/make_yaml_extract.py); on the GPU box, where the reference does
     not exist, the decoders are built from the extract alone."""
     import json
     import os
     from types import SimpleNamespace
     from mvgformer_amd.factory import build_decoder_from_cfg, load_yaml_config
     here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, "golden", "yaml_extract.json")) as f:
+    with open(os.path.join(os.path.dirname(here), "mvgformer_amd", "data", "yaml_extract.json")) as f:
         extract = json.load(f)
     assert "configs/panoptic/knn5-lr4-q1024-g8.yaml" in extract and len(extract) == 12
     ref = os.environ.get("MVG_REFERENCE", "/root/reference")
@@ -133,3 +133,19 @@ def test_host_level_tables_are_cached_per_tensor_and_follow_in_place_updates():
     assert c[0] is not a[0] and list(c[0]) == [8, 12, 5, 6] and c[1] is a[1]
     other = ops.host_levels(shapes.clone(), starts)            # a different tensor object never sees somebody else's copy
     assert other[0] is not c[0] and list(other[0]) == [8, 12, 5, 6]
+
+
+def test_only_the_product_and_checker_libraries_ship():
+    """The tree that travels to the GPU box holds exactly two kinds of shared objects: the product (libmvgformer_hip.so) and the
+    oracle's C checker (libmsda_ref.so, oracle/_ref/*).  Experiment builds left in the package directory would ship with every
+    push and could be loaded by accident."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    allowed = {os.path.join("mvgformer_amd", "libmvgformer_hip.so"), os.path.join("oracle", "libmsda_ref.so")}
+    found = set()
+    for base, dirs, files in os.walk(root):
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__", ".pytest_cache", "_ref")]
+        for name in files:
+            if name.endswith(".so") or ".so." in name:
+                found.add(os.path.relpath(os.path.join(base, name), root))
+    assert found <= allowed, sorted(found - allowed)

@@ -55,3 +55,30 @@ def test_producer_in_place_pyramid_and_weight_refresh():
         want2 = dec(c.tgt, c.reference_points, c.src_views, c.meta, c.spatial_shapes, c.level_start_index, None,
                     query_pos=c.query_pos, threshold=0.1)
     assert all(torch.equal(x, y) for x, y in zip(b, want2[:4])) and not torch.equal(b[0], a[0])
+
+
+def test_graph_survives_an_eager_call_with_other_shapes_on_the_same_decoder():
+    """the captured graph addresses ProjAttn._vp / _G and the cached operands by raw pointer.  An eager forward of
+    the same decoder with another compute dtype / resolution re-allocates them; the runner pins what it captured and re-captures
+    when the decoder has moved to other buffers -- results stay those of the eager forward."""
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from mvgformer_amd.serving import GraphedDecoder
+    c = case_to_device(build_case("mini5", seed=7, layers=2), DEV)
+    dec = build_decoder_for_case(c, DEV, dtype=torch.bfloat16)
+    run = GraphedDecoder(dec, c.meta, c.spatial_shapes, c.level_start_index, 1, c.NQ, 0.1)
+    run.load(src_views=c.src_views, tgt=c.tgt, query_pos=c.query_pos, reference_points=c.reference_points)
+    first = [t.clone() for t in run.replay()[:4]]
+    held = [t.data_ptr() for t in run._pinned]
+    assert held and all(l.proj_attn._vp.data_ptr() in held for l in dec.layers)
+    # another scene through the same decoder object: other map shapes -> the per-layer buffers are re-allocated
+    small = [s[:, :, : s.shape[2] // 2, :].contiguous() for s in c.src_views]
+    shapes = torch.tensor([[s.shape[2], s.shape[3]] for s in small], dtype=torch.long, device=DEV)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    with torch.no_grad():
+        dec(c.tgt, c.reference_points, small, c.meta, shapes, starts, None, query_pos=c.query_pos, threshold=0.1)
+        junk = [torch.full((1 << 22,), 7.0, device=DEV) for _ in range(8)]      # recycle whatever was freed
+    torch.cuda.synchronize()
+    assert run._buffer_ptrs() != run._captured_ptrs
+    again = [t.clone() for t in run.replay()[:4]]
+    del junk
+    assert all(torch.equal(x, y) for x, y in zip(first, again))
