@@ -274,6 +274,41 @@ int mvg_msda_gsamp_chain(const void* vh, const void* G, const float* xw, const f
                          const void* W1, const float* b1, const float* W2, const float* b2, void* attn, float* o,
                          const float* o_masked, int N_img, int Lq, int L, int S, int B, void* stream);
 
+/* ---- fp32 path as fused kernels ("f32s": fp32 storage, fp32-accurate products on the bf16 matrix pipe; csrc/f32s.hip) --------
+ * The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75 dispatches float / double only; the Linears of
+ * lib/models/dq_decoder.py:763-848,659-717 and lib/models/ops/modules/projattn.py:169,180-181,203 are fp32 nn.Linear).  These
+ * entry points keep fp32 tensors at every boundary and form every product as six bf16 MFMAs on operands split into three bf16
+ * parts (x = h + m + l exactly; the dropped cross terms are below 2^-25 |a w|: error against the fp64 product not above an fp32
+ * fmaf chain's, tests/test_hip_parity.py).  Weight operands W*_planes: the three bf16 parts of the nn.Linear weight, each in the
+ * MFMA-fragment order of mvg_chain_attn_pose (mvgformer_amd.ops.swizzle_weight), part p at element offset p * N * K, N padded to
+ * a multiple of 256 with zero rows (mvgformer_amd.ops.split_swizzle_weight).  A non-finite or > 3.39e38 input value makes its
+ * output row NaN (as in mvg_linear's split form). */
+
+/* value = feat @ Wv^T + bv  (rows, 256)  and  G = feat @ Wg^T  (rows, n_g)  in one pass over the packed pyramid feat (rows, 256):
+ * the value projection of projattn.py:169 and the pyramid side of the offsets / logits Linear (projattn.py:180-181 through
+ * Linear(bilinear(feat) + x) = bilinear(feat W^T) + (x W^T + b), see mvg_msda_gfused_f32).  n_g: multiple of 32, <= 256. */
+int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
+                     float* G, int64_t rows, int n_g, void* stream);
+
+/* mvg_chain_attn_pose in fp32 (dq_decoder.py:585-588,659-690): samp / attn (rows, 256) f32, o (rows, 3) f32; Wp, W0, W1 planes
+ * of the (256, 256) weights; W2 (3, 256) f32; order / o_masked as in mvg_chain_attn_pose (o_masked: this entry point run on one
+ * masked row).  Replaces mvg_linear_ordered x 3 + mvg_rowdot3 of the unfused fp32 path. */
+int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
+                             const float* b0, const void* W1, const float* b1, const float* W2, const float* b2,
+                             float* attn, float* o, const int32_t* order, const float* o_masked, int rows, void* stream);
+
+/* mvg_chain_update_ffn_class in fp32 (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-908): attn (V, B*NQ*J, 256)
+ * f32; Wu (256,256), W1 (1024,256), W2 (256,1024), W_next (n_next padded to 256, 256) as planes; everything else as in
+ * mvg_chain_update_ffn_class (n_next: multiple of 32).  Replaces mvg_mean_views + mvg_linear x 3 (+ the next layer's query-term
+ * GEMM) + mvg_add_layernorm x 2 + mvg_class_head of the unfused fp32 path. */
+int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu,
+                                    const float* g2, const float* be2, const void* W1, const float* b1,
+                                    const void* W2, const float* b2, const float* g3, const float* be3,
+                                    const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
+                                    float* tgt_out, float* prob, uint8_t* valid, int* any_valid,
+                                    const float* query_pos, const void* W_next, const float* b_next,
+                                    float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream);
+
 /* Fused bf16 chain per joint token (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-908):
  *   t1 = LN2(tgt + Wu mean_v(attn_v) + bu);  tgt' = LN3(t1 + W2 relu(W1 t1 + b1) + b2) (has_ffn) else t1;
  *   prob = mean_j sigmoid(Wc tgt' + bc);  valid = prob[...,1] > threshold (or forced_valid).

@@ -1,0 +1,628 @@
+// fp32 path of the decoder layer as fused kernels ("f32s": fp32 storage, products on the bf16 matrix pipe from 3-way split
+// operands -- f32s_dev.h).  The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75, the Linears of
+// lib/models/dq_decoder.py:763-848,659-717); rounds 1-3 ran it as 17 launches per layer with every intermediate in HBM.
+//
+//   mvg_pyramid_f32s             value = feat Wv^T + bv  and  G = feat [Wo; Wa]^T  in ONE pass over the pyramid
+//                                (projattn.py:169 and the pyramid side of :180-181): a 64-row tile is split once, 14 column
+//                                blocks are produced from it; persistent workgroups, the next tile's rows in flight.
+//   mvg_chain_attn_pose_f32s     chain A: attn = inside * (samp Wp^T + bp) -> stored; o = pose MLP(attn)   (dq_decoder.py:585-588,659-690)
+//   mvg_chain_update_ffn_class_f32s   chain B: view mean -> update Linear -> +tgt -> LN2 -> FFN -> LN3 -> class head -> next layer's
+//                                query term (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-893)
+//
+// Geometry shared by the three: 512 threads = 8 wavefronts, one workgroup per CU (the three activation planes of a 64-row tile
+// are 101 KB of LDS), wavefront w owns the 32-column block w of every 256-column weight block and both 32-row blocks of the
+// tile.  Weight operands: three bf16 planes (h, m, l), each in ops.swizzle_weight order, plane p at p * N * K elements.
+#include <algorithm>
+
+#include "common.h"
+
+#include "f32s_dev.h"
+
+namespace {
+
+using namespace f32s;
+
+constexpr int RM = 64;                       // rows per tile
+constexpr int PLANE = RM * PLP;              // bytes per activation plane
+constexpr int NT = 512;
+
+// ------------------------------------------------------------------------------------------------------------------
+// pyramid products.  The MFMA operands are swapped against the chains (activations first): a lane then holds one output
+// COLUMN and 16 rows of it, so every store instruction writes two full 128-byte lines of the row-major outputs.
+template <int KSTEPS, int RING>
+__device__ __forceinline__ void stage_swapped(const char* __restrict__ act, const bf16_t* __restrict__ wp, long wplane,
+                                              f32x16 (&acc)[2], int rot, int lane) {
+  const int rl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+  f32x4 ring[RING][3];
+#pragma unroll
+  for (int p = 0; p < RING; ++p) {
+    const int kq = (p + rot) & (KSTEPS - 1);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) ring[p][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
+  }
+  const char* arow = act + rl * PLP + 16 * h;
+  f32x4 a_nxt[2][3];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * PLANE + mt * 32 * PLP + (rot & (KSTEPS - 1)) * 32);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    bf16x8 a[2][3], b[3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[mt][s] = __builtin_bit_cast(bf16x8, a_nxt[mt][s]);
+    if (ks + 1 < KSTEPS) {
+      const int kn = (ks + 1 + rot) & (KSTEPS - 1);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * PLANE + mt * 32 * PLP + kn * 32);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b[s] = __builtin_bit_cast(bf16x8, ring[ks % RING][s]);
+    if (ks + RING < KSTEPS) {
+      const int kq = (ks + RING + rot) & (KSTEPS - 1);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) ring[ks % RING][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
+    }
+    constexpr int TB[6] = {2, 0, 1, 1, 0, 0}, TA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][TA[t]], b[TB[t]], acc[mt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// acc[mt][4 g + t] = out[row 32 mt + 8 g + 4 h + t][column rl of the block]
+__device__ __forceinline__ void store_swapped(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[2],
+                                              float bias, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long row = r0 + 32 * mt + 8 * (e >> 2) + 4 * h + (e & 3);
+      if (row < rows) out[row * ld + col] = acc[mt][e] + bias;
+    }
+}
+
+__global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv,
+                                                          const float* __restrict__ bv, const bf16_t* __restrict__ Wg,
+                                                          float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long ntiles = (rows + RM - 1) / RM;
+  const int rot = (w * 3) & 15;
+  const bf16_t* wpv = frag_ptr(Wv, 0, w, 16, lane);
+  const bf16_t* wpg = frag_ptr(Wg, 0, w, 16, lane);
+  const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
+  const bool has_g = 32 * w < ng;
+  // (the weights do not change from tile to tile: without the empty asm below hipcc hoists all 96 fragment loads out of the
+  // tile loop -- 384 registers, spilled)
+  f32x4 x[8];
+  long tile = blockIdx.x;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * NT + tid;
+      x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
+    }
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * RM;
+    asm volatile("" : "+v"(wpv), "+v"(wpg));
+    __syncthreads();                               // the previous tile's stages have read the planes
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * NT + tid;
+      store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, x[i]);
+    }
+    __syncthreads();
+    const long nxt = tile + gridDim.x;
+    if (nxt < ntiles) {                            // the next tile's rows: in flight under this tile's stages
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid;
+        x[i] = *reinterpret_cast<const f32x4*>(feat + min(nxt * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
+      }
+    }
+    f32x16 acc[2];
+    stage_swapped<16, 4>(act, wpv, 65536, acc, rot, lane);
+    store_swapped(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, lane);
+    if (has_g) {
+      stage_swapped<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+      store_swapped(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// chain A
+__global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restrict__ samp, const uint8_t* __restrict__ inside,
+                                                          const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
+                                                          const bf16_t* __restrict__ W0, const float* __restrict__ b0,
+                                                          const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ W2, const float* __restrict__ b2,
+                                                          float* __restrict__ attn, float* __restrict__ o,
+                                                          const int* __restrict__ order, const float* __restrict__ o_masked,
+                                                          int R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;
+  int* rid = reinterpret_cast<int*>(smem + 3 * PLANE);          // global row of every tile row (-1: past the end)
+  int* keepf = rid + RM;                                        // in-image flag of every tile row
+  float* w2s = reinterpret_cast<float*>(keepf + RM);            // last pose layer (3 x 256 f32)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31;
+  const int ntiles = (R + RM - 1) / RM;
+  const int rot = (w * 3) & 15;
+  for (int i = tid; i < 768; i += NT) w2s[i] = W2[i];
+  const bf16_t* wp1 = frag_ptr(Wp, 0, w, 16, lane);
+  const bf16_t* wp2 = frag_ptr(W0, 0, w, 16, lane);
+  const bf16_t* wp3 = frag_ptr(W1, 0, w, 16, lane);
+  const float m0 = o_masked ? o_masked[0] : 0.f, m1 = o_masked ? o_masked[1] : 0.f, m2 = o_masked ? o_masked[2] : 0.f;
+  const float bo0 = b2[0], bo1 = b2[1], bo2 = b2[2];
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * RM;
+    asm volatile("" : "+v"(wp1), "+v"(wp2), "+v"(wp3));         // no hoisting of the (tile-invariant) weight loads: 576 registers
+    __syncthreads();                                            // rid / planes of the previous tile are no longer read
+    bool mine = false;
+    if (tid < RM) {
+      const int slot = r0 + tid;
+      const int g = slot < R ? (order ? order[slot] : slot) : -1;
+      rid[tid] = g;
+      mine = g >= 0 && inside[g] != 0;
+      keepf[tid] = mine ? 1 : 0;
+    }
+    const bool any_inside = __syncthreads_or(mine) != 0;
+    if (!any_inside && o_masked) {                              // all-masked tile: attn = 0, o = the MLP of a zero row
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid, g = rid[c >> 6];
+        if (g >= 0) *reinterpret_cast<f32x4*>(attn + (long)g * 256 + (c & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (tid < RM && rid[tid] >= 0) {
+        float* og = o + (long)rid[tid] * 3;
+        og[0] = m0;
+        og[1] = m1;
+        og[2] = m2;
+      }
+      continue;
+    }
+    f32x4 pf[4][3];
+    ring_prefetch<16, 4>(wp1, 65536, pf, rot);                  // stage 1's first fragments, in flight under the tile load
+    {
+      f32x4 x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid;
+        x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid[c >> 6], 0) * 256 + (c & 63) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid;
+        store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, rid[c >> 6] >= 0 ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+    }
+    bool keep[2], all[2] = {true, true};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) keep[mt] = keepf[mt * 32 + rl] != 0;                  // dq_decoder.py:585-586
+    __syncthreads();
+
+    // attn = inside * output_proj(samp)
+    f32x16 acc[2];
+    f32x4 bvr[4];
+    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp1, 65536, acc, nullptr, true, rot, lane, pf);
+    load_bias(bp + 32 * w, bvr, lane);
+    ring_prefetch<16, 4>(wp2, 65536, pf, (rot + 5) & 15);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, false, keep, lane);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                               // attn rows -> global (needed for the view mean): 32 B per thread
+      const int c = i * NT + tid, row = c >> 5, ch = c & 31, g = rid[row];
+      const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + ch * 16);
+      const uint4 mm = *reinterpret_cast<const uint4*>(act + PLANE + row * PLP + ch * 16);
+      const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * PLANE + row * PLP + ch * 16);
+      if (g >= 0) {
+        float* dst = attn + (long)g * 256 + ch * 8;
+        *reinterpret_cast<f32x4*>(dst) = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
+        *reinterpret_cast<f32x4*>(dst + 4) = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
+      }
+    }
+    // pose_embed MLP layers 0, 1 (ReLU)
+    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp2, 65536, acc, nullptr, true, (rot + 5) & 15, lane, pf);
+    load_bias(b0 + 32 * w, bvr, lane);
+    ring_prefetch<16, 4>(wp3, 65536, pf, (rot + 10) & 15);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
+    __syncthreads();
+    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp3, 65536, acc, nullptr, true, (rot + 10) & 15, lane, pf);
+    load_bias(b1 + 32 * w, bvr, lane);
+    __syncthreads();
+    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
+    __syncthreads();
+    // last layer (3 outputs): 8 threads per row, 32 columns each in column order, then the balanced tree over the 8 lanes
+    {
+      const int row = tid >> 3, part = tid & 7;
+      float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 32; c += 8) {
+        const int col = part * 32 + c;
+        const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + col * 2);
+        const uint4 mm = *reinterpret_cast<const uint4*>(act + PLANE + row * PLP + col * 2);
+        const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * PLANE + row * PLP + col * 2);
+        const f32x4 va = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
+        const f32x4 vb = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col);
+          const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col + 4);
+          a3[k] += va[0] * wa[0] + va[1] * wa[1] + va[2] * wa[2] + va[3] * wa[3] + vb[0] * wb[0] + vb[1] * wb[1] +
+                   vb[2] * wb[2] + vb[3] * wb[3];
+          asm volatile("" : "+v"(a3[k]));          // keep the accumulators scalar (chain_dev.h: packed-f32 miscompare)
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float v = a3[k];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+        a3[k] = v;
+      }
+      if (part == 0 && rid[row] >= 0) {
+        float* og = o + (long)rid[row] * 3;
+        og[0] = a3[0] + bo0;
+        og[1] = a3[1] + bo1;
+        og[2] = a3[2] + bo2;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// chain B: one workgroup = 4 person-queries x 15 joints (60 token rows in a 64-row tile).
+// Row statistics (LayerNorm, class head) live in the accumulator layout -- lane (rl, h) of wavefront w holds columns
+// 32 w + 8 g + 4 h + t of rows rl and 32 + rl -- and are completed across the 8 wavefronts through a (64 x 8) LDS table
+// summed in wavefront order by every reader (a fixed order: results do not depend on timing).
+constexpr int HPLANE = RM * PLP128;          // bytes per plane of the FFN's hidden chunk (128 columns)
+constexpr int FCH = 128;                     // hidden columns per FFN chunk
+
+__device__ __forceinline__ float row_total(const float* __restrict__ part, int row) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(part + row * 8), b = *reinterpret_cast<const f32x4*>(part + row * 8 + 4);
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+}
+
+// x[mt][g] (4 columns each) of rows rl, 32 + rl -> LayerNorm over the 256 columns of the row, in place
+__device__ __forceinline__ void layernorm_rows(f32x4 (&x)[2][4], const float* __restrict__ gamma_cb, const float* __restrict__ beta_cb,
+                                               float* __restrict__ part, float* __restrict__ part2, int lane, int w) {
+  const int rl = lane & 31, h = lane >> 5;
+  float s[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v += (x[mt][g][0] + x[mt][g][1]) + (x[mt][g][2] + x[mt][g][3]);
+    v += __shfl_xor(v, 32, 64);
+    s[mt] = v;
+    if (h == 0) part[(mt * 32 + rl) * 8 + w] = v;
+  }
+  __syncthreads();
+  float q[2], mean[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    mean[mt] = row_total(part, mt * 32 + rl) * (1.f / 256.f);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      x[mt][g] = x[mt][g] - mean[mt];
+      v += (x[mt][g][0] * x[mt][g][0] + x[mt][g][1] * x[mt][g][1]) + (x[mt][g][2] * x[mt][g][2] + x[mt][g][3] * x[mt][g][3]);
+    }
+    v += __shfl_xor(v, 32, 64);
+    q[mt] = v;
+    if (h == 0) part2[(mt * 32 + rl) * 8 + w] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const float rstd = 1.f / sqrtf(row_total(part2, mt * 32 + rl) * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma_cb + 8 * g + 4 * h), be = *reinterpret_cast<const f32x4*>(beta_cb + 8 * g + 4 * h);
+      x[mt][g] = x[mt][g] * rstd * ga + be;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
+    const float* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu,
+    const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
+    const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+    const float* __restrict__ b2, const float* __restrict__ g3, const float* __restrict__ be3,
+    const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
+    float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
+    const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
+    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;                                   // 3 planes x 64 rows x 256 columns: mean, then t1, then tgt' + query_pos
+  char* hb = smem + 3 * PLANE;                        // 3 planes x 64 rows x 128 columns: FFN hidden chunk
+  float* part = reinterpret_cast<float*>(hb + 3 * HPLANE);
+  float* part2 = part + RM * 8;
+  float* pr = part2 + RM * 8;                         // per-row class probabilities (64 x 2)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
+  const int qpt = RM / J, rpt = qpt * J;
+  const int q0 = blockIdx.x * qpt, r0 = q0 * J;
+  const int nrow = min(rpt, rows - r0);
+  const int rot = (w * 3) & 15;
+  const long colb = 32 * w;                           // the wavefront's column block
+
+  // residual rows in the accumulator layout, requested long before their use
+  f32x4 tg[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      tg[mt][g] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(mt * 32 + rl, nrow - 1)) * 256 + colb + 8 * g + 4 * h);
+
+  // ---- mean over views (dq_decoder.py:770) -> planes
+  {
+    f32x4 s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < V; ++v) {
+      f32x4 xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid;
+        xv[i] = *reinterpret_cast<const f32x4*>(attn + ((long)v * rows + r0 + min(c >> 6, nrow - 1)) * 256 + (c & 63) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += xv[i];
+    }
+    const float Vf = (float)V;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * NT + tid, row = c >> 6;
+      f32x4 m = {s[i][0] / Vf, s[i][1] / Vf, s[i][2] / Vf, s[i][3] / Vf};
+      if (row >= nrow) m = f32x4{0.f, 0.f, 0.f, 0.f};
+      store_split4<PLP>(act, PLANE, row, (c & 63) * 4, m);
+    }
+  }
+  __syncthreads();
+
+  // ---- t1 = LN2(tgt + feature_update_mlp(mean))   (dq_decoder.py:773-778)
+  f32x16 acc[2];
+  f32x4 bvr[4];
+  stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, nullptr, true, rot, lane);
+  load_bias(bu + colb, bvr, lane);
+  f32x4 t1[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) t1[mt][g][t] = acc[mt][4 * g + t] + bvr[g][t];
+      if (mt * 32 + rl < nrow) t1[mt][g] += tg[mt][g];
+    }
+  layernorm_rows(t1, g2 + colb, be2 + colb, part, part2, lane, w);      // (its first barrier: every wavefront is done reading `act`)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
+  __syncthreads();
+
+  f32x4 y[2][4];
+  if (has_ffn) {
+    // ---- FFN (mvp_decoder.py:94-98): Y = sum_c relu(t1 W1_c^T + b1_c) W2[:, c]^T over hidden chunks of 128 columns.
+    // First GEMM of a chunk: wavefront = (row block w & 1, 32 hidden columns w >> 1); second: all 64 rows x output block w.
+    f32x16 accy[2];
+    const int mt1 = w & 1, cb4 = w >> 1;
+    const bool one[1] = {true};
+#pragma unroll 1
+    for (int c = 0; c < 1024 / FCH; ++c) {
+      f32x16 a1[1], a2;
+      stage<1, 16, PLP>(act, PLANE, 32 * mt1, frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane), 1024 * 256, a1, &a2, true, rot, lane);
+      a1[0] += a2;
+      load_bias(b1 + c * FCH + 32 * cb4, bvr, lane);
+      __syncthreads();                                              // the previous chunk's second GEMM has read hb
+      write_planes<1, PLP128>(hb, HPLANE, 32 * mt1, 32 * cb4, a1, bvr, true, one, lane);
+      __syncthreads();
+      stage<2, 8, PLP128>(hb, HPLANE, 0, frag_ptr(W2, 0, w, 64, lane) + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0,
+                          rot & 7, lane);
+    }
+    load_bias(b2 + colb, bvr, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[mt][g][t] = t1[mt][g][t] + (accy[mt][4 * g + t] + bvr[g][t]);
+    layernorm_rows(y, g3 + colb, be3 + colb, part, part2, lane, w);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) y[mt][g] = t1[mt][g];
+  }
+
+  // ---- tgt' -> global; class head (dq_decoder.py:889-893): per-row logits, completed across the wavefronts
+  {
+    float c0[2], c1[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (mt * 32 + rl < nrow)
+          *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + mt * 32 + rl) * 256 + colb + 8 * g + 4 * h) = y[mt][g];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + colb + 8 * g + 4 * h);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + colb + 8 * g + 4 * h);
+        a0 += (y[mt][g][0] * w0[0] + y[mt][g][1] * w0[1]) + (y[mt][g][2] * w0[2] + y[mt][g][3] * w0[3]);
+        a1 += (y[mt][g][0] * w1[0] + y[mt][g][1] * w1[1]) + (y[mt][g][2] * w1[2] + y[mt][g][3] * w1[3]);
+      }
+      a0 += __shfl_xor(a0, 32, 64);
+      a1 += __shfl_xor(a1, 32, 64);
+      c0[mt] = a0;
+      c1[mt] = a1;
+    }
+    __syncthreads();                                                // part / part2 of the last LayerNorm have been read
+    if (h == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        part[(mt * 32 + rl) * 8 + w] = c0[mt];
+        part2[(mt * 32 + rl) * 8 + w] = c1[mt];
+      }
+    }
+    __syncthreads();
+    if (tid < RM) {
+      pr[2 * tid] = 1.f / (1.f + expf(-(row_total(part, tid) + bc[0])));
+      pr[2 * tid + 1] = 1.f / (1.f + expf(-(row_total(part2, tid) + bc[1])));
+    }
+    __syncthreads();
+    if (tid < qpt && q0 + tid < nq_total) {
+      float p0 = 0.f, p1 = 0.f;
+      for (int j = 0; j < J; ++j) {
+        p0 += pr[2 * (tid * J + j)];
+        p1 += pr[2 * (tid * J + j) + 1];
+      }
+      p0 /= (float)J;
+      p1 /= (float)J;
+      const int qi = q0 + tid;
+      prob[2 * (long)qi] = p0;
+      prob[2 * (long)qi + 1] = p1;
+      const bool ok = forced ? (forced[qi] != 0) : (p1 > threshold);                   // dq_decoder.py:605
+      valid[qi] = ok ? 1 : 0;
+      if (ok) atomicOr(any_valid, 1);
+    }
+  }
+  if (Wn) {
+    // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets / logits Linear
+    //      (projattn.py:180-181) while the rows are still on the CU.  Every wavefront passed the barriers above: `act` is free.
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 x = y[mt][g];
+        if (qpos)
+          x += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(mt * 32 + rl, nrow - 1)) * 256 + colb + 8 * g + 4 * h);
+        store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, x);
+      }
+    __syncthreads();
+    if (colb < n_next) {
+      stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, nullptr, true, (rot + 7) & 15, lane);
+      load_bias(bn + colb, bvr, lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (mt * 32 + rl < nrow) {
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = acc[mt][4 * g + t] + bvr[g][t];
+            *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + mt * 32 + rl) * n_next + colb + 8 * g + 4 * h) = v;
+          }
+    }
+  }
+}
+
+template <typename K>
+int configure_lds(K kernel, size_t lds, bool (&configured)[MVG_MAX_DEVICES]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
+  if (!configured[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured[dev] = true;
+  }
+  return 0;
+}
+
+int cu_count() {
+  static int cus[MVG_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+}  // namespace
+
+int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
+
+extern "C" int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
+                                float* G, int64_t rows, int n_g, void* stream) {
+  if (!feat || !Wv_planes || !Wg_planes || !value || !G || rows < 0 || n_g <= 0 || n_g > 256 || n_g % 32 != 0) return MVG_E_BADARG;
+  if (rows == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(G) |
+       reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
+    return MVG_E_BADARG;
+  const size_t lds = 3 * PLANE;
+  static bool configured[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&pyramid_f32s_kernel, lds, configured)) return rc;
+  const long ntiles = (rows + RM - 1) / RM;
+  const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
+  hipLaunchKernelGGL(pyramid_f32s_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, bv,
+                     (const bf16_t*)Wg_planes, value, G, (long)rows, n_g);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
+                                        const float* b0, const void* W1, const float* b1, const float* W2, const float* b2,
+                                        float* attn, float* o, const int32_t* order, const float* o_masked, int rows,
+                                        void* stream) {
+  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
+  if (rows == 0) return 0;
+  const size_t lds = 3 * PLANE + 2 * RM * sizeof(int) + 768 * sizeof(float);
+  static bool configured[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&chain_a_f32s_kernel, lds, configured)) return rc;
+  const int ntiles = (rows + RM - 1) / RM;
+  const int grid = std::min(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
+  hipLaunchKernelGGL(chain_a_f32s_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp, bp,
+                     (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu,
+                                               const float* g2, const float* be2, const void* W1, const float* b1,
+                                               const void* W2, const float* b2, const float* g3, const float* be3,
+                                               const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
+                                               float* tgt_out, float* prob, uint8_t* valid, int* any_valid,
+                                               const float* query_pos, const void* W_next, const float* b_next,
+                                               float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream) {
+  if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
+  if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
+  if (V <= 0 || J <= 0 || J > 64 || B < 0 || NQ < 0) return MVG_E_BADARG;
+  if (W_next && (!b_next || !xw_next || n_next <= 0 || n_next > 256 || n_next % 32 != 0)) return MVG_E_BADARG;
+  const int nq_total = B * NQ, rows = nq_total * J;
+  if (rows == 0) return 0;
+  const int qpt = RM / J;
+  const size_t lds = 3 * PLANE + 3 * HPLANE + 2 * RM * 8 * sizeof(float) + RM * 2 * sizeof(float);
+  static bool configured[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&chain_b_f32s_kernel, lds, configured)) return rc;
+  hipLaunchKernelGGL(chain_b_f32s_kernel, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, (hipStream_t)stream, attn, V, tgt,
+                     (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc, threshold,
+                     forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next, n_next,
+                     rows, J, nq_total, has_ffn);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1091,6 +1091,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
 extern int g_chain_rm;
 extern int g_linear_tiles;
 extern int g_f32_split;
+extern int g_f32s_grid;
 extern int g_tri_lanes;
 extern int g_linear_xcd;
 extern int g_chain_waves;
@@ -1114,6 +1115,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "linear_xcd") && (value == 0 || value == 1)) { g_linear_xcd = value; return 0; }
   if (!strcmp(key, "tri_lanes") && (value == 0 || value == 1)) { g_tri_lanes = value; return 0; }
   if (!strcmp(key, "f32_split") && (value == 0 || value == 1)) { g_f32_split = value; return 0; }
+  if (!strcmp(key, "f32s_grid") && value >= 0 && value <= 4096) { g_f32s_grid = value; return 0; }
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128 || value == 256)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }

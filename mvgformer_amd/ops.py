@@ -459,6 +459,121 @@ def swizzle_weight(w):
     return t.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)
 
 
+def split_swizzle_weight(w, pad_rows_to=256):
+    """fp32 nn.Linear weight (N, K) -> the operand of the f32s kernels (csrc/f32s.hip): its three bf16 parts h = bf16(w),
+    m = bf16(w - h), l = bf16(w - h - m) (round to nearest even at each step, as the kernels split the activations), each
+    in swizzle_weight order, concatenated (part p at element offset p * Np * K; N zero-padded to a multiple of 256)."""
+    w = w.detach().float()
+    N, K = w.shape
+    Np = (N + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+    if Np != N:
+        w = torch.cat([w, w.new_zeros(Np - N, K)], 0)
+    h = w.to(torch.bfloat16)
+    r1 = w - h.float()
+    m = r1.to(torch.bfloat16)
+    l = (r1 - m.float()).to(torch.bfloat16)
+    return torch.cat([swizzle_weight(p) for p in (h, m, l)])
+
+
+def pyramid_f32s(feat, Wv_planes, bv, Wg_planes, n_g, value=None, G=None):
+    """value (n_img, S, 256) f32 = feat @ Wv^T + bv and G (n_img * S, n_g) f32 = feat @ Wg^T in one pass over the packed fp32
+    pyramid feat (n_img, S, 256) (include/mvg_decoder.h: mvg_pyramid_f32s)."""
+    n_img, S, Cc = feat.shape
+    if feat.dtype != torch.float32 or Cc != 256 or not feat.is_contiguous():
+        raise RuntimeError("mvg_pyramid_f32s: contiguous fp32 (n_img, S, 256) pyramid required")
+    rows = n_img * S
+    for t, n in ((Wv_planes, 3 * 256 * 256), (Wg_planes, 3 * 256 * 256)):
+        if t.dtype != torch.bfloat16 or t.numel() != n or not t.is_contiguous():
+            raise RuntimeError("mvg_pyramid_f32s: weight planes from split_swizzle_weight required")
+    if value is None:
+        value = torch.empty((n_img, S, 256), dtype=torch.float32, device=feat.device)
+    if G is None:
+        G = torch.empty((rows, n_g), dtype=torch.float32, device=feat.device)
+    assert value.dtype == torch.float32 and value.numel() == rows * 256 and value.is_contiguous()
+    assert G.dtype == torch.float32 and tuple(G.shape) == (rows, n_g) and G.is_contiguous()
+    with _timed("pyramid_f32s"):
+      L.check(L.load().mvg_pyramid_f32s(L.ptr(feat), L.ptr(Wv_planes), L.ptr(bv), L.ptr(Wg_planes), L.ptr(value), L.ptr(G),
+                                        rows, n_g, L.stream_ptr()), "mvg_pyramid_f32s")
+    return value, G
+
+
+def chain_attn_pose_f32s(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
+    """fp32 chain A (include/mvg_decoder.h: mvg_chain_attn_pose_f32s): samp (rows, 256) f32 -> (attn f32 (rows, 256),
+    o f32 (rows, 3)); Wp / W0 / W1 from split_swizzle_weight."""
+    rows = samp.shape[0]
+    if samp.dtype != torch.float32 or samp.shape[1] != 256 or not samp.is_contiguous():
+        raise RuntimeError("mvg_chain_attn_pose_f32s: contiguous fp32 (rows, 256) samples required")
+    for t in (Wp, W0, W1):
+        if t.dtype != torch.bfloat16 or t.numel() != 3 * 256 * 256 or not t.is_contiguous():
+            raise RuntimeError("mvg_chain_attn_pose_f32s: weight planes from split_swizzle_weight required")
+    assert inside.dtype == torch.uint8 and inside.numel() == rows and inside.is_contiguous()
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == rows and order.is_contiguous()
+    attn = torch.empty((rows, 256), dtype=torch.float32, device=samp.device)
+    o = torch.empty((rows, 3), dtype=torch.float32, device=samp.device)
+    with _timed("chain_attn_pose_f32s"):
+      L.check(L.load().mvg_chain_attn_pose_f32s(L.ptr(samp), L.ptr(inside), L.ptr(Wp), L.ptr(bp), L.ptr(W0), L.ptr(b0),
+                                                L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
+                                                None if order is None else L.ptr(order),
+                                                None if o_masked is None else L.ptr(o_masked), rows, L.stream_ptr()),
+              "mvg_chain_attn_pose_f32s")
+    return attn, o
+
+
+def chain_masked_row_output_f32s(Wp, bp, W0, b0, W1, b1, W2, b2):
+    """o (3,) f32 of a row with inside == 0 as the fp32 chain A computes it (the chain run on one masked row)."""
+    dev = Wp.device
+    samp = torch.zeros((1, 256), dtype=torch.float32, device=dev)
+    inside = torch.zeros((1,), dtype=torch.uint8, device=dev)
+    global PROFILE
+    saved, PROFILE = PROFILE, None
+    try:
+        _, o = chain_attn_pose_f32s(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2)
+    finally:
+        PROFILE = saved
+    return o.reshape(3)
+
+
+def chain_update_ffn_class_f32s(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
+                                forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None):
+    """fp32 chain B (include/mvg_decoder.h: mvg_chain_update_ffn_class_f32s); arguments and results as chain_update_ffn_class,
+    attn (V * rows, 256) f32, weights from split_swizzle_weight."""
+    dev = attn.device
+    rows = B * NQ * J
+    if attn.dtype != torch.float32 or attn.numel() != V * rows * 256 or not attn.is_contiguous():
+        raise RuntimeError("mvg_chain_update_ffn_class_f32s: contiguous fp32 (V * rows, 256) attn required")
+    assert tgt.dtype == torch.float32 and tgt.numel() == rows * 256 and tgt.is_contiguous()
+    assert Wu.dtype == torch.bfloat16 and Wu.numel() == 3 * 256 * 256
+    if has_ffn:
+        assert W1.dtype == torch.bfloat16 and W1.numel() == 3 * 1024 * 256 and W2.dtype == torch.bfloat16 and W2.numel() == 3 * 256 * 1024
+    if tgt_out is None:
+        tgt_out = torch.empty((rows, 256), dtype=torch.float32, device=dev)
+    else:
+        assert tgt_out.dtype == torch.float32 and tgt_out.numel() == rows * 256 and tgt_out.is_contiguous()
+        tgt_out = tgt_out.view(rows, 256)
+    prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
+    qpos = Wn = bn = xw_next = None
+    n_next = 0
+    if next_query_proj is not None:
+        qpos, Wn, bn, n_next = next_query_proj
+        assert Wn.dtype == torch.bfloat16 and Wn.numel() == 3 * 256 * 256 and bn.numel() == 256 and bn.dtype == torch.float32
+        if qpos is not None:
+            assert qpos.dtype == torch.float32 and qpos.numel() == rows * 256 and qpos.is_contiguous()
+        xw_next = torch.empty((rows, n_next), dtype=torch.float32, device=dev)
+    if any_valid is None:
+        any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with _timed("chain_update_ffn_class_f32s"):
+      L.check(L.load().mvg_chain_update_ffn_class_f32s(
+          L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
+          L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out), L.ptr(prob),
+          L.ptr(valid), L.ptr(any_valid), L.ptr(qpos), L.ptr(Wn), L.ptr(bn), L.ptr(xw_next), n_next, B, NQ, J,
+          1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class_f32s")
+    if next_query_proj is not None:
+        return tgt_out, prob, valid, any_valid, xw_next
+    return tgt_out, prob, valid, any_valid
+
+
 def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
     """fused output_proj (* in-image mask) + 3-layer pose MLP; Wp/W0/W1 in swizzle_weight order.
     order (rows) i32: row processing order (bin_pairs: masked rows last); o_masked (3) f32 from
