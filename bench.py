@@ -91,6 +91,160 @@ def measure_traffic_live(argv_tail, kernel_prefix):
                         "fetch_correction": 2.0}
 
 
+SAMPLER_KERNELS = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel",
+                   "msda_gfused_f32": "msda_gfused_f32_kernel", "msda_fused": "msda_fused_kernel"}
+
+# the workloads measured next to the headline in the driver's one command: (name, config, dtype, inside, batch)
+SECONDARY = (("cfg2_fp32", "cfg2", "fp32", "grid", 1), ("cfg4_fp32", "cfg4", "fp32", "grid", 1),
+             ("cfg2_bf16_inside_all", "cfg2", "bf16", "all", 1), ("cfg5_bf16", "cfg5", "bf16", "grid", 1),
+             ("cfg2_bf16_batch2", "cfg2", "bf16", "grid", 2), ("cfg2_bf16_batch4", "cfg2", "bf16", "grid", 4))
+
+
+def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3, profile_steps=2):
+    """One more workload in this process, after the headline's timed region: `steps` graph-replayed forwards of a batch of
+    `batch` samples (barrier-free single GPU: synchronize on both sides), then `profile_steps` eager forwards with the side
+    stream off for the sampling kernel's own duration.  No PMC passes, no CPU leg."""
+    import gc
+    from mvgformer_amd import ops
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from mvgformer_amd.synthetic import build_case
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    elem = 2 if dtype_name == "bf16" else 4
+    case = build_case(config, B=batch, seed=0, ref_extent=0.3 if inside == "all" else 1.0)
+    dec = build_decoder_for_case(case, dev, dtype)
+    g = case_to_device(case, dev)
+    ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, batch, dev)
+
+    def forward():
+        ctx.feat = None
+        return dec(g.tgt, g.reference_points, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None,
+                   query_pos=g.query_pos, threshold=0.1, context=ctx)
+    with torch.no_grad():
+        for _ in range(2):
+            out = forward()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = forward()
+        for _ in range(warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert torch.isfinite(out[1]).all(), "non-finite poses"
+        saved, ops.PROFILE = ops.PROFILE, {}
+        overlap, dec.overlap_pyramid = dec.overlap_pyramid, False
+        for _ in range(profile_steps):
+            forward()
+        torch.cuda.synchronize()
+        prof = ops.profile_summary()
+        ops.PROFILE, dec.overlap_pyramid = saved, overlap
+    S = int(sum(h * w for h, w in case.shapes))
+    bytes_launch = batch * case.V * algorithmic_bytes_per_view_layer(S, 256, case.NQ * 15, 8, len(case.shapes), 8, elem)
+    key = next((k for k in SAMPLER_KERNELS if k in prof), None)
+    rec = {"workload": "%s: %d views, %d queries x 15 joints, %d layers, maps %s x 256ch, batch %d, initial poses %s"
+                       % (config, case.V, case.NQ, case.layers, case.shapes, batch, inside),
+           "dtype": dtype_name, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "ms_per_sample": round(elapsed / steps / batch * 1e3, 4), "value": round(batch * steps / elapsed, 3),
+           "unit": "samples/s", "hip_graph": True}
+    if key is not None:
+        us = prof[key][1] * 1e3
+        rec.update({"sampler_kernel": SAMPLER_KERNELS[key], "sampler_us": round(us, 2),
+                    "frac": round(bytes_launch / (us * 1e-6) / 8e12, 4), "algorithmic_bytes_per_launch": bytes_launch})
+    rec["kernels_us"] = {k: round(ms * 1e3, 1) for k, (n, ms) in sorted(prof.items())}
+    del graph, out, dec, g, ctx, case
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def rccl_preflight(rank, world, dev):
+    """First contact with the collectives BEFORE anything is timed: one all_gather_into_tensor and one MAX all_reduce on tiny
+    tensors, the library version and every rank's device.  A failure prints a line that says where it happened instead of
+    leaving the job hanging inside the timed region."""
+    info = {"ranks": world, "backend": dist.get_backend()}
+    try:
+        t0 = time.perf_counter()
+        mine = torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int32, device=dev)
+        seen = torch.empty((world * 2,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(seen, mine)
+        top = torch.tensor([rank], dtype=torch.int32, device=dev)
+        dist.all_reduce(top, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        seen = seen.view(world, 2).tolist()
+        info.update({"ranks_seen": [r for r, _ in seen], "local_devices": [d for _, d in seen], "max_rank": int(top.item()),
+                     "first_collectives_s": round(time.perf_counter() - t0, 3), "device_name": torch.cuda.get_device_name(dev)})
+        try:
+            info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:           # gloo plumbing runs
+            info["version"] = "n/a (%s)" % type(e).__name__
+        if info["ranks_seen"] != list(range(world)) or info["max_rank"] != world - 1:
+            raise RuntimeError("ranks seen %s, max %s" % (info["ranks_seen"], info["max_rank"]))
+        info["ok"] = True
+    except Exception as e:
+        info.update({"ok": False, "error": "%s: %s" % (type(e).__name__, e)})
+        print("# rank %d/%d: collective preflight FAILED on %s (backend %s): %s" % (rank, world, dev, dist.get_backend(), info["error"]),
+              file=sys.stderr, flush=True)
+    return info
+
+
+def measure_replicas(config, dtype_name, rank, world, dev, steps, warmup):
+    """N GPUs, one sample per rank and step (batch-parallel replicas, weak scaling): every rank's own full forward as a HIP
+    graph + one all-gather of the final pose sets per step; barrier + synchronize on both sides, MAX over the ranks."""
+    import gc
+    from mvgformer_amd.decoder import DecoderContext
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from mvgformer_amd.synthetic import build_case
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    case = build_case(config, seed=100 + rank)
+    dec = build_decoder_for_case(case, dev, dtype)
+    g = case_to_device(case, dev)
+    ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, 1, dev)
+
+    def forward():
+        ctx.feat = None
+        return dec(g.tgt, g.reference_points, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None,
+                   query_pos=g.query_pos, threshold=0.1, context=ctx)
+    with torch.no_grad():
+        for _ in range(2):
+            out = forward()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = forward()
+        send = torch.cat([out[1][-1].reshape(-1), out[4][-1].reshape(-1)])
+        recv = send.new_empty((world * send.numel(),))
+
+        def step():
+            graph.replay()
+            torch.cat([out[1][-1].reshape(-1), out[4][-1].reshape(-1)], out=send)
+            dist.all_gather_into_tensor(recv, send)
+        for _ in range(warmup):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    rec = {"workload": "%s, one sample per rank and step, all-gather of the final pose sets" % config, "dtype": dtype_name,
+           "scaling": "weak", "n_gpus": world, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "value": round(world * steps / elapsed, 3), "unit": "samples/s", "hip_graph": True}
+    del graph, out, dec, g, ctx, case
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def self_launch(n):
     """Re-run this command line as n ranks under torch.distributed.run (one process per GPU); returns its exit code."""
     import socket
@@ -154,6 +308,13 @@ def main():
                          "profiles/r03_f32_split_gemm.txt); exact = v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--secondary", type=int, default=-1,
+                    help="1 GPU: after the headline's timed region also measure cfg-2 fp32, cfg-4 fp32, cfg-2 --inside all, cfg-5 bf16 "
+                         "and cfg-2 bf16 with 2 / 4 samples per forward (>= 10 graph replays each, ~20 s) and attach them as "
+                         "`secondary`; N GPUs, query-sharded: also time one-sample-per-rank replicas (`shard_samples`).  -1 = auto: "
+                         "on for the default headline command, off when a diagnostic override is given")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="samples per forward (the decoder batches natively); the headline is quoted at 1")
     ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -192,6 +353,9 @@ def main():
     from mvgformer_amd.synthetic import build_case
 
     arch, cus = _lib.device_info()
+    rccl = rccl_preflight(rank, world, dev) if world > 1 else None
+    if rccl is not None and not rccl["ok"]:
+        raise SystemExit("collective preflight failed: %s" % rccl["error"])
     _lib.check(_lib.load().mvg_set_tuning(b"f32_split", 1 if args.f32_gemm == "split" else 0), "mvg_set_tuning(f32_split)")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     elem = 2 if args.dtype == "bf16" else 4
@@ -200,8 +364,8 @@ def main():
     sharded = world > 1 and args.shard == "queries"       # one sample, queries split over the ranks
     replicas = world > 1 and args.shard == "samples"      # one sample per rank
     ref_extent = 0.3 if args.inside == "all" else 1.0
-    case = build_case(args.config, seed=rank if replicas else 0, valid_fraction=args.valid_fraction, NQ=args.queries,
-                      ref_extent=ref_extent)
+    case = build_case(args.config, B=args.batch, seed=rank if replicas else 0, valid_fraction=args.valid_fraction,
+                      NQ=args.queries, ref_extent=ref_extent)
     NQ, J, V, Ly = case.NQ, 15, case.V, case.layers
     cpu_case = None
     if rank == 0 and args.cpu_baseline and world == 1:
@@ -216,7 +380,7 @@ def main():
         mdist.install_any_valid_sync(dec, None)
 
     # host-side, per-sample preparation that belongs to data loading (camera records)
-    ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, 1, dev)
+    ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, args.batch, dev)
 
     src_views = g.src_views
     if args.producer == "nhwc":
@@ -393,6 +557,18 @@ def main():
             dec.overlap_pyramid = overlap
             live_frac = float(torch.stack(live_fracs).mean()) if live_fracs else None
 
+    default_headline = (args.config == "cfg2" and args.dtype == "bf16" and args.queries is None and args.valid_fraction is None
+                        and args.inside == "grid" and args.inflight == 1 and args.batch == 1 and args.producer == "nchw")
+    want_secondary = default_headline if args.secondary < 0 else bool(args.secondary)
+    secondary = {}
+    if want_secondary and sharded:
+        # the weak-scaling number next to the strong-scaling one, in the same job (collective: every rank takes part)
+        try:
+            secondary["shard_samples"] = measure_replicas(args.config, args.dtype, rank, world, dev, args.steps, args.warmup)
+        except Exception as e:
+            secondary["shard_samples"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            print("# rank %d: replica measurement failed: %s" % (rank, secondary["shard_samples"]["error"]), file=sys.stderr)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -401,12 +577,12 @@ def main():
     refs = out[1]
     assert torch.isfinite(refs).all(), "non-finite poses"
     ms_per_step = elapsed / args.steps * 1e3
-    value = (world if replicas else 1) * args.inflight * args.steps / elapsed   # samples / s of the whole job
+    value = (world if replicas else 1) * args.inflight * args.batch * args.steps / elapsed   # samples / s of the whole job
 
     # roofline of the dominant kernel: one sampling-kernel launch covers all V views of one layer
     Lq_loc = (hi - lo) * J
     S = int(sum(h * w for h, w in case.shapes))
-    bytes_launch = V * algorithmic_bytes_per_view_layer(S, 256, Lq_loc, 8, len(case.shapes), 8, elem)
+    bytes_launch = args.batch * V * algorithmic_bytes_per_view_layer(S, 256, Lq_loc, 8, len(case.shapes), 8, elem)
     roof = None
     # HBM-side bytes of the same kernel from the PMC counters (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  Either
     # measured by this run (two rocprofv3 child passes of the same command) or the committed figure of tools/prof.sh --
@@ -460,7 +636,7 @@ def main():
                 "pairs_skipped": bool(samp_key in ("msda_gsamp", "msda_gsamp_chain", "msda_gfused_f32")),
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
-                "fused_minimum_bytes_per_launch": V * (S * 256 + Lq_loc * 256) * elem}
+                "fused_minimum_bytes_per_launch": args.batch * V * (S * 256 + Lq_loc * 256) * elem}
         if samp_key == "msda_gsamp":
             # The roof this kernel actually runs against: its gathers are served by the L1s, which deliver
             # 55-57 B/clk/CU = ~35 TB/s to loads of this shape (tools/probes/l1_gather_probe).  Bytes delivered to the lanes per
@@ -468,7 +644,7 @@ def main():
             live = live_frac if live_frac is not None else 1.0
             n_lv, n_pt, n_head = len(case.shapes), 8, 8
             per_unit = n_lv * n_pt * 4 * 64 + 4 * 9 * 16
-            delivered = int(V * Lq_loc * n_head * per_unit * live)
+            delivered = int(args.batch * V * Lq_loc * n_head * per_unit * live)
             l1_peak = 57.0 * 256 * 2.4           # GB/s: 57 B/clk/CU x 256 CUs x 2.4 GHz
             roof["l1_path"] = {"delivered_bytes_per_launch": delivered, "in_image_pair_fraction": round(live, 4),
                                "achieved": round(delivered / (ms * 1e-3) / 1e9, 1), "peak": round(l1_peak, 1), "unit": "GB/s",
@@ -481,11 +657,25 @@ def main():
     # rank), "variable" = everything proportional to this rank's queries
     split = None
     if prof and args.profile_steps > 0:
-        fixed_keys = ("pack_level", "pack_level_nhwc", "value_proj_ws", "feat_linear_ws", "pyramid_all_layers")
+        n_pyr = args.batch * V * S          # rows of the pyramid GEMMs: query-independent whatever the path (fp32: plain linears)
+        fixed_keys = ("pack_level", "pack_level_nhwc", "value_proj_ws", "feat_linear_ws", "pyramid_all_layers", "pyramid_f32s",
+                      "linear_%dx256x256" % n_pyr, "linear_%dx192x256" % n_pyr)
         fx = sum(n * ms for k, (n, ms) in prof.items() if k in fixed_keys) / args.profile_steps
         var = sum(n * ms for k, (n, ms) in prof.items() if k not in fixed_keys) / args.profile_steps
         split = {"fixed_us": round(fx * 1e3, 1), "variable_us": round(var * 1e3, 1),
                  "note": "rank 0, kernels timed one at a time; fixed = replicated query-independent work"}
+
+    if want_secondary and world == 1:
+        # the other named workloads, driver-witnessed: same process, same command, after the headline's timed region
+        for name, cfg_name, dt_name, inside, batch in SECONDARY:
+            try:
+                t_sec = time.perf_counter()
+                secondary[name] = measure_secondary(cfg_name, dt_name, inside, batch, dev)
+                secondary[name]["wall_s"] = round(time.perf_counter() - t_sec, 1)
+            except Exception as e:      # a secondary workload must never cost the headline line
+                secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
 
     cpu = None
     if cpu_case is not None:
@@ -517,7 +707,7 @@ def main():
         else "decoder samples/sec (%s)" % args.config,
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if sharded else "weak",
+        "scaling": "strong" if sharded else ("weak" if replicas else None),
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: %d views, %d queries x %d joints, %d decoder layers, maps %s x 256ch, "
                                "all queries valid" % (args.config, V, NQ, J, Ly, case.shapes)
@@ -533,12 +723,13 @@ def main():
                                        "inplace": "produced in the packed layout (no per-step pack)"}[args.producer],
                    "initial_poses": {"grid": "'sample_space' grid over the whole space (SURVEY 8(d))",
                                      "all": "grid over 30 % of the space: > 99 % of the (view, query) pairs inside their image"}[args.inside],
-                   "samples_in_flight": args.inflight,
+                   "samples_in_flight": args.inflight, "samples_per_forward": args.batch,
                    **({"fp32_gemm": {"split": "operands split into 3 bf16 parts, 6 bf16 MFMA products, fp32 accumulate",
                                      "exact": "v_mfma_f32_32x32x2_f32 (fmaf chain)"}[args.f32_gemm]}
                       if args.dtype == "fp32" else {}),
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
         "roofline": roof, "cpu_baseline": cpu, "rank_time_split": split, "kernels": kern,
+        "secondary": secondary or None, "rccl": rccl,
     }
     print(json.dumps(line))
     if world > 1:

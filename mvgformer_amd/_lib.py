@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvgformer_hip.so")
+# MVG_LIB: another build of the same library (measurement variants of tools/ab_*.sh); the product never sets it
+LIB_PATH = os.environ.get("MVG_LIB") or os.path.join(_HERE, "libmvgformer_hip.so")
 
 MVG_F32, MVG_BF16 = 0, 1
 CAM_STRIDE = 48

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
     float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
     const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
-    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
+    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn, int g_skew) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                   // 3 planes x 64 rows x 256 columns: mean, then t1, then tgt' + query_pos
   char* hb = smem + 3 * PLANE;                        // 3 planes x 64 rows x 128 columns: FFN hidden chunk
@@ -383,15 +383,20 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     f32x4 s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < V; ++v) {
-      f32x4 xv[8];
+    for (int v = 0; v < V; v += 2) {                 // two views per round: 16 loads of 16 B in flight per thread
+      f32x4 xv[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = i * NT + tid;
+          xv[u][i] = *reinterpret_cast<const f32x4*>(attn + ((long)min(v + u, V - 1) * rows + r0 + min(c >> 6, nrow - 1)) * 256 + (c & 63) * 4);
+        }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid;
-        xv[i] = *reinterpret_cast<const f32x4*>(attn + ((long)v * rows + r0 + min(c >> 6, nrow - 1)) * 256 + (c & 63) * 4);
+        s[i] += xv[0][i];
+        if (v + 1 < V) s[i] += xv[1][i];
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] += xv[i];
     }
     const float Vf = (float)V;
 #pragma unroll
@@ -404,25 +409,31 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
   }
   __syncthreads();
 
+  // All workgroups walk the same weights; started together they request the same L2 lines at the same time.  The 32
+  // workgroups of an XCD (blockIdx >> 3) start their first stage up to 15 k-steps apart -- a skew in TIME: the arithmetic of
+  // a row does not depend on where it is computed.
+  if (g_skew) for (int i = ((blockIdx.x >> 3) & 15) * g_skew; i > 0; --i) __builtin_amdgcn_s_sleep(8);
   // ---- t1 = LN2(tgt + feature_update_mlp(mean))   (dq_decoder.py:773-778)
   f32x16 acc[2];
   f32x4 bvr[4];
   stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, nullptr, true, rot, lane);
   load_bias(bu + colb, bvr, lane);
-  f32x4 t1[2][4];
+  {
+    f32x4 t1[2][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) t1[mt][g][t] = acc[mt][4 * g + t] + bvr[g][t];
-      if (mt * 32 + rl < nrow) t1[mt][g] += tg[mt][g];
-    }
-  layernorm_rows(t1, g2 + colb, be2 + colb, part, part2, lane, w);      // (its first barrier: every wavefront is done reading `act`)
+        for (int t = 0; t < 4; ++t) t1[mt][g][t] = acc[mt][4 * g + t] + bvr[g][t];
+        if (mt * 32 + rl < nrow) t1[mt][g] += tg[mt][g];
+      }
+    layernorm_rows(t1, g2 + colb, be2 + colb, part, part2, lane, w);    // (its first barrier: every wavefront is done reading `act`)
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
+      for (int g = 0; g < 4; ++g) store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
+  }
   __syncthreads();
 
   f32x4 y[2][4];
@@ -432,17 +443,26 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     f32x16 accy[2];
     const int mt1 = w & 1, cb4 = w >> 1;
     const bool one[1] = {true};
+    const bf16_t* wp2 = frag_ptr(W2, 0, w, 64, lane);
+    // every stage's first fragments are requested one stage ahead, before the barriers in front of it (ring_prefetch)
+    f32x4 pf1[4][3], pf2[4][3];
+    ring_prefetch<16, 4>(frag_ptr(W1, 0, cb4, 16, lane), 1024 * 256, pf1, rot);
 #pragma unroll 1
     for (int c = 0; c < 1024 / FCH; ++c) {
       f32x16 a1[1], a2;
-      stage<1, 16, PLP>(act, PLANE, 32 * mt1, frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane), 1024 * 256, a1, &a2, true, rot, lane);
+      stage<1, 16, PLP, 4, true>(act, PLANE, 32 * mt1, frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane), 1024 * 256, a1, &a2, true,
+                                 rot, lane, pf1);
       a1[0] += a2;
       load_bias(b1 + c * FCH + 32 * cb4, bvr, lane);
+      ring_prefetch<8, 4>(wp2 + (long)c * 8 * 1024, 256 * 1024, pf2, rot & 7);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                                              // the previous chunk's second GEMM has read hb
       write_planes<1, PLP128>(hb, HPLANE, 32 * mt1, 32 * cb4, a1, bvr, true, one, lane);
+      if (c + 1 < 1024 / FCH)
+        ring_prefetch<16, 4>(frag_ptr(W1, (c + 1) >> 1, 4 * ((c + 1) & 1) + cb4, 16, lane), 1024 * 256, pf1, rot);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-      stage<2, 8, PLP128>(hb, HPLANE, 0, frag_ptr(W2, 0, w, 64, lane) + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0,
-                          rot & 7, lane);
+      stage<2, 8, PLP128, 4, true>(hb, HPLANE, 0, wp2 + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
     }
     load_bias(b2 + colb, bvr, lane);
 #pragma unroll
@@ -450,13 +470,26 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) y[mt][g][t] = t1[mt][g][t] + (accy[mt][4 * g + t] + bvr[g][t]);
+        for (int t = 0; t < 4; ++t) y[mt][g][t] = accy[mt][4 * g + t] + bvr[g][t];
+    // + t1, re-read from the planes (h + m + l is exactly the fp32 value that was split): 32 registers less across the FFN
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const char* src = act + (mt * 32 + rl) * PLP + (colb + 8 * g + 4 * h) * 2;
+        y[mt][g] += join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + PLANE),
+                          *reinterpret_cast<const uint2*>(src + 2 * PLANE));
+      }
     layernorm_rows(y, g3 + colb, be3 + colb, part, part2, lane, w);
   } else {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) y[mt][g] = t1[mt][g];
+      for (int g = 0; g < 4; ++g) {
+        const char* src = act + (mt * 32 + rl) * PLP + (colb + 8 * g + 4 * h) * 2;
+        y[mt][g] = join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + PLANE),
+                         *reinterpret_cast<const uint2*>(src + 2 * PLANE));
+      }
   }
 
   // ---- tgt' -> global; class head (dq_decoder.py:889-893): per-row logits, completed across the wavefronts
@@ -565,6 +598,7 @@ int cu_count() {
 
 }  // namespace
 
+int g_f32s_skew = 6;      // tuning knob "f32s_skew": start-up skew between the workgroups of an XCD, in s_sleep(8) units per phase step
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
 
 extern "C" int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
@@ -622,7 +656,7 @@ extern "C" int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const f
   hipLaunchKernelGGL(chain_b_f32s_kernel, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, (hipStream_t)stream, attn, V, tgt,
                      (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc, threshold,
                      forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next, n_next,
-                     rows, J, nq_total, has_ffn);
+                     rows, J, nq_total, has_ffn, g_f32s_skew);
   MVG_LAUNCH_CHECK();
   return 0;
 }

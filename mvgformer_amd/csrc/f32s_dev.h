@@ -14,6 +14,12 @@
 #pragma once
 #include "common.h"
 
+// Measurement hook (tools/ab_f32s.sh builds variants; the product is built with 0): bit 0 = no ring refills (every k-step reuses
+// the first RING fragments), bit 1 = no LDS reads in the k loop, bit 2 = no MFMAs.  Results are wrong with any bit set.
+#ifndef F32S_KO
+#define F32S_KO 0
+#endif
+
 namespace f32s {
 
 constexpr int PLP = 528;      // bytes per 256-column plane row in LDS (512 + 16 pad)
@@ -113,7 +119,7 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int s = 0; s < 3; ++s) a[mt][s] = __builtin_bit_cast(bf16x8, a_nxt[mt][s]);
-    if (ks + 1 < KSTEPS) {
+    if (ks + 1 < KSTEPS && !(F32S_KO & 2)) {
       const int kn = (ks + 1 + rot) & (KSTEPS - 1);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -123,7 +129,7 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) b[s] = __builtin_bit_cast(bf16x8, ring[ks % RING][s]);
-    if (ks + RING < KSTEPS) {
+    if (ks + RING < KSTEPS && !(F32S_KO & 1)) {
       const int kq = (ks + RING + rot) & (KSTEPS - 1);
 #pragma unroll
       for (int s = 0; s < 3; ++s) ring[ks % RING][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
@@ -134,6 +140,10 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
     for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        if (F32S_KO & 4) {
+          acc[mt][t] += __builtin_bit_cast(f32x4, b[TB[t]])[0] * __builtin_bit_cast(f32x4, a[mt][TA[t]])[1];
+          continue;
+        }
         if (MT == 1 && (t & 1))
           *acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[TB[t]], a[mt][TA[t]], *acc2, 0, 0, 0);
         else

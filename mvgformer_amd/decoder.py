@@ -174,6 +174,8 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.d_model = d_model
         self.compute_dtype = torch.float32
         self.use_fused_chains = True    # bf16 inference: LDS-resident Linear chains (csrc/chain.hip)
+        # fp32 inference: the same two chains on pre-split operands (csrc/f32s.hip); MVG_F32_FUSED=0: one launch per GEMM / row op
+        self.use_fused_chains_f32 = os.environ.get("MVG_F32_FUSED", "1") != "0"
         self.fuse_boundary = True       # the triangulation launch also projects the new points for the next layer
         # fp32 path: output projection + pose MLP skip the tiles whose pairs are all outside their image (round 3)
         self.skip_masked_f32 = os.environ.get("MVG_SKIP_MASKED_F32", "1") != "0"
@@ -275,6 +277,43 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self._w("b3", (self.norm3.bias,), f32) if ffn else None,
                 self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
 
+    def _chain_a_weights_f32s(self):
+        f32, bf = torch.float32, torch.bfloat16
+        pose_layers = self.pose_embed.MLP.layers
+        sp = ops.split_swizzle_weight
+        wts = (self._w("Wp_f32s", (self.proj_attn.output_proj.weight,), bf, sp), self._w("bp", (self.proj_attn.output_proj.bias,), f32),
+               self._w("Wpe0_f32s", (pose_layers[0].weight,), bf, sp), self._w("bpe0", (pose_layers[0].bias,), f32),
+               self._w("Wpe1_f32s", (pose_layers[1].weight,), bf, sp), self._w("bpe1", (pose_layers[1].bias,), f32),
+               self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
+        pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
+        o_masked = self._w("o_masked_f32s", pose_params, f32, lambda *_: ops.chain_masked_row_output_f32s(*wts))
+        return wts, o_masked
+
+    def _chain_b_weights_f32s(self):
+        f32, bf = torch.float32, torch.bfloat16
+        sp = ops.split_swizzle_weight
+        ffn = self.open_forward_ffn
+        return (self._w("Wu_f32s", (self.feature_update_mlp.weight,), bf, sp), self._w("bu", (self.feature_update_mlp.bias,), f32),
+                self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
+                self._w("W1_f32s", (self.linear1.weight,), bf, sp) if ffn else None,
+                self._w("b1", (self.linear1.bias,), f32) if ffn else None,
+                self._w("W2_f32s", (self.linear2.weight,), bf, sp) if ffn else None,
+                self._w("bb2", (self.linear2.bias,), f32) if ffn else None,
+                self._w("g3", (self.norm3.weight,), f32) if ffn else None,
+                self._w("b3", (self.norm3.bias,), f32) if ffn else None,
+                self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
+
+    def _fuses_chains_f32(self, dt, Lq=None, levels=None):
+        """(chain A, chain B) of the fp32 path run as the fused f32s kernels (csrc/f32s.hip)"""
+        pose_layers = self.pose_embed.MLP.layers
+        ok = dt == torch.float32 and self.use_fused_chains_f32 and self.d_model == 256
+        fuse_a = (ok and len(pose_layers) == 3 and pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256
+                  and pose_layers[0].in_features == 256 and self.proj_attn.f32_fused
+                  and (levels is None or self.proj_attn.f32_g_form(Lq, levels.L, levels.S)))
+        fuse_b = (ok and self.num_joints <= 64 and (not self.open_forward_ffn or (self.linear1.out_features == 1024 and
+                                                                                   self.linear1.in_features == 256)))
+        return fuse_a, fuse_b
+
     def _fuses_chains(self, dt):
         """(chain A, chain B) run as the fused LDS-resident kernels for this configuration."""
         pose_layers = self.pose_embed.MLP.layers
@@ -300,6 +339,13 @@ class DQDecoderLayer(MvPDecoderLayer):
             if dt == torch.float32 and self.proj_attn.g_sampling_f32 is not False and \
                     self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192:
                 self.proj_attn._fast_query_weights(dt)      # the fp32 G-sampling branch of native_sample (Woa_perm / boa_perm)
+                if self.proj_attn.f32_fused and self.proj_attn.rayconv.weight.shape == (256, 256):
+                    self.proj_attn.query_term_weights_f32s()
+            fa32, fb32 = self._fuses_chains_f32(dt)
+            if fa32:
+                self._chain_a_weights_f32s()
+            if fb32:
+                self._chain_b_weights_f32s()
         fuse_a, fuse_b = self._fuses_chains(dt)
         if fuse_a:
             self._chain_a_weights(dt, fused_sampler=self.proj_attn.fuse_sampler_chain)
@@ -455,6 +501,14 @@ class DQDecoderLayer(MvPDecoderLayer):
                                                     order=order, xw=xw_in)
                 wts, o_masked = self._chain_a_weights(dt)
                 attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+        elif self._fuses_chains_f32(dt, Lq, ctx.levels)[0] and C == 256:
+            # fp32, fused: G-sampling kernel + chain A on pre-split operands (csrc/f32s.hip); pairs in processing order, masked
+            # pairs last (zero-filled by the sampler, all-masked tiles skipped by the chain)
+            order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels) if (self.proj_attn.sort_pairs and Lq <= 65536) else None
+            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1), order=order,
+                                                xw=xw_in)
+            wts, o_masked = self._chain_a_weights_f32s()
+            attn, o = ops.chain_attn_pose_f32s(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
             # fp32 (reference arithmetic): the per-view output projection and pose MLP run over the pairs in processing order and
             # skip the tiles whose pairs are all outside their image (their rows are zero / a cached constant either way).
@@ -477,7 +531,22 @@ class DQDecoderLayer(MvPDecoderLayer):
                 forced[b, torch.as_tensor(q, dtype=torch.long, device=tgt.device)] = 1
         tgt32 = tgt.float().reshape(B * Lq, C).contiguous()
         fuse_b = fuse_b and C == 256 and J <= 64
-        if fuse_b:
+        fuse_b32 = self._fuses_chains_f32(dt)[1] and C == 256 and not fuse_b
+        if fuse_b32:
+            nxt = self._next_layer[0] if self._next_layer else None
+            next_proj = None
+            if (nxt is not None and nxt.compute_dtype == dt and nxt._fuses_chains_f32(dt, Lq, ctx.levels)[0]
+                    and (query_pos is None or query_pos.shape == tgt.shape)):
+                Wn, bn, n_next = nxt.proj_attn.query_term_weights_f32s()
+                qp = None if query_pos is None else query_pos.float().reshape(B * Lq, C).contiguous()
+                next_proj = (qp, Wn, bn, n_next)
+            res = ops.chain_update_ffn_class_f32s(
+                attn, V, tgt32, *self._chain_b_weights_f32s(), threshold, B, NQ, J, forced, self.open_forward_ffn,
+                tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
+            tgt_update, prob, valid, any_valid = res[:4]
+            if next_proj is not None:
+                nxt._xw_in = res[4]
+        elif fuse_b:
             ffn = self.open_forward_ffn
             # the next layer's query term xw = (tgt' + query_pos) W^T + b rides on this chain (its rows are in LDS)
             nxt = self._next_layer[0] if self._next_layer else None     # (kept in a tuple: not a sub-module)

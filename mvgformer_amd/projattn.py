@@ -106,6 +106,9 @@ class ProjAttn(nn.Module):
         self.g_sampling_f32 = {"0": False, "1": True}.get(os.environ.get("MVG_G_SAMPLING_F32", "auto"), "auto")
         # training path: reference-point features through the HIP sampling op (False: torch grid_sample per level)
         self.ref_gather_native = os.environ.get("MVG_REF_GATHER", "1") != "0"
+        # fp32 path: fused kernels on pre-split operands (csrc/f32s.hip): one-pass pyramid products here, chain A / chain B in
+        # DQDecoderLayer.  MVG_F32_FUSED=0: the unfused kernels of rounds 1-3 (mvg_linear per GEMM).
+        self.f32_fused = os.environ.get("MVG_F32_FUSED", "1") != "0"
         self.sort_pairs = os.environ.get("MVG_SORT_PAIRS", "layer")
         if self.sort_pairs in ("0", "off", "False"):
             self.sort_pairs = False
@@ -166,8 +169,13 @@ class ProjAttn(nn.Module):
     def f32_g_form(self, Lq, L, S):
         """fp32 path: G-sampling (the offsets / logits Linear applied to the pyramid) rather than gather-then-Linear -- by
         MVG_G_SAMPLING_F32, else whenever the gathered rows (Lq * L per image) outnumber the pyramid's (S)"""
+        geometry = self.sampling_offsets.out_features + self.attention_weights.out_features == 192 and self.rayconv.weight.shape == (256, 256)
+        if self.g_sampling_f32 == "auto" and self.f32_fused and geometry:
+            # with the one-pass pyramid kernel (mvg_pyramid_f32s) the G form moves fewer bytes at every shipped shape: the gather
+            # form re-fetched 2.6 x its algorithmic bytes at cfg-4 (profiles/r03_bench_cfg4_fp32.json)
+            return True
         use_g = self.g_sampling_f32 if self.g_sampling_f32 != "auto" else Lq * L >= S
-        return bool(use_g) and self.sampling_offsets.out_features + self.attention_weights.out_features == 192
+        return bool(use_g) and geometry
 
     def _wait_pyramid(self):
         """both pyramid projections were produced ahead of time on a side stream (DQDecoder.launch_pyramid_projections)."""
@@ -189,8 +197,12 @@ class ProjAttn(nn.Module):
             if self._vp is None or self._vp.dtype != dt or tuple(self._vp.shape) != (n_img, S, Cc) or self._vp.device != feat.device:
                 self._vp = torch.empty((n_img, S, Cc), dtype=dt, device=feat.device)
                 self._G = torch.empty((n_img * S, 192), dtype=dt, device=feat.device)
-            ops.linear(feat.view(n_img * S, Cc), Wv, bv, out=self._vp.view(n_img * S, Cc))       # projattn.py:169
-            ops.linear(feat.view(n_img * S, Cc), Wq, None, out=self._G)
+            if self.f32_fused and Cc == 256 and feat.is_contiguous():
+                Wv_pl, Wg_pl = self.pyramid_planes_f32s()
+                ops.pyramid_f32s(feat, Wv_pl, bv, Wg_pl, 192, value=self._vp, G=self._G)        # projattn.py:169 + 180-181
+            else:
+                ops.linear(feat.view(n_img * S, Cc), Wv, bv, out=self._vp.view(n_img * S, Cc))       # projattn.py:169
+                ops.linear(feat.view(n_img * S, Cc), Wq, None, out=self._G)
             if record_event:
                 self._vp_event = torch.cuda.Event()
                 self._vp_event.record()
@@ -243,6 +255,22 @@ class ProjAttn(nn.Module):
         bn = self._wc.get("boa_pad", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, bpad)
         return Wf, bn, 192
 
+    def pyramid_planes_f32s(self):
+        """operands of mvg_pyramid_f32s: the value projection and the [offsets; logits] Linear (gsamp_column_order) as split planes"""
+        bf = torch.bfloat16
+        perm = lambda a, b: ops.split_swizzle_weight(torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)])
+        return (self._wc.get("Wv_f32s", (self.rayconv.weight,), bf, ops.split_swizzle_weight),
+                self._wc.get("Woa_f32s", (self.sampling_offsets.weight, self.attention_weights.weight), bf, perm))
+
+    def query_term_weights_f32s(self):
+        """operands of xw = (tgt + query_pos) @ [Woff; Wattn]^T + b as the fp32 chain B of the PREVIOUS layer takes them: (split
+        planes of the (192 -> 256, 256) weight in gsamp_column_order, bias (256,) f32 zero-padded, n = 192)"""
+        Wpl = self.pyramid_planes_f32s()[1]
+        perm = lambda a, b: torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)]
+        bpad = lambda a, b: torch.cat([perm(a, b), a.new_zeros(64)], 0)
+        bn = self._wc.get("boa_pad", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, bpad)
+        return Wpl, bn, 192
+
     def _fast_query_weights(self, dt):
         """[offsets; logits] Linear in the column order of the G-sampling kernel (ops.gsamp_column_order)."""
         perm = lambda a, b: torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)]
@@ -260,7 +288,8 @@ class ProjAttn(nn.Module):
         Wv, bv, Woa, boa, Wp, bp = self.weights(dt)
         n_img, S, Cc = feat.shape
         parts = getattr(x, "parts", None)        # (tgt, query_pos) when the caller has not formed tgt + query_pos yet
-        if callable(x) and not (self.uses_fast_path(dt) and (xw is not None or parts is not None)):
+        f32_g = dt == torch.float32 and Cc == 256 and self.f32_g_form(r.shape[1], levels.L, S)
+        if callable(x) and not (self.uses_fast_path(dt) and (xw is not None or parts is not None)) and not (f32_g and xw is not None):
             x = x()
         if self.uses_fast_path(dt):
             # Linear(bilinear(feat) + x) = bilinear(Linear(feat)) + Linear(x): project the pyramid once (G), compute
@@ -276,11 +305,16 @@ class ProjAttn(nn.Module):
                     xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
             vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
-        if dt == torch.float32 and Cc == 256 and self.f32_g_form(r.shape[1], levels.L, S):
+        if f32_g:
             # fp32, reference arithmetic, same re-association as the bf16 fast path: the offsets / logits Linear applied to
             # the pyramid once (G) instead of to V*Lq*L gathered rows -- no `ain` (236 MB) / `oa` (177 MB) per layer
-            Wq, bq = self._fast_query_weights(dt)
-            xw32 = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=dt)
+            if xw is not None:      # computed by the previous layer's fp32 chain B
+                xw32 = xw
+            else:
+                Wq, bq = self._fast_query_weights(dt)
+                if callable(x):
+                    x = x()
+                xw32 = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=dt)
             if order is None and self.sort_pairs and r.shape[1] <= 65536:
                 order = ops.bin_pairs(r, pair_mask, levels)
             # the two pyramid products: computed here, or ahead of time on the side stream (DQDecoder.launch_pyramid_projections)

@@ -144,7 +144,7 @@ def test_only_the_product_and_checker_libraries_ship():
     allowed = {os.path.join("mvgformer_amd", "libmvgformer_hip.so"), os.path.join("oracle", "libmsda_ref.so")}
     found = set()
     for base, dirs, files in os.walk(root):
-        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__", ".pytest_cache", "_ref")]
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__", ".pytest_cache", "_ref", "build")]
         for name in files:
             if name.endswith(".so") or ".so." in name:
                 found.add(os.path.relpath(os.path.join(base, name), root))

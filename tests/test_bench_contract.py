@@ -49,6 +49,18 @@ def test_bench_line_has_the_contract_fields():
     assert r["algorithmic_bytes_per_launch"] == 231014400
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_us"] / 1e3) < 1.0
     assert 0.02 < r["frac"] < 1.0
+    assert d["scaling"] is None and d["rccl"] is None           # one GPU: neither weak nor strong, no collectives
+    # the other named workloads ride in the same line (driver-witnessed): fp32 at cfg-2 / cfg-4, nothing-skipped bf16, cfg-5, B > 1
+    sec = d["secondary"]
+    assert set(sec) == {"cfg2_fp32", "cfg4_fp32", "cfg2_bf16_inside_all", "cfg5_bf16", "cfg2_bf16_batch2", "cfg2_bf16_batch4"}
+    for name, rec in sec.items():
+        assert "error" not in rec, (name, rec)
+        for k in ("ms_per_step", "ms_per_sample", "value", "dtype", "workload", "sampler_kernel", "sampler_us", "frac", "steps"):
+            assert k in rec, (name, k)
+        assert rec["steps"] >= 10 and rec["hip_graph"] is True and 0.02 < rec["frac"] < 1.0
+        assert rec["dtype"] == ("fp32" if name.endswith("fp32") else "bf16")
+    assert abs(sec["cfg2_bf16_batch2"]["ms_per_sample"] * 2 - sec["cfg2_bf16_batch2"]["ms_per_step"]) < 1e-3
+    assert sec["cfg5_bf16"]["ms_per_step"] > sec["cfg2_fp32"]["ms_per_step"] > d["ms_per_step"]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -90,3 +102,27 @@ def test_two_rank_query_sharded_bench_runs_end_to_end_on_one_gpu(speculative):
     assert ("speculative" in d["config"]["parallelism"]) == bool(speculative)
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]       # one sample per step, whole job
     assert "process group up (gloo)" in p.stderr
+    # first-contact insurance: the collectives ran once before anything was timed, and the line says what they saw
+    assert d["rccl"]["ok"] is True and d["rccl"]["ranks"] == 2 and d["rccl"]["ranks_seen"] == [0, 1] and d["rccl"]["backend"] == "gloo"
+    # the weak-scaling number of the same job: one sample per rank and step
+    rep = d["secondary"]["shard_samples"]
+    assert rep["scaling"] == "weak" and rep["n_gpus"] == 2 and abs(rep["value"] - 2e3 / rep["ms_per_step"]) < 1e-2 * rep["value"]
+
+
+@pytest.mark.gpu
+def test_eight_rank_query_sharded_bench_on_one_gpu():
+    """the shape of the driver's 8-GPU command (8 ranks, 128 queries each, one graph per rank + the all-gather) on the one-GPU box:
+    all ranks on cuda:0, gloo carrying the collectives -- everything of the N = 8 run except RCCL itself and the xGMI links."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MVG_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--traffic", "off", "--profile-steps", "1", "--secondary", "0"],
+                       cwd=ROOT, env=env, timeout=1500, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and "queries sharded x8" in d["config"]["parallelism"]
+    assert d["rccl"]["ok"] is True and d["rccl"]["ranks_seen"] == list(range(8))
+    assert d["roofline"]["algorithmic_bytes_per_launch"] < 231014400       # a rank's shard: 128 of the 1024 queries
