@@ -18,6 +18,21 @@
 
 #include "f32s_dev.h"
 
+// Measurement hook (variant builds of tools/ab_f32s.sh only; the product is built without it): s_memtime stamps of one thread
+// per workgroup at phase boundaries, read back with mvg_f32s_read_stamps.
+#ifdef F32S_STAMPS
+__device__ unsigned long long f32s_stamps[4096 * 64];
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) f32s_stamps[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int mvg_f32s_read_stamps(unsigned long long* host, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(f32s_stamps), sizeof(unsigned long long) * 64 * n_blocks);
+}
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 using namespace f32s;
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
   const int rot = (w * 3) & 15;
   const long colb = 32 * w;                           // the wavefront's column block
 
+  STAMP(0);
   // residual rows in the accumulator layout, requested long before their use
   f32x4 tg[2][4];
 #pragma unroll
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     }
   }
   __syncthreads();
+  STAMP(1);
 
   // All workgroups walk the same weights; started together they request the same L2 lines at the same time.  The 32
   // workgroups of an XCD (blockIdx >> 3) start their first stage up to 15 k-steps apart -- a skew in TIME: the arithmetic of
@@ -418,6 +435,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
   f32x4 bvr[4];
   stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, nullptr, true, rot, lane);
   load_bias(bu + colb, bvr, lane);
+  STAMP(2);
   {
     f32x4 t1[2][4];
 #pragma unroll
@@ -435,6 +453,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
       for (int g = 0; g < 4; ++g) store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
   }
   __syncthreads();
+  STAMP(3);
 
   f32x4 y[2][4];
   if (has_ffn) {
@@ -446,22 +465,28 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     const bf16_t* wp2 = frag_ptr(W2, 0, w, 64, lane);
     // every stage's first fragments are requested one stage ahead, before the barriers in front of it (ring_prefetch)
     f32x4 pf1[4][3], pf2[4][3];
-    ring_prefetch<16, 4>(frag_ptr(W1, 0, cb4, 16, lane), 1024 * 256, pf1, rot);
+    // (the k-step rotation of a stage follows the COLUMN block only: rows of both row blocks -- and hence of every tile position --
+    // are summed in the same order)
+    const int rot1 = (cb4 * 5) & 15;
+    ring_prefetch<16, 4>(frag_ptr(W1, 0, cb4, 16, lane), 1024 * 256, pf1, rot1);
 #pragma unroll 1
     for (int c = 0; c < 1024 / FCH; ++c) {
       f32x16 a1[1], a2;
+      STAMP(4 + 4 * c);
       stage<1, 16, PLP, 4, true>(act, PLANE, 32 * mt1, frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane), 1024 * 256, a1, &a2, true,
-                                 rot, lane, pf1);
+                                 rot1, lane, pf1);
       a1[0] += a2;
+      STAMP(5 + 4 * c);
       load_bias(b1 + c * FCH + 32 * cb4, bvr, lane);
       ring_prefetch<8, 4>(wp2 + (long)c * 8 * 1024, 256 * 1024, pf2, rot & 7);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                                              // the previous chunk's second GEMM has read hb
       write_planes<1, PLP128>(hb, HPLANE, 32 * mt1, 32 * cb4, a1, bvr, true, one, lane);
       if (c + 1 < 1024 / FCH)
-        ring_prefetch<16, 4>(frag_ptr(W1, (c + 1) >> 1, 4 * ((c + 1) & 1) + cb4, 16, lane), 1024 * 256, pf1, rot);
+        ring_prefetch<16, 4>(frag_ptr(W1, (c + 1) >> 1, 4 * ((c + 1) & 1) + cb4, 16, lane), 1024 * 256, pf1, rot1);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      STAMP(6 + 4 * c);
       stage<2, 8, PLP128, 4, true>(hb, HPLANE, 0, wp2 + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
     }
     load_bias(b2 + colb, bvr, lane);
@@ -480,7 +505,9 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
         y[mt][g] += join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + PLANE),
                           *reinterpret_cast<const uint2*>(src + 2 * PLANE));
       }
+    STAMP(36);
     layernorm_rows(y, g3 + colb, be3 + colb, part, part2, lane, w);
+    STAMP(37);
   } else {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -542,6 +569,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
       if (ok) atomicOr(any_valid, 1);
     }
   }
+  STAMP(38);
   if (Wn) {
     // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets / logits Linear
     //      (projattn.py:180-181) while the rows are still on the CU.  Every wavefront passed the barriers above: `act` is free.
@@ -555,8 +583,10 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
         store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, x);
       }
     __syncthreads();
+    STAMP(39);
     if (colb < n_next) {
       stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, nullptr, true, (rot + 7) & 15, lane);
+      STAMP(40);
       load_bias(bn + colb, bvr, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -570,6 +600,7 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
           }
     }
   }
+  STAMP(41);
 }
 
 template <typename K>

@@ -314,14 +314,16 @@ def test_cfg5_full_stress_forward_properties():
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), name
 
 
-def test_cfg5_full_stress_fp32_permutation_and_shards_are_exact():
+@pytest.mark.parametrize("g_form", [False, True], ids=["gather_form", "g_form_fused_chains"])
+def test_cfg5_full_stress_fp32_permutation_and_shards_are_exact(g_form):
     """The fp32 path (reference arithmetic, no position-dependent rounding anywhere) at cfg-5's full size, 2 of its layers:
-    query permutation and shard concatenation are BIT-exact."""
+    query permutation and shard concatenation are BIT-exact -- in the gather form (unfused chain A + the fused fp32 chain B) and
+    in the G-sampling form (one-pass pyramid products, fused fp32 chains A and B: csrc/f32s.hip)."""
     from mvgformer_amd.factory import build_decoder_for_case, case_to_device
     case = build_case("cfg5", seed=3, layers=2)
     dec = build_decoder_for_case(case, DEV, dtype=torch.float32)
     for layer in dec.layers:            # one sampling form for every query count (see ProjAttn.g_sampling_f32)
-        layer.proj_attn.g_sampling_f32 = False
+        layer.proj_attn.g_sampling_f32 = g_form
     g = case_to_device(case, DEV)
     NQ, J = case.NQ, 15
     run = lambda t, p, r: dec(t, r, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None, query_pos=p,

@@ -8,7 +8,11 @@ mode=$1; shift
 variants=${1:-"0 1 2 4"}
 mkdir -p build/exp
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=fast -fno-slp-vectorize"
-if [ "$mode" = build ]; then
+if [ "$mode" = stamps ]; then
+  /opt/rocm/bin/hipcc $FLAGS -DF32S_STAMPS=1 -c mvgformer_amd/csrc/f32s.hip -o build/exp/f32s_stamps.o
+  objs=$(ls mvgformer_amd/csrc/*.o | grep -v f32s.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o build/exp/libmvg_stamps.so $objs build/exp/f32s_stamps.o
+elif [ "$mode" = build ]; then
   for v in $variants; do
     /opt/rocm/bin/hipcc $FLAGS -DF32S_KO=$v $EXTRA -c mvgformer_amd/csrc/f32s.hip -o build/exp/f32s_ko$v.o
     objs=$(ls mvgformer_amd/csrc/*.o | grep -v f32s.o)
