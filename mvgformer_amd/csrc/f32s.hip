@@ -20,6 +20,12 @@
 
 // Measurement hook (variant builds of tools/ab_f32s.sh only; the product is built without it): s_memtime stamps of one thread
 // per workgroup at phase boundaries, read back with mvg_f32s_read_stamps.
+#ifndef F32S_PYR_WIDE
+#define F32S_PYR_WIDE 1       // tiled pyramid kernel: 16-byte stores from the (row, 4 columns) accumulator layout
+#endif
+#ifndef F32S_WS_INTERLEAVE
+#define F32S_WS_INTERLEAVE 0
+#endif
 #ifdef F32S_STAMPS
 __device__ unsigned long long f32s_stamps[4096 * 64];
 #define STAMP(i)                                                                                   \
@@ -101,13 +107,35 @@ __device__ __forceinline__ void stage_swapped(const char* __restrict__ act, cons
 __device__ __forceinline__ void store_swapped(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[2],
                                               float bias, int lane) {
   const int h = lane >> 5;
+  float* dst = out + (r0 + 4 * h) * ld + col;
+  if (r0 + RM <= rows) {             // every tile but the last: no per-row predicate (32 exec regions per stage and wavefront)
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long row = r0 + 32 * mt + 8 * (e >> 2) + 4 * h + (e & 3);
-      if (row < rows) out[row * ld + col] = acc[mt][e] + bias;
+      for (int e = 0; e < 16; ++e) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (r0 + 4 * h + 32 * mt + 8 * (e >> 2) + (e & 3) < rows) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
+  }
+}
+
+// acc[mt][4 g + t] = out[row 32 mt + rl][column 8 g + 4 h + t of the block]  (f32s::stage, weights first): 16-byte stores
+__device__ __forceinline__ void store_rows4(float* __restrict__ out, long ld, long r0, long rows, int col0, const f32x16 (&acc)[2],
+                                            const f32x4 (&bias)[4], int lane) {
+  const int rl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 b = bias[g];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const long row = r0 + 32 * mt + rl;
+      const f32x4 v = {acc[mt][4 * g] + b[0], acc[mt][4 * g + 1] + b[1], acc[mt][4 * g + 2] + b[2], acc[mt][4 * g + 3] + b[3]};
+      if (row < rows) *reinterpret_cast<f32x4*>(out + row * ld + col0 + 8 * g + 4 * h) = v;
     }
+  }
 }
 
 __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv,
@@ -121,6 +149,12 @@ __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restric
   const bf16_t* wpv = frag_ptr(Wv, 0, w, 16, lane);
   const bf16_t* wpg = frag_ptr(Wg, 0, w, 16, lane);
   const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
+  f32x4 bias4[4], zero4[4];          // (row, 4 columns) layout: the value bias of this lane's columns, held for the whole launch
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    zero4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bias4[g] = bv ? *reinterpret_cast<const f32x4*>(bv + 32 * w + 8 * g + 4 * (lane >> 5)) : zero4[g];
+  }
   const bool has_g = 32 * w < ng;
   // (the weights do not change from tile to tile: without the empty asm below hipcc hoists all 96 fragment loads out of the
   // tile loop -- 384 registers, spilled)
@@ -133,32 +167,219 @@ __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restric
       x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
     }
   }
-  for (; tile < ntiles; tile += gridDim.x) {
+  int it = 0;
+  for (; tile < ntiles; tile += gridDim.x, ++it) {
     const long r0 = tile * RM;
     asm volatile("" : "+v"(wpv), "+v"(wpg));
+    if (it == 2) STAMP(0);
     __syncthreads();                               // the previous tile's stages have read the planes
+    if (it == 2) STAMP(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = i * NT + tid;
       store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, x[i]);
     }
+    if (it == 2) STAMP(2);
     __syncthreads();
+    if (it == 2) STAMP(3);
     const long nxt = tile + gridDim.x;
-    if (nxt < ntiles) {                            // the next tile's rows: in flight under this tile's stages
+    f32x16 acc[2];
+#if F32S_PYR_WIDE
+    stage<2, 16, PLP>(act, PLANE, 0, wpv, 65536, acc, nullptr, true, rot, lane);
+#else
+    stage_swapped<16, 4>(act, wpv, 65536, acc, rot, lane);
+#endif
+    if (it == 2) STAMP(4);
+    if (nxt < ntiles) {
+      // the next tile's rows: requested BEHIND the first stage's fragment loads (a wavefront's memory operations complete in
+      // order: in front of them every ring refill of that stage would wait for an HBM round trip), in flight under the second
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = i * NT + tid;
         x[i] = *reinterpret_cast<const f32x4*>(feat + min(nxt * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
       }
     }
-    f32x16 acc[2];
-    stage_swapped<16, 4>(act, wpv, 65536, acc, rot, lane);
+#if F32S_PYR_WIDE
+    store_rows4(value, 256, r0, rows, 32 * w, acc, bias4, lane);
+#else
     store_swapped(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, lane);
+#endif
+    if (it == 2) STAMP(5);
     if (has_g) {
+#if F32S_PYR_WIDE
+      stage<2, 16, PLP>(act, PLANE, 0, wpg, 65536, acc, nullptr, true, (rot + 7) & 15, lane);
+      if (it == 2) STAMP(6);
+      store_rows4(G, ng, r0, rows, 32 * w, acc, zero4, lane);
+#else
       stage_swapped<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+      if (it == 2) STAMP(6);
       store_swapped(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, lane);
+#endif
+    }
+    if (it == 2) STAMP(7);
+    if (it == 3) STAMP(8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pyramid products, weight-stationary.  The tiled kernel above streams 672 KB of weight planes per 64-row tile through the
+// CU's vector-memory path -- 672 one-KB fragment loads per tile next to 24.6 k cycles of MFMA: the path is as busy as the
+// matrix pipe, and every queueing delay stalls it (s_memtime: 45 k cycles per tile).  Here a workgroup keeps ONE of the two
+// weights on the CU for the whole launch -- 8 wavefronts (two per SIMD), a wavefront holds one 32-column block x 256 k x 3
+// planes, 12 of its 16 k-steps in registers -- and streams 32-row tiles of the pyramid through a double-buffered LDS image of
+// their planes.  Role of a workgroup: (blockIdx >> 3) & 1 = value or G; workgroups b and b + 8 share an XCD (b % 8) and walk
+// the same tiles, so a tile comes from HBM once and from that XCD's L2 the second time.  G is padded to 256 columns (its planes
+// are, by ops.split_swizzle_weight; wavefronts 6, 7 of a G workgroup multiply by zeros): both roles take the same time per tile.
+constexpr int WS_RM = 32, WS_PLANE = WS_RM * PLP;
+#ifndef F32S_WS_NSTREAM
+#define F32S_WS_NSTREAM 2
+#endif
+
+__global__ __launch_bounds__(NT) void pyramid_ws_f32s_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv,
+                                                             const float* __restrict__ bv, const bf16_t* __restrict__ Wg,
+                                                             float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
+  const int role = (blockIdx.x >> 3) & 1;
+  const long pair = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), npairs = gridDim.x >> 1;
+  const bf16_t* __restrict__ W = role ? Wg : Wv;
+  float* __restrict__ out = role ? G : value;
+  const int ld = role ? ng : 256;
+  const long ntiles = (rows + WS_RM - 1) / WS_RM;
+
+  // the wavefront's weights: column block w, three planes.  16 - NSTREAM of the 16 k-steps stay in registers for the whole launch
+  // (12 registers each); k-steps SLO .. SLO+NSTREAM-1 are re-read from L2 once per tile, one k-step ahead of their use, into one
+  // 12-register slot (with all 16 resident a wavefront of this 2-per-SIMD kernel would need more than its 256 registers).  The
+  // streamed k-steps sit EARLY in the loop: a wavefront's memory operations complete in order, and the second half of the
+  // loop requests the pyramid rows (HBM round trips nothing should queue behind).
+  constexpr int NSTREAM = F32S_WS_NSTREAM, SLO = 2;
+  auto resident = [](int ks) { return ks < SLO || ks >= SLO + NSTREAM; };
+  auto ridx = [](int ks) { return ks < SLO ? ks : ks - NSTREAM; };
+  f32x4 wr[16 - NSTREAM][3];
+  const bf16_t* wp = frag_ptr(W, 0, w, 16, lane);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+    if (resident(ks)) {
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) wr[ridx(ks)][sp] = *reinterpret_cast<const f32x4*>(wp + sp * 65536 + ks * 1024);
+    }
+  const float bias = (!role && bv) ? bv[32 * w + rl] : 0.f;
+  const bool col_ok = 32 * w < ld;
+
+  // The pyramid rows never pass through registers on their way in: wavefront w moves rows 4 w .. 4 w + 3 of a tile with one
+  // LDS-DMA instruction each (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KB row, lane l to byte 16 l of the row's slot in
+  // `raw`), a whole tile ahead of their use, and later reads back exactly the bytes its own lanes requested (ordered by its
+  // own vmcnt wait, no barrier).  hipcc does not see these loads (inline asm): it neither counts them (its own waits only get
+  // stricter: completion is in order) nor drains them in front of the workgroup barrier.
+  constexpr int RPW = WS_RM / 8;          // rows per wavefront and tile
+  char* raw = smem + 2 * 3 * WS_PLANE;
+  const unsigned raw_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)raw + (unsigned)w * RPW * 1024;
+  auto dma_row = [&](long tile_, int i) {
+    const float* gsrc = feat + min(tile_ * WS_RM + RPW * w + i, rows - 1) * 256 + lane * 4;
+    const unsigned dst = raw_lds + i * 1024;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  };
+  long tile = pair;
+  if (tile < ntiles) {
+    f32x4 x[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * WS_RM + RPW * w + i, rows - 1) * 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) store_split4<PLP>(smem, WS_PLANE, RPW * w + i, lane * 4, x[i]);
+    if (tile + npairs < ntiles) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) dma_row(tile + npairs, i);
     }
   }
+  // The outputs of a tile are stored from the NEXT tile's k loop (two 4-byte-per-lane stores per k-step 0..7): a block of 16
+  // stores in front of the workgroup barrier cost every wavefront ~1.2 k cycles of an idle matrix pipe plus the skew it
+  // caused at the barrier (s_memtime: 2 k cycles).
+  f32x16 prev;
+  long prev_r0 = -1;
+  auto store_rows = [&](const f32x16& v, long r0_, int e0, int e1) {
+    if (!col_ok) return;
+    float* dst = out + (r0_ + 4 * h) * ld + 32 * w + rl;
+    if (r0_ + WS_RM <= rows) {              // every tile but the last: no per-row predicate
+#pragma unroll
+      for (int e = e0; e < e1; ++e)
+        if (!((F32S_KO & 8) && e > 1)) dst[(long)(8 * (e >> 2) + (e & 3)) * ld] = v[e] + bias;
+    } else {
+#pragma unroll
+      for (int e = e0; e < e1; ++e)
+        if (r0_ + 4 * h + 8 * (e >> 2) + (e & 3) < rows) dst[(long)(8 * (e >> 2) + (e & 3)) * ld] = v[e] + bias;
+    }
+  };
+  int buf = 0, it = 0;
+  for (; tile < ntiles; tile += npairs, buf ^= 1, ++it) {
+    if (it == 3) STAMP(16);
+    const char* act = smem + buf * 3 * WS_PLANE;
+    char* nxt = smem + (buf ^ 1) * 3 * WS_PLANE;
+    const bool has_next = tile + npairs < ntiles, has_next2 = tile + 2 * npairs < ntiles;
+    asm volatile("" : "+v"(wp));            // the streamed fragments are loop-invariant: keep their loads in the loop
+    __syncthreads();        // this tile's planes are complete; the other buffer is no longer read
+    if (it == 3) STAMP(17);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const char* arow = act + rl * PLP + 16 * h;
+    f32x4 a_nxt[3], wst[3];
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) a_nxt[sp] = *reinterpret_cast<const f32x4*>(arow + sp * WS_PLANE);
+    if (NSTREAM > 0 && SLO == 0) {
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) wst[sp] = *reinterpret_cast<const f32x4*>(wp + sp * 65536 + SLO * 1024);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) a[sp] = __builtin_bit_cast(bf16x8, a_nxt[sp]);
+      if (ks + 1 < 16) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a_nxt[sp] = *reinterpret_cast<const f32x4*>(arow + sp * WS_PLANE + (ks + 1) * 32);
+      }
+      // filler of k-steps 8 .. 8+RPW-1: one of the wavefront's rows of the NEXT tile (in `raw` since the previous tile's k loop)
+      // is split into the other buffer.  No wait of its own: the streamed fragment loads of this tile's first k-steps were issued
+      // after those LDS-DMA loads and have been waited for -- loads complete in order.
+      if (ks >= 8 && ks < 8 + RPW && has_next && !(F32S_KO & 64)) {
+        if (NSTREAM == 0 && ks == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + (RPW * w + ks - 8) * 1024 + lane * 16);
+        store_split4<PLP>(nxt, WS_PLANE, RPW * w + ks - 8, lane * 4, xr);
+      }
+      bf16x8 bw[3];
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) bw[sp] = __builtin_bit_cast(bf16x8, resident(ks) ? wr[resident(ks) ? ridx(ks) : 0][sp] : wst[sp]);
+      constexpr int TB[6] = {2, 0, 1, 1, 0, 0}, TA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (F32S_KO & 4) {
+          acc[t] += __builtin_bit_cast(f32x4, bw[TB[t]])[0] * __builtin_bit_cast(f32x4, a[TA[t]])[1];
+          continue;
+        }
+        if (col_ok) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], bw[TB[t]], acc, 0, 0, 0);   // (G: wavefronts 6, 7 own padding)
+      }
+      // streamed fragments of the next k-step into the slot this step has just consumed
+      if (NSTREAM > 0 && ks + 1 >= SLO && ks + 1 < SLO + NSTREAM && !(F32S_KO & 32)) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) wst[sp] = *reinterpret_cast<const f32x4*>(wp + sp * 65536 + (ks + 1) * 1024);
+      }
+      // the previous tile's outputs, two rows of the accumulator per k-step
+      if (ks < 8 && prev_r0 >= 0) store_rows(prev, prev_r0, 2 * ks, 2 * ks + 2);
+      // ... and the same row of the tile after the next is requested into the slot just read
+      if (ks >= 8 && ks < 8 + RPW && has_next2 && !(F32S_KO & 16)) dma_row(tile + 2 * npairs, ks - 8);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it == 3 && (ks == 7 || ks == 11)) STAMP(ks == 7 ? 18 : 19);
+    }
+    if (it == 3) STAMP(20);
+    prev = acc;
+    prev_r0 = tile * WS_RM;
+    if (it == 3) STAMP(21);
+    if (it == 4) STAMP(22);
+  }
+  if (prev_r0 >= 0) store_rows(prev, prev_r0, 0, 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this wavefront is in flight when its LDS is released
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -630,6 +851,7 @@ int cu_count() {
 }  // namespace
 
 int g_f32s_skew = 6;      // tuning knob "f32s_skew": start-up skew between the workgroups of an XCD, in s_sleep(8) units per phase step
+int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
 
 extern "C" int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
@@ -639,6 +861,18 @@ extern "C" int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const 
   if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(G) |
        reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
     return MVG_E_BADARG;
+  if (g_f32s_pyr_ws) {
+    const size_t lds_ws = 2 * 3 * WS_PLANE + WS_RM * 1024;
+    static bool configured_ws[MVG_MAX_DEVICES] = {};
+    if (int rc = configure_lds(&pyramid_ws_f32s_kernel, lds_ws, configured_ws)) return rc;
+    const long nt32 = (rows + WS_RM - 1) / WS_RM;
+    long pairs = std::min<long>(nt32, (g_f32s_grid > 0 ? g_f32s_grid : cu_count()) / 2);
+    pairs = std::max<long>(8, (pairs / 8) * 8);          // whole groups of 8 pairs: role = (blockIdx >> 3) & 1
+    hipLaunchKernelGGL(pyramid_ws_f32s_kernel, dim3((int)(2 * pairs)), dim3(NT), lds_ws, (hipStream_t)stream, feat,
+                       (const bf16_t*)Wv_planes, bv, (const bf16_t*)Wg_planes, value, G, (long)rows, n_g);
+    MVG_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = 3 * PLANE;
   static bool configured[MVG_MAX_DEVICES] = {};
   if (int rc = configure_lds(&pyramid_f32s_kernel, lds, configured)) return rc;
