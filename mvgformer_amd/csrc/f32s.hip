@@ -20,6 +20,9 @@
 
 // Measurement hook (variant builds of tools/ab_f32s.sh only; the product is built without it): s_memtime stamps of one thread
 // per workgroup at phase boundaries, read back with mvg_f32s_read_stamps.
+#ifndef F32S_PRIO
+#define F32S_PRIO 1           // the two wavefronts of a SIMD alternate issue priority per k-step (f32s_dev.h: stage)
+#endif
 #ifndef F32S_PYR_WIDE
 #define F32S_PYR_WIDE 1       // tiled pyramid kernel: 16-byte stores from the (row, 4 columns) accumulator layout
 #endif
@@ -394,32 +397,62 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
                                                           int R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
-  int* rid = reinterpret_cast<int*>(smem + 3 * PLANE);          // global row of every tile row (-1: past the end)
-  int* keepf = rid + RM;                                        // in-image flag of every tile row
-  float* w2s = reinterpret_cast<float*>(keepf + RM);            // last pose layer (3 x 256 f32)
+  int* ridb = reinterpret_cast<int*>(smem + 3 * PLANE);         // [2][RM] global row of every tile row (-1: past the end), double-buffered
+  int* keepb = ridb + 2 * RM;                                   // [2][RM] in-image flag of every tile row
+  float* w2s = reinterpret_cast<float*>(keepb + 2 * RM);        // last pose layer (3 x 256 f32)
+  float* bias_s = w2s + 768;                                    // bp | b0 | b1 (3 x 256 f32): the epilogues read them from LDS
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31;
   const int ntiles = (R + RM - 1) / RM;
   const int rot = (w * 3) & 15;
-  for (int i = tid; i < 768; i += NT) w2s[i] = W2[i];
+  for (int i = tid; i < 768; i += NT) {
+    w2s[i] = W2[i];
+    bias_s[i] = (i < 256 ? bp : i < 512 ? b0 : b1)[i & 255];
+  }
   const bf16_t* wp1 = frag_ptr(Wp, 0, w, 16, lane);
   const bf16_t* wp2 = frag_ptr(W0, 0, w, 16, lane);
   const bf16_t* wp3 = frag_ptr(W1, 0, w, 16, lane);
   const float m0 = o_masked ? o_masked[0] : 0.f, m1 = o_masked ? o_masked[1] : 0.f, m2 = o_masked ? o_masked[2] : 0.f;
   const float bo0 = b2[0], bo1 = b2[1], bo2 = b2[2];
+  const int prio = F32S_PRIO ? (w >> 2) : -1;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int r0 = tile * RM;
-    asm volatile("" : "+v"(wp1), "+v"(wp2), "+v"(wp3));         // no hoisting of the (tile-invariant) weight loads: 576 registers
-    __syncthreads();                                            // rid / planes of the previous tile are no longer read
-    bool mine = false;
-    if (tid < RM) {
-      const int slot = r0 + tid;
-      const int g = slot < R ? (order ? order[slot] : slot) : -1;
-      rid[tid] = g;
-      mine = g >= 0 && inside[g] != 0;
-      keepf[tid] = mine ? 1 : 0;
+  // Software pipeline over the tiles of this workgroup (one workgroup per CU: nobody else hides a tile's dependent loads --
+  // order -> inside -> sampled rows, three round trips, 9 k cycles by s_memtime).  While tile t runs its stages, the row ids /
+  // flags of tile t + 1 are fetched (during stage 1) and its sampled rows are requested (behind stage 3's k loop: a
+  // wavefront's memory operations complete in order, so in front of a stage they would stall its fragment ring).
+  auto fetch_ids = [&](int tile_, int& g, int& k) {             // threads 0 .. RM-1
+    const int slot = tile_ * RM + tid;
+    g = (tile_ < ntiles && slot < R) ? (order ? order[slot] : slot) : -1;
+    k = (g >= 0 && inside[g] != 0) ? 1 : 0;
+  };
+  f32x4 x[8];
+  auto request_rows = [&](const int* rid_) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * NT + tid;
+      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid_[c >> 6], 0) * 256 + (c & 63) * 4);
     }
-    const bool any_inside = __syncthreads_or(mine) != 0;
+  };
+  int cur = 0;
+  {
+    int g = -1, k = 0;
+    if (tid < RM) {
+      fetch_ids(blockIdx.x, g, k);
+      ridb[tid] = g;
+      keepb[tid] = k;
+    }
+    __syncthreads();
+    if ((int)blockIdx.x < ntiles) request_rows(ridb);
+  }
+  int it = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it, cur ^= 1) {
+    int* rid = ridb + cur * RM;
+    int* keepf = keepb + cur * RM;
+    const int nxt_tile = tile + gridDim.x;
+    if (it == 1) STAMP(0);
+    asm volatile("" : "+v"(wp1), "+v"(wp2), "+v"(wp3));         // no hoisting of the (tile-invariant) weight loads: 576 registers
+    const bool any_inside = __syncthreads_or(tid < RM && keepf[tid] != 0) != 0;     // (also: the previous tile's planes are free)
+    if (it == 1) STAMP(1);
+    int g_n = -1, k_n = 0;
     if (!any_inside && o_masked) {                              // all-masked tile: attn = 0, o = the MLP of a zero row
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -432,39 +465,45 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
         og[1] = m1;
         og[2] = m2;
       }
+      if (tid < RM) {
+        fetch_ids(nxt_tile, g_n, k_n);
+        ridb[(cur ^ 1) * RM + tid] = g_n;
+        keepb[(cur ^ 1) * RM + tid] = k_n;
+      }
+      __syncthreads();
+      if (nxt_tile < ntiles) request_rows(ridb + (cur ^ 1) * RM);
       continue;
     }
     f32x4 pf[4][3];
-    ring_prefetch<16, 4>(wp1, 65536, pf, rot);                  // stage 1's first fragments, in flight under the tile load
-    {
-      f32x4 x[8];
+    ring_prefetch<16, 4>(wp1, 65536, pf, rot);                  // stage 1's first fragments
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid;
-        x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid[c >> 6], 0) * 256 + (c & 63) * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid;
-        store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, rid[c >> 6] >= 0 ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f});
-      }
+    for (int i = 0; i < 8; ++i) {                               // this tile's rows (requested during the previous tile) -> planes
+      const int c = i * NT + tid;
+      store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, rid[c >> 6] >= 0 ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f});
     }
     bool keep[2], all[2] = {true, true};
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) keep[mt] = keepf[mt * 32 + rl] != 0;                  // dq_decoder.py:585-586
+    if (tid < RM) fetch_ids(nxt_tile, g_n, k_n);                // next tile's ids: two dependent round trips, under stage 1
     __syncthreads();
+    if (it == 1) STAMP(2);
 
     // attn = inside * output_proj(samp)
     f32x16 acc[2];
     f32x4 bvr[4];
-    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp1, 65536, acc, nullptr, true, rot, lane, pf);
-    load_bias(bp + 32 * w, bvr, lane);
+    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp1, 65536, acc, nullptr, true, rot, lane, pf, prio);
+    if (it == 1) STAMP(3);
+    load_bias(bias_s + 32 * w, bvr, lane);
     ring_prefetch<16, 4>(wp2, 65536, pf, (rot + 5) & 15);
+    if (tid < RM) {
+      ridb[(cur ^ 1) * RM + tid] = g_n;
+      keepb[(cur ^ 1) * RM + tid] = k_n;
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, false, keep, lane);
     __syncthreads();
+    if (it == 1) STAMP(4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                               // attn rows -> global (needed for the view mean): 32 B per thread
       const int c = i * NT + tid, row = c >> 5, ch = c & 31, g = rid[row];
@@ -477,19 +516,28 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
         *reinterpret_cast<f32x4*>(dst + 4) = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
       }
     }
+    if (it == 1) STAMP(5);
     // pose_embed MLP layers 0, 1 (ReLU)
-    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp2, 65536, acc, nullptr, true, (rot + 5) & 15, lane, pf);
-    load_bias(b0 + 32 * w, bvr, lane);
+    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp2, 65536, acc, nullptr, true, (rot + 5) & 15, lane, pf, prio);
+    if (it == 1) STAMP(6);
+    load_bias(bias_s + 256 + 32 * w, bvr, lane);
     ring_prefetch<16, 4>(wp3, 65536, pf, (rot + 10) & 15);
     __builtin_amdgcn_sched_barrier(0);
+    if (it == 1) STAMP(20);
+    __syncthreads();
+    if (it == 1) STAMP(21);
+    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
+    if (it == 1) STAMP(22);
+    __syncthreads();
+    if (it == 1) STAMP(7);
+    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp3, 65536, acc, nullptr, true, (rot + 10) & 15, lane, pf, prio);
+    if (it == 1) STAMP(8);
+    load_bias(bias_s + 512 + 32 * w, bvr, lane);
+    if (nxt_tile < ntiles) request_rows(ridb + (cur ^ 1) * RM);    // the next tile's rows, in flight under the rest of this tile
     __syncthreads();
     write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
     __syncthreads();
-    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp3, 65536, acc, nullptr, true, (rot + 10) & 15, lane, pf);
-    load_bias(b1 + 32 * w, bvr, lane);
-    __syncthreads();
-    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
-    __syncthreads();
+    if (it == 1) STAMP(9);
     // last layer (3 outputs): 8 threads per row, 32 columns each in column order, then the balanced tree over the 8 lanes
     {
       const int row = tid >> 3, part = tid & 7;
@@ -526,9 +574,9 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
         og[2] = a3[2] + bo2;
       }
     }
+    if (it == 1) STAMP(10);
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // chain B: one workgroup = 4 person-queries x 15 joints (60 token rows in a 64-row tile).
@@ -890,7 +938,7 @@ extern "C" int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside
                                         void* stream) {
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
-  const size_t lds = 3 * PLANE + 2 * RM * sizeof(int) + 768 * sizeof(float);
+  const size_t lds = 3 * PLANE + 4 * RM * sizeof(int) + 2 * 768 * sizeof(float);
   static bool configured[MVG_MAX_DEVICES] = {};
   if (int rc = configure_lds(&chain_a_f32s_kernel, lds, configured)) return rc;
   const int ntiles = (rows + RM - 1) / RM;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void ring_prefetch(const bf16_t* __restrict__ wp, lon
 template <int MT, int KSTEPS, int PITCH, int RING = 4, bool PRE = false>
 __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_bytes, int row0, const bf16_t* __restrict__ wp,
                                       long wplane, f32x16 (&acc)[MT], f32x16* acc2, bool zero, int rot, int lane,
-                                      f32x4 (*pre)[3] = nullptr) {
+                                      f32x4 (*pre)[3] = nullptr, int prio_half = -1) {
   static_assert((KSTEPS & (KSTEPS - 1)) == 0, "KSTEPS must be a power of two");
   const int rl = lane & 31, h = lane >> 5;
   if (zero) {
@@ -114,6 +114,14 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
+    // prio_half = 0 | 1 (the wavefront's half of an 8-wavefront workgroup: the two wavefronts of a SIMD differ in it): the two
+    // take turns at the higher issue priority, k-step by k-step.  With equal priorities the older wavefront of a SIMD is served
+    // first throughout, finishes its stage early and leaves the younger one to run the rest alone, uncovered (s_memtime: the
+    // barrier behind a stage waited 4 k cycles for it).
+    if (prio_half >= 0) {
+      if ((ks & 1) == prio_half) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     bf16x8 a[MT][3], b[3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -151,6 +159,7 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
       }
     __builtin_amdgcn_sched_barrier(0);     // keep the ring refills a full RING of k-steps ahead of their MFMAs (chain_dev.h)
   }
+  if (prio_half >= 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // bias of the wavefront's column block: bv[g] = bias[8 g + 4 h .. + 3]
