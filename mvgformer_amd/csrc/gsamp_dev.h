@@ -72,6 +72,13 @@ struct GsampWin {
 };
 
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef MVG_GSAMP_NT0
+#define MVG_GSAMP_NT0 0
+#endif
+__device__ __forceinline__ uint4 gs_load_nt(const char* p) {
+  const gs_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(p));      // global_load_dwordx4 ... nt
+  return uint4{v.x, v.y, v.z, v.w};
+}
 __device__ __forceinline__ uint4 lds_load16(lds_bytes_t p) {
   const gs_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const gs_u32x4*>(p);   // ds_read_b128
   return uint4{v.x, v.y, v.z, v.w};
@@ -268,8 +275,28 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
         raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
         raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                            \
       }
+#define MVG_QS_NT(SS)                                                                                   \
+      {                                                                                                 \
+        const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
+        const unsigned dxs = quad_bcast<SS>(co_x);                                                      \
+        raw[SS][0] = gs_load_nt(vp_bytes + ot);                                                         \
+        raw[SS][1] = gs_load_nt(vp_bytes + (ot + dxs));                                                 \
+        raw[SS][2] = gs_load_nt(vp_bytes + ob);                                                         \
+        raw[SS][3] = gs_load_nt(vp_bytes + (ob + dxs));                                                 \
+      }
+#if MVG_GSAMP_NT0
+      // measurement variant: the level-0 gathers (3 x reuse) with the nt policy, so that they do not evict the
+      // high-reuse level-1 / 2 and G lines from the 32-KB L1
+      if (it * NB < P) {
+        MVG_QS_NT(0) MVG_QS_NT(1) MVG_QS_NT(2) MVG_QS_NT(3)
+      } else {
+        MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
+      }
+#else
       MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
+#endif
 #undef MVG_QS
+#undef MVG_QS_NT
       const unsigned pw_t = cw_t, pw_b = cw_b;        // this batch's weights, broadcast at blend time (fewer live VGPRs)
       __builtin_amdgcn_sched_barrier(0);
       // next batch's coordinates while the gathers are in flight (the last iteration recomputes batch 0: branch-free)
