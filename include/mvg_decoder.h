@@ -168,6 +168,21 @@ int mvg_linear_ordered(const float* A, int lda, const float* W, const float* bia
                        const uint8_t* rowmask, int relu, int M, int N, int K, const int32_t* order,
                        const uint8_t* inside, const float* masked_row, void* stream);
 
+/* Split-K form of the fp32 mvg_linear for reductions far longer than the output is wide -- the weight gradient of a Linear under
+ * autograd, dW (N_out, K_in) = dY^T X summed over 10^4 .. 10^5 rows (lib/models/dq_decoder.py:659-717,763-778 trained by
+ * run/train_3d.py): partial[z] (M, N) = A[:, z K/splits : (z + 1) K/splits] @ W[:, same range]^T for z < splits; the caller sums
+ * the partials (a fixed order: deterministic).  A (M, K) / W (N, K) fp32 with leading dimensions lda / ldw; K / splits a multiple
+ * of 32; no bias / activation. */
+int mvg_linear_splitk_f32(const float* A, int lda, const float* W, int ldw, float* partial, int M, int N, int K, int splits,
+                          void* stream);
+
+/* The weight gradient itself, from the row-major tensors autograd holds: partial[z] (N, K) = sum over the rows of slice z of
+ * dY[r][n] X[r][k]  (dY (rows, N), X (rows, K) fp32, leading dimensions ldy / ldx; the rows are cut into `splits` slices of whole
+ * 32-row slabs, slices past the end write zeros).  Split-form products like mvg_linear; the operands are transposed on their way
+ * into LDS, no dY^T / X^T copies.  N, K multiples of 4. */
+int mvg_linear_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, int rows, int N, int K, int splits,
+                         void* stream);
+
 /* mvg_linear with the activation formed as A + A2 on load (A2: fp32, same shape and leading dimension as A, or NULL):
  * the query term of the first layer, Linear(tgt + query_pos) (dq_decoder.py:580 `with_pos_embed` + projattn.py:180-181),
  * without a separate elementwise pass over the two (B*Lq, 256) tensors. */

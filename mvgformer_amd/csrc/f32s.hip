@@ -24,7 +24,7 @@
 #define F32S_PRIO 1           // the two wavefronts of a SIMD alternate issue priority per k-step (f32s_dev.h: stage)
 #endif
 #ifndef F32S_PYR_WIDE
-#define F32S_PYR_WIDE 1       // tiled pyramid kernel: 16-byte stores from the (row, 4 columns) accumulator layout
+#define F32S_PYR_WIDE 0       // tiled pyramid kernel: 16-byte stores from the (row, 4 columns) accumulator layout
 #endif
 #ifndef F32S_WS_INTERLEAVE
 #define F32S_WS_INTERLEAVE 0

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
                                                      const uint8_t* __restrict__ rowmask, int relu, int M, int N,
                                                      int K, const int* __restrict__ order = nullptr,
                                                      const uint8_t* __restrict__ inside = nullptr,
-                                                     const float* __restrict__ masked_row = nullptr, int xcd_map = 0) {
+                                                     const float* __restrict__ masked_row = nullptr, int xcd_map = 0,
+                                                     int ldw = 0, int k_split = 0) {
   using TW = typename std::conditional<BF16, bf16_t, float>::type;
   const TW* __restrict__ W = reinterpret_cast<const TW*>(Wv);
   constexpr int KSLAB = BF16 ? 64 : 32;   // K elements per 128-byte slab
@@ -137,9 +138,17 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
     by = group * 8 + (within - bx * R);
   }
   const int m0 = by * BM, n0 = bx * BN;
-  const TA* Ab = A + (long)m0 * lda;
-  const TA* A2b = A2 ? A2 + (long)m0 * lda : nullptr;      // optional addend (fp32 storage only): A + A2 formed on load
-  const TW* Wb = W + (long)n0 * K;
+  // split K (mvg_linear_splitk: the weight gradient dW = dY^T X, whose reduction runs over hundreds of thousands of rows and whose
+  // output is one or four tiles): slice z = blockIdx.z works on k in [z k_split, (z + 1) k_split) and writes its own (M, N) partial
+  const long wld = ldw > 0 ? ldw : K;
+  const long koff = k_split > 0 ? (long)blockIdx.z * k_split : 0;
+  if (k_split > 0) {
+    out += (long)blockIdx.z * M * ldc;
+    K = k_split;
+  }
+  const TA* Ab = A + (long)m0 * lda + koff;
+  const TA* A2b = A2 ? A2 + (long)m0 * lda + koff : nullptr;      // optional addend (fp32 storage only): A + A2 formed on load
+  const TW* Wb = W + (long)n0 * wld + koff;
   const int mrows = min(BM, M - m0), nrows = min(BN, N - n0);
   __shared__ int rid[IDX ? BM : 1];                         // IDX: global row of every tile row (-1: past the end)
   if constexpr (IDX) {
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int c = tid + 256 * i;
-      cb[i] = load_chunk<TW, BF16>(Wb, (long)K, c >> 3, nrows, k0, c & 7);
+      cb[i] = load_chunk<TW, BF16>(Wb, wld, c >> 3, nrows, k0, c & 7);
     }
   };
   auto lstore = [&]() {
@@ -349,6 +358,124 @@ __global__ __launch_bounds__(256, (BN > 128 ? 2 : (SPLIT ? 3 : 1))) void linear_
   }
 }
 
+// Weight gradient of a Linear under autograd:  dW[n][k] = sum_r dY[r][n] X[r][k]  (both operands row-major over the rows r that
+// are the reduction: a "TN" product).  mvg_linear wants both operands K-major, i.e. dY^T and X^T -- as torch copies those two
+// transposes were 37 % of a training step (profiles/r04_experiments.txt).  Here the transposition happens on the way into LDS:
+// a thread loads an 8-row x 4-column patch of its operand's 32-row slab (8 x 16 B), and writes, per column and split part, the 8
+// row values as ONE 16-byte LDS store into the split form's plane layout (row = output index, 32 k per slab) -- the compute
+// phase is linear_kernel's.  blockIdx.z cuts the rows into slices; every slice writes its own (N, K) partial (summed by the caller
+// in slice order: deterministic).
+__device__ __forceinline__ void split8_store(char* lds, int row, int slot, const float (&v)[8]) {
+  float r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = v[i];
+#pragma unroll
+  for (int sp = 0; sp < 3; ++sp) {
+    uint4 p;
+    p.x = pack_bf16(r[0], r[1]);
+    p.y = pack_bf16(r[2], r[3]);
+    p.z = pack_bf16(r[4], r[5]);
+    p.w = pack_bf16(r[6], r[7]);
+    if (sp < 2) {
+      r[0] -= __uint_as_float(p.x << 16); r[1] -= __uint_as_float(p.x & 0xffff0000u);
+      r[2] -= __uint_as_float(p.y << 16); r[3] -= __uint_as_float(p.y & 0xffff0000u);
+      r[4] -= __uint_as_float(p.z << 16); r[5] -= __uint_as_float(p.z & 0xffff0000u);
+      r[6] -= __uint_as_float(p.w << 16); r[7] -= __uint_as_float(p.w & 0xffff0000u);
+    }
+    *reinterpret_cast<uint4*>(lds + row * SPITCH + 64 * sp + split_slot(row, slot)) = p;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_f32s_kernel(const float* __restrict__ dY, long ldy, const float* __restrict__ X, long ldx,
+                                                            float* __restrict__ partial, int rows, int N, int K, int rows_per_split) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * SPITCH];
+  char* ldsA = lds;                 // dY^T tile: row = output feature n (of dY), 32 reduction rows per slab
+  char* ldsB = lds + BM * SPITCH;   // X^T tile: row = input feature k
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, rl = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long r_begin = (long)blockIdx.z * rows_per_split, r_end = min((long)rows, r_begin + rows_per_split);
+  // loader role: threads 0..127 stage dY, 128..255 stage X; patch = 8 rows (rgrp) x 4 columns (cgrp) of the 32 x 128 slab
+  const int opnd = tid >> 7, p = tid & 127, rgrp = p >> 5, cgrp = p & 31;
+  const float* src = opnd ? X : dY;
+  const long ld = opnd ? ldx : ldy;
+  const int width = opnd ? K : N, c0 = (opnd ? n0 : m0) + 4 * cgrp;
+  char* dst = opnd ? ldsB : ldsA;
+  f32x4 x[8];
+  auto gload = [&](long r0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long r = r0 + 8 * rgrp + i;
+      // clamped address + select: rows past the slice and columns past the operand contribute zeros
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + min(r, (long)rows - 1) * ld + min(c0, width - 4));
+      x[i] = (r < r_end && c0 < width) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v[8] = {x[0][c], x[1][c], x[2][c], x[3][c], x[4][c], x[5][c], x[6][c], x[7][c]};
+      split8_store(dst, 4 * cgrp + c, rgrp, v);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nslab = (int)((r_end - r_begin + 31) / 32);
+  if (nslab > 0) {
+    gload(r_begin);
+    lstore();
+  }
+  __syncthreads();
+  for (int t = 0; t < nslab; ++t) {
+    if (t + 1 < nslab) gload(r_begin + (long)(t + 1) * 32);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a[i][sp] = *reinterpret_cast<const bf16x8*>(ldsA + (wm * 64 + i * 32 + rl) * SPITCH + 64 * sp + split_slot(rl, 2 * g + h));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          b[j][sp] = *reinterpret_cast<const bf16x8*>(ldsB + (wn * 64 + j * 32 + rl) * SPITCH + 64 * sp + split_slot(rl, 2 * g + h));
+      }
+      constexpr int TB[6] = {2, 0, 1, 1, 0, 0}, TA_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][TB[tt]], a[i][TA_[tt]], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (t + 1 < nslab) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  // acc[i][j][4 g + t] = dW[m0 + wm*64 + i*32 + rl][n0 + wn*64 + j*32 + 8 g + 4 h + t]
+  float* outz = partial + (long)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + rl;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+        if (m < N && n < K)
+          *reinterpret_cast<f32x4*>(outz + (long)m * K + n) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+      }
+  }
+}
+
 template <typename TA, bool BF16, typename TO, int BM, int BN>
 int launch_linear_tile(const void* A, const void* A2, long lda, const void* W, const float* bias, void* out, long ldc,
                        const uint8_t* rowmask, int relu, int M, int N, int K, hipStream_t st) {
@@ -418,6 +545,36 @@ extern "C" int mvg_linear_ordered(const float* A, int lda, const float* W, const
   if (g_linear_tiles && tiles128 < 384 && M > 64)
     return launch_linear_idx<64>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, st);
   return launch_linear_idx<128>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, st);
+}
+
+extern "C" int mvg_linear_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, int rows, int N, int K, int splits,
+                                    void* stream) {
+  if (!dY || !X || !partial || rows <= 0 || N <= 0 || K <= 0 || splits <= 0) return MVG_E_BADARG;
+  if (N % 4 != 0 || K % 4 != 0 || ldy % 4 != 0 || ldx % 4 != 0 || ldy < N || ldx < K) return MVG_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(partial)) % 16 != 0) return MVG_E_BADARG;
+  const int rps = ((rows + splits - 1) / splits + 31) / 32 * 32;          // whole 32-row slabs per slice
+  dim3 grid((K + 127) / 128, (N + 127) / 128, splits);
+  hipLaunchKernelGGL(wgrad_f32s_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, X, (long)ldx, partial, rows, N, K, rps);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mvg_linear_splitk_f32(const float* A, int lda, const float* W, int ldw, float* partial, int M, int N, int K, int splits,
+                                     void* stream) {
+  if (!A || !W || !partial || M <= 0 || N <= 0 || K <= 0 || splits <= 0) return MVG_E_BADARG;
+  if (K % splits != 0 || (K / splits) % 32 != 0 || N % 8 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K) return MVG_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(partial)) % 16 != 0) return MVG_E_BADARG;
+  dim3 grid((N + 127) / 128, (M + 127) / 128, splits);
+  if (g_f32_split)
+    hipLaunchKernelGGL((linear_kernel<float, false, float, 128, 128, false, true>), grid, dim3(256), 0, (hipStream_t)stream, A,
+                       (const float*)nullptr, (long)lda, (const void*)W, (const float*)nullptr, partial, (long)N, (const uint8_t*)nullptr, 0,
+                       M, N, K, nullptr, nullptr, nullptr, 0, ldw, K / splits);
+  else
+    hipLaunchKernelGGL((linear_kernel<float, false, float, 128, 128>), grid, dim3(256), 0, (hipStream_t)stream, A, (const float*)nullptr,
+                       (long)lda, (const void*)W, (const float*)nullptr, partial, (long)N, (const uint8_t*)nullptr, 0, M, N, K, nullptr,
+                       nullptr, nullptr, 0, ldw, K / splits);
+  MVG_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,

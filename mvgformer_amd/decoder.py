@@ -108,6 +108,58 @@ class DecoderContext:
                            src_views[0].device).pack(src_views)
 
 
+class PyramidPipeline:
+    """View-group schedule of the query-independent GEMMs for pyramids that do not fit the 256-MB Infinity Cache (cfg-5: 31 views,
+    value planes + G of one layer = 1.1 GB).  The plain schedule issues every layer's products up front on the side stream; by the
+    time a layer's sampler gathers from them they come from HBM (the same launch measured 109 us warm against 143 us cold at
+    cfg-2).  Here the images are cut into groups of `group` views; item k = (layer, group) of the sequence is produced on the
+    side stream `depth` items ahead of the sampler launch that consumes it -- its production is issued when item k - depth has
+    been consumed (an event recorded on the main stream) -- so a sampler launch finds its planes written a group ago.
+    Everything is fork / join of two streams: capturable as one HIP graph."""
+
+    def __init__(self, layers, feat, n_img, group, depth, side):
+        self.layers, self.feat, self.side, self.depth = list(layers), feat, side, depth
+        self.bounds = [(i, min(i + group, n_img)) for i in range(0, n_img, group)]
+        self.n_groups = len(self.bounds)
+        self.items = [(l, g) for l in range(len(self.layers)) for g in range(self.n_groups)]
+        self.ready = {}
+        self.next_item = 0
+        self.index = {id(layer.proj_attn): l for l, layer in enumerate(self.layers)}
+        for layer in self.layers:
+            layer.proj_attn._pipeline = self
+        feat.record_stream(side)
+        for _ in range(min(depth, len(self.items))):
+            self._produce(None)
+
+    def _produce(self, after):
+        if self.next_item >= len(self.items):
+            return
+        l, g = self.items[self.next_item]
+        self.next_item += 1
+        if after is not None:
+            self.side.wait_event(after)
+        with torch.cuda.stream(self.side):
+            i0, i1 = self.bounds[g]
+            self.layers[l].proj_attn.project_pyramid_group(self.feat, i0, i1)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.ready[(l, g)] = ev
+
+    def wait_ready(self, proj_attn, g):
+        torch.cuda.current_stream().wait_event(self.ready[(self.index[id(proj_attn)], g)])
+        return self.bounds[g]
+
+    def consumed(self, proj_attn, g):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._produce(ev)
+
+    def close(self):
+        for layer in self.layers:
+            layer.proj_attn._pipeline = None
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
 class MvPDecoderLayer(nn.Module):
     """helpers shared with the MvP base class (mvp_decoder.py:49-105)."""
 
@@ -415,10 +467,14 @@ class DQDecoderLayer(MvPDecoderLayer):
         ref_lvl = r_all.unsqueeze(2) * WH / (WH - 1)                               # dq_decoder.py:570-573
         a_all = self.proj_attn(x.repeat(V, 1, 1), ref_lvl, src_views, None, src_spatial_shapes, level_start_index)
         a_all = inside_all.unsqueeze(-1).to(a_all.dtype) * a_all                   # dq_decoder.py:585-586
+        from .functions import linear as lin
         mean = a_all.view(V, B, Lq, C).mean(0)
-        tgt_update = self.norm2(tgt + self.dropout2(self.feature_update_mlp(mean)))
-        if self.open_forward_ffn:
-            tgt_update = self.forward_ffn(tgt_update)
+        tgt_update = self.norm2(tgt + self.dropout2(lin(mean, self.feature_update_mlp.weight, self.feature_update_mlp.bias)))
+        if self.open_forward_ffn:           # forward_ffn (mvp_decoder.py:94-98) with the two GEMMs on mvg_linear
+            h1 = lin(tgt_update, self.linear1.weight, self.linear1.bias, relu=self.activation_name == "relu")
+            if self.activation_name != "relu":
+                h1 = self.activation(h1)
+            tgt_update = self.norm3(tgt_update + self.dropout4(lin(self.dropout3(h1), self.linear2.weight, self.linear2.bias)))
         prob = self.class_embed(tgt_update).view(B, NQ, J, 2).sigmoid().mean(2)
         if not self.filter_query or self.query_filter_method == "all":
             valid = torch.ones((B, NQ), dtype=torch.bool, device=dev)
@@ -430,7 +486,11 @@ class DQDecoderLayer(MvPDecoderLayer):
             valid = prob[..., 1] > threshold
         if not bool(valid.any()):
             valid[0, 0] = True                                                 # dq_decoder.py:620-623
-        off, cl = self.pose_embed(a_all)                                        # (V*B,Lq,2), (V*B,Lq)
+        hp = a_all                                                              # offset_net (dq_decoder.py:97-111)
+        pl = self.pose_embed.MLP.layers
+        for i, layer_ in enumerate(pl):
+            hp = lin(hp, layer_.weight, layer_.bias, relu=i < len(pl) - 1)
+        off, cl = hp[..., :2], hp[..., -1]                                      # (V*B,Lq,2), (V*B,Lq)
         ref2d = ((r_all + off / img) * img).view(V, B, Lq, 2).transpose(0, 1)    # (B,V,Lq,2)
         proj2d = (r_all * img).view(V, B, Lq, 2).transpose(0, 1)
         conf = torch.softmax(cl.reshape(V, B, Lq).transpose(0, 1), 1)
@@ -652,6 +712,11 @@ class DQDecoder(MvPDecoder):
         self._side_stream = None
         # layer l's fused chain B also computes layer l+1's query term xw = (tgt' + query_pos) W^T + b (bf16 path)
         self.fuse_next_query_term = True
+        # view groups (PyramidPipeline): MVG_VIEW_GROUP = views per group (0 = off, the default: measured SLOWER at cfg-5, 15.7 ->
+        # 16.3-17.7 ms, with the sampler's FETCH_SIZE unchanged -- profiles/r04_experiments.txt; "auto" = 3 views once one layer's
+        # value planes + G exceed the Infinity Cache), MVG_VIEW_GROUP_DEPTH = groups produced ahead of the sampler
+        self.view_group = os.environ.get("MVG_VIEW_GROUP", "0")
+        self.view_group_depth = int(os.environ.get("MVG_VIEW_GROUP_DEPTH", "2"))
 
     def set_compute_dtype(self, dtype):
         for layer in self.layers:
@@ -680,6 +745,19 @@ class DQDecoder(MvPDecoder):
                 l.prepare_caches()
         self._side_stream.wait_stream(torch.cuda.current_stream())
         return self._side_stream
+
+    def _view_group_size(self, ctx):
+        """views per group of the PyramidPipeline, or 0 for the plain schedule (bf16 fast path with the pairs binned per layer only)"""
+        l0 = self.layers[0]
+        if not (l0.compute_dtype == torch.bfloat16 and all(l.proj_attn.sort_pairs not in (False, "first") for l in self.layers)):
+            return 0
+        if ctx.feat.shape[1] * l0.num_joints == 0 or ctx.feat.shape[0] // max(ctx.B, 1) < 2:
+            return 0
+        if self.view_group == "auto":
+            per_layer = ctx.feat.shape[0] * ctx.levels.S * (512 + 384)          # bytes of one layer's value planes + G
+            return 3 if per_layer > (256 << 20) and ctx.V >= 6 else 0
+        g = int(self.view_group)
+        return g if 0 < g < ctx.V else 0
 
     def launch_pyramid_projections(self, ctx, side=None):
         """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
@@ -722,7 +800,7 @@ class DQDecoder(MvPDecoder):
         output = tgt
         layer0 = self.layers[0]
         ctx = context
-        side = None
+        side = pipeline = None
         hs_buf = flags = geo_buf = None
         try:
             if ctx is None:
@@ -738,8 +816,13 @@ class DQDecoder(MvPDecoder):
             inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
             ref_points_2d = None
             side = self.fork_side_stream(tgt.device, (tgt.shape[1], ctx.levels.L, ctx.levels.S))
+            pipeline = None
             if side is not None:
-                self.launch_pyramid_projections(ctx, side)
+                group = self._view_group_size(ctx)
+                if group:
+                    pipeline = PyramidPipeline(self.layers, ctx.feat, ctx.feat.shape[0], group * ctx.B, self.view_group_depth, side)
+                else:
+                    self.launch_pyramid_projections(ctx, side)
             # the fused chain writes every layer's hidden state straight into its slice of the stacked output
             hs_buf = None
             if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
@@ -779,6 +862,9 @@ class DQDecoder(MvPDecoder):
                 layer._next_layer = None
                 layer._xw_in = None
                 layer._proj_in = None
+            if pipeline is not None:
+                pipeline.close()
+                side = None
             self.join_pyramid_projections(side)
         if self.return_intermediate:
             in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape

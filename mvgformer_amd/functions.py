@@ -1,5 +1,8 @@
 """autograd wrapper of the sampling op -- mirror of
 lib/models/ops/functions/deform_func.py:34-65 (DeformFunction)."""
+import os
+
+import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -32,3 +35,61 @@ class DeformFunction(Function):
         with DF._device_of(value):
             gv, gl, ga = ops.msda_backward(value, shapes, starts, loc, attn, grad_output.contiguous(), host=ctx.host_levels)
         return gv, None, None, gl, ga, None
+
+
+# training-path GEMMs: "f32s" = this repo's mvg_linear (fp32 storage, fp32-accurate products on the bf16 matrix pipe from 3-way split
+# operands -- csrc/gemm.hip) for forward, dgrad and wgrad; "torch" = nn.functional.linear (rocBLAS fp32: the f32-input MFMA runs at
+# 1/16 of the bf16 rate and was 40 % of a training step's kernel time, profiles/r02_train_step.txt)
+TRAIN_GEMM = os.environ.get("MVG_TRAIN_GEMM", "f32s")
+
+
+class LinearF32S(Function):
+    """y = act(x W^T + b) with all three GEMMs of its autograd on mvg_linear's split form:
+         forward  y  = x W^T              (rows, K) x (N, K)^T, bias + ReLU in the epilogue
+         dgrad    dx = dy W               = mvg_linear(dy, W^T as an (K, N) "weight")
+         wgrad    dW = dy^T x             = mvg_linear_wgrad_f32 (the reduction runs over the rows; split into slices)
+       (the Linear + ReLU + Linear chains of lib/models/dq_decoder.py:659-717,763-778, mvp_decoder.py:94-98 and
+       lib/models/ops/modules/projattn.py:169,180-181,203 under torch autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        y = ops.linear(x2, weight.contiguous(), bias, out_dtype=torch.float32, relu=bool(relu))
+        ctx.relu = bool(relu)
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        x2, weight, y = ctx.saved_tensors
+        N, K = weight.shape
+        dy = grad_y.reshape(-1, N)
+        if ctx.relu:
+            dy = dy * (y > 0)
+        elif not dy.is_contiguous():
+            dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(dy, weight.t().contiguous(), None, out_dtype=torch.float32).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy, x2)          # no dy^T / x^T copies: transposed on the way into LDS
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    """nn.functional.linear (+ ReLU) for the training path: LinearF32S where mvg_linear's shape rules hold (fp32 on the GPU,
+    in_features % 32 == 0, out_features % 32 == 0 -- every 256 / 1024 / 192-wide Linear of the decoder), torch elsewhere (the
+    2- and 3-output heads)."""
+    N, K = weight.shape
+    if (TRAIN_GEMM == "f32s" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 32 == 0
+            and N % 32 == 0 and x.numel() > 0):
+        return LinearF32S.apply(x, weight, bias, relu)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if relu else y

@@ -266,6 +266,45 @@ def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None, add=N
     return out
 
 
+def linear_splitk(a, w, splits=None):
+    """a (M, K) @ w (N, K)^T in fp32 with the reduction cut into `splits` slices (mvg_linear_splitk_f32) -> (M, N): the weight
+    gradient of a Linear, dW = dY^T X, whose K is the row count.  The partials are summed here in slice order."""
+    M, K = a.shape
+    N = w.shape[0]
+    if a.dtype != torch.float32 or w.dtype != torch.float32 or a.stride(1) != 1 or w.stride(1) != 1 or w.shape[1] != K:
+        raise RuntimeError("mvg_linear_splitk: fp32 K-contiguous operands with equal K required")
+    if splits is None:      # enough slices to fill the chip with 128 x 128 tiles, slices of whole 32-element slabs
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min(K // 32, (512 + tiles - 1) // tiles))
+        while K % (splits * 32) != 0 and splits > 1:
+            splits -= 1
+    if K % (splits * 32) != 0:
+        raise RuntimeError("mvg_linear_splitk: K = %d is not %d slices of whole 32-element slabs" % (K, splits))
+    partial = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    with _timed("linear_splitk_%dx%dx%d" % (M, N, K)):
+      L.check(L.load().mvg_linear_splitk_f32(L.ptr(a), a.stride(0), L.ptr(w), w.stride(0), L.ptr(partial), M, N, K, splits,
+                                             L.stream_ptr()), "mvg_linear_splitk_f32")
+    return partial.sum(0) if splits > 1 else partial[0]
+
+
+def linear_wgrad(dy, x, splits=None):
+    """dW (N, K) = dy^T x for dy (rows, N), x (rows, K) fp32 row-major (mvg_linear_wgrad_f32): the weight gradient of a Linear,
+    straight from the tensors autograd holds.  The per-slice partials are summed here in slice order."""
+    rows, N = dy.shape
+    K = x.shape[1]
+    if (dy.dtype != torch.float32 or x.dtype != torch.float32 or dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != rows
+            or N % 4 or K % 4):
+        raise RuntimeError("mvg_linear_wgrad: fp32 row-major (rows, N) / (rows, K) operands with N, K multiples of 4 required")
+    if splits is None:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min((rows + 255) // 256, (768 + tiles - 1) // tiles))
+    partial = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+    with _timed("linear_wgrad_%dx%dx%d" % (N, K, rows)):
+      L.check(L.load().mvg_linear_wgrad_f32(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(partial), rows, N, K, splits,
+                                            L.stream_ptr()), "mvg_linear_wgrad_f32")
+    return partial.sum(0) if splits > 1 else partial[0]
+
+
 def linear_ordered(a, w, bias, order, inside, masked_row, relu=False, rowmask=None, out=None):
     """fp32 ``linear`` over the rows in processing order ``order`` (mvg_linear_ordered): tiles without a row of ``inside`` write
     ``masked_row`` (N,) to all their rows instead of computing them.  Rows keep their places in a / out."""
@@ -357,21 +396,31 @@ def gsamp_column_order(device=None):
     return torch.where(w < 16, 16 * g + w, 128 + 8 * g + (w - 16))
 
 
-def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None):
+def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None, out=None, images=None):
     """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h); the 192
     columns of G and xw are in gsamp_column_order().
-    pair_mask (n_img*Lq) u8: rows with 0 are zero-filled, not sampled; order (n_img*Lq) i32 from bin_pairs."""
+    pair_mask (n_img*Lq) u8: rows with 0 are zero-filled, not sampled; order (n_img*Lq) i32 from bin_pairs.
+    images = (i0, i1): only the pairs of images i0 .. i1-1 (their slots of `order` -- mvg_bin_pairs sorts per image, so they are
+    the contiguous range [i0 * Lq, i1 * Lq) -- into their rows of `out`): the per-view-group launches of a pyramid that is
+    sampled while it is being produced (DQDecoder: view groups)."""
     n_img = vp.shape[0]
     Lq = r.shape[1]
-    samp = torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
+    samp = out if out is not None else torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
+    assert samp.dtype == torch.bfloat16 and tuple(samp.shape) == (n_img * Lq, 256) and samp.is_contiguous()
     if pair_mask is not None:
         assert pair_mask.dtype == torch.uint8 and pair_mask.numel() == n_img * Lq and pair_mask.is_contiguous()
     if order is not None:
         assert order.dtype == torch.int32 and order.numel() == n_img * Lq and order.is_contiguous()
+    n_launch, order_arg = n_img, order
+    if images is not None:
+        i0, i1 = images
+        if order is None or not (0 <= i0 < i1 <= n_img):
+            raise RuntimeError("msda_gsamp: an image range needs the processing order of mvg_bin_pairs")
+        n_launch, order_arg = i1 - i0, order[i0 * Lq:i1 * Lq]
     with _timed("msda_gsamp"):
       L.check(L.load().mvg_msda_gsamp(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
                                       L.ptr(samp), None if pair_mask is None else L.ptr(pair_mask),
-                                      None if order is None else L.ptr(order), n_img, Lq, levels.L, levels.S, B,
+                                      None if order_arg is None else L.ptr(order_arg), n_launch, Lq, levels.L, levels.S, B,
                                       L.stream_ptr()), "mvg_msda_gsamp")
     return samp
 

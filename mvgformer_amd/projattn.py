@@ -219,6 +219,20 @@ class ProjAttn(nn.Module):
             self._vp_event.record()
         return vp, self._G
 
+    def project_pyramid_group(self, feat, i0, i1):
+        """project_pyramid for images i0 .. i1-1 only (bf16 fast path; the buffers hold all images): one step of the view-group
+        pipeline of DQDecoder (PyramidPipeline)."""
+        dt = feat.dtype
+        n_img, S, _ = feat.shape
+        bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
+        Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
+        vp = self._plane_buffer(n_img, S, feat.device)
+        shape = (n_img * S, 192)
+        if self._G is None or self._G.dtype != torch.bfloat16 or tuple(self._G.shape) != shape or self._G.device != feat.device:
+            self._G = torch.empty(shape, dtype=torch.bfloat16, device=feat.device)
+        ops.value_proj_planes_ws(feat[i0:i1], Wv_f, bv, vp[i0:i1])
+        ops.feat_linear_ws(feat[i0:i1], self.query_term_weights(dt)[0], 192, out=self._G[i0 * S:i1 * S])
+
     def project_values(self, feat):
         """value = rayconv(input_flatten) (projattn.py:169) as bf16 head planes vh[img][head][s][32]."""
         dt = feat.dtype
@@ -303,6 +317,16 @@ class ProjAttn(nn.Module):
                     xw = ops.linear(parts[0].reshape(-1, Cc), Wq, bq, out_dtype=torch.float32, add=parts[1].reshape(-1, Cc))
                 else:
                     xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
+            pipe = getattr(self, "_pipeline", None)
+            if pipe is not None and order is not None:
+                # view groups: every group is sampled right behind the GEMMs that produced its planes (still in the Infinity
+                # Cache), while the side stream produces the next groups (DQDecoder: PyramidPipeline)
+                samp = torch.empty((n_img * r.shape[1], 256), dtype=torch.bfloat16, device=feat.device)
+                for g in range(pipe.n_groups):
+                    i0, i1 = pipe.wait_ready(self, g)
+                    ops.msda_gsamp(self._vp, self._G, xw, r, levels, B, pair_mask=pair_mask, order=order, out=samp, images=(i0, i1))
+                    pipe.consumed(self, g)
+                return samp
             vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
         if f32_g:
@@ -397,13 +421,17 @@ class ProjAttn(nn.Module):
         else:
             feats = torch.stack([F.grid_sample(src_views[l], sample_grid[:, :, l:l + 1, :], align_corners=False).squeeze(-1)
                                  .permute(0, 2, 1) for l in range(feat_lvls)], dim=2)
-        value = self.rayconv(input_flatten)
+        from .functions import linear as lin
+        value = lin(input_flatten, self.rayconv.weight, self.rayconv.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(n_views, -1, self.n_heads, self.d_model // self.n_heads)
         xin = feats + query.unsqueeze(2)
-        sampling_offsets = self.sampling_offsets(xin).view(n_views, Len_q, self.n_heads, feat_lvls, self.n_points, 2)
-        attention_weights = self.attention_weights(xin).view(n_views, Len_q, self.n_heads, feat_lvls * self.n_points)
+        n_off = self.sampling_offsets.out_features
+        oa = lin(xin, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),      # one GEMM for both heads
+                 torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+        sampling_offsets = oa[..., :n_off].reshape(n_views, Len_q, self.n_heads, feat_lvls, self.n_points, 2)
+        attention_weights = oa[..., n_off:].reshape(n_views, Len_q, self.n_heads, feat_lvls * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(n_views, Len_q, self.n_heads, feat_lvls,
                                                                   self.n_points)
         offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
@@ -412,7 +440,7 @@ class ProjAttn(nn.Module):
         output = DeformFunction.apply(value.contiguous(), input_spatial_shapes.contiguous(),
                                       input_level_start_index.contiguous(), sampling_locations.contiguous(),
                                       attention_weights.contiguous(), self._step(n_views))
-        return self.output_proj(output)
+        return lin(output, self.output_proj.weight, self.output_proj.bias)
 
 
 # north_star alias

@@ -1625,3 +1625,30 @@ def test_every_kernel_variant_behind_a_tuning_knob(key, value, exact):
         assert float((got[0] - ref[0]).abs().max()) < 4e-2
         assert float((got[1] - ref[1]).norm(dim=-1).max()) < 6.0 and float((got[2] - ref[2]).abs().max()) < 0.5     # the bf16 bars of section 5
     assert lib.mvg_set_tuning(b"no_such_knob", 1) != 0 and lib.mvg_set_tuning(key.encode(), -7) != 0
+
+
+@pytest.mark.parametrize("rows,N,K", [(76800, 256, 256), (1000, 192, 256), (15360, 1024, 256), (777, 256, 1024), (33, 64, 32)])
+def test_linear_wgrad_and_autograd_function_vs_fp64(rows, N, K):
+    """mvg_linear_wgrad_f32 (dW = dY^T X from row-major operands, split over row slices) and the LinearF32S autograd Function
+    (forward / dgrad / wgrad on this library's GEMMs) against fp64: errors in units of sum|a||b| like the forward GEMM's."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.functions import LinearF32S
+    gen = torch.Generator(device="cpu").manual_seed(rows + N)
+    dy = torch.randn(rows, N, generator=gen).to(DEV)
+    x = torch.randn(rows, K, generator=gen).to(DEV)
+    dw = ops.linear_wgrad(dy, x)
+    want = dy.double().t() @ x.double()
+    scale = dy.double().abs().t() @ x.double().abs()
+    assert float(((dw.double() - want).abs() / scale).max()) < 2e-6
+    assert torch.equal(dw, ops.linear_wgrad(dy, x))                       # deterministic (slice-ordered sum)
+    if N % 32 == 0 and K % 32 == 0:
+        w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV).requires_grad_(True)
+        b = torch.randn(N, generator=gen).to(DEV).requires_grad_(True)
+        xi = x.clone().requires_grad_(True)
+        y = LinearF32S.apply(xi, w, b, True)
+        y.backward(dy)
+        w64, b64, x64 = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True), x.double().requires_grad_(True)
+        y64 = torch.relu(x64 @ w64.t() + b64)
+        y64.backward(dy.double())
+        for got, ref in ((y, y64), (xi.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
+            assert float((got.double() - ref.detach()).abs().max()) < 3e-6 * max(1.0, float(ref.detach().abs().max())) * (rows ** 0.5 if got is w.grad or got is b.grad else 1.0)
