@@ -361,6 +361,12 @@ int mvg_triangulate_project(const float* r, const float* o, const float* cams, c
                             int V, int B, int NQ, int J, const int64_t* shapes_host, int L,
                             float* r_next, float* ref_lvl_next, uint8_t* inside_next, void* stream);
 
+/* Training path: the refined 2D points ref2d (B, V, Lq, 2; network-image px) -> un-cropped, undistorted
+ * original-image px ud (B, V, Lq, 2) (lib/models/dq_decoder.py:414-420, 119-204: inverse crop affine, K^-1, 5 fixed-point
+ * iterations, K) and jac (B, V, Lq, 4) = the row-major 2 x 2 Jacobian d(ud) / d(ref2d) of every point (forward mode through the
+ * same iterations): the backward of this step is grad_ref2d = jac^T grad_ud.  cams: the packed records, image n = v * B + b. */
+int mvg_uncrop_undistort_jac(const float* ref2d, const float* cams, float* ud, float* jac, int V, int B, int Lq, void* stream);
+
 /* Batched eigen-decomposition of n symmetric 4x4 fp64 matrices G (n,4,4): evals (n,4) in no particular order, evecs
  * (n,4,4) with the eigenvectors as columns (G v_k = evals_k v_k, v_k = evecs[:, :, k]).  fp64 cyclic Jacobi, one lane
  * per matrix.  Used by the differentiable DLT of the training path (multiview.py:170-228 under autograd): smallest

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mvg_rowdot3": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "mvg_triangulate": [_vp] * 8 + [_i] * 4 + [_vp],
     "mvg_triangulate_project": [_vp] * 8 + [_i] * 4 + [_vp, _i] + [_vp] * 4,
+    "mvg_uncrop_undistort_jac": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_sym4_eigh": [_vp] * 3 + [C.c_long, _vp],
 }
 

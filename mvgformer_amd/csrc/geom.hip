@@ -962,6 +962,57 @@ __global__ __launch_bounds__(256) void sym4_eigh_kernel(const double* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Training path: un-crop + undistortion of the refined 2D points (dq_decoder.py:414-420, 119-204) as ONE
+// launch that also returns the 2 x 2 Jacobian d(ud) / d(ref2d) of every point -- forward-mode through the inverse crop affine and the
+// 5 fixed-point iterations -- so that the backward is one small product per point instead of torch autograd through ~80
+// elementwise kernels forward and ~160 backward per decoder layer.
+__global__ __launch_bounds__(256) void uncrop_undistort_jac_kernel(const float* __restrict__ ref2d, const float* __restrict__ cams,
+                                                                   float* __restrict__ ud, float* __restrict__ jac, int V, int B,
+                                                                   int Lq) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * V * Lq;
+  if (i >= total) return;
+  const int v = (int)((i / Lq) % V), b = (int)(i / ((long)Lq * V));
+  const float* cam = cams + ((long)v * B + b) * MVG_CAM_STRIDE;
+  const float2 kp = *reinterpret_cast<const float2*>(ref2d + i * 2);
+  const float a00 = cam[27], a01 = cam[28], a10 = cam[30], a11 = cam[31];
+  const float uo = a00 * kp.x + a01 * kp.y + cam[29];
+  const float vo = a10 * kp.x + a11 * kp.y + cam[32];
+  const float fx = cam[12], fy = cam[13], cx = cam[14], cy = cam[15];
+  const float k1 = cam[16], k2 = cam[17], k3 = cam[18], p1 = cam[19], p2 = cam[20];
+  const float x0 = uo * (1.f / fx) + (-cx / fx), y0 = vo * (1.f / fy) + (-cy / fy);
+  float x = x0, y = y0;
+  // tangents of (x, y) with respect to (x0, y0)
+  float xa = 1.f, xb = 0.f, ya = 0.f, yb = 1.f;
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    const float r2 = x * x + y * y;
+    const float q = 1.f + ((k3 * r2 + k2) * r2 + k1) * r2;
+    const float icd = 1.f / q;
+    const float dq = (3.f * k3 * r2 + 2.f * k2) * r2 + k1;          // dq / dr2
+    const float dX = 2.f * p1 * x * y + p2 * (r2 + 2.f * x * x);
+    const float dY = p1 * (r2 + 2.f * y * y) + 2.f * p2 * x * y;
+    const float dXx = 2.f * p1 * y + 6.f * p2 * x, dXy = 2.f * p1 * x + 2.f * p2 * y;
+    const float dYx = 2.f * p1 * x + 2.f * p2 * y, dYy = 6.f * p1 * y + 2.f * p2 * x;
+    const float nx = x0 - dX, ny = y0 - dY;
+    const float c = -dq * icd * icd;                                   // d(icd) = c * d(r2)
+    // direction a (d / dx0), direction b (d / dy0)
+    const float r2a = 2.f * (x * xa + y * ya), r2b = 2.f * (x * xb + y * yb);
+    const float nxa = (1.f - (dXx * xa + dXy * ya)) * icd + nx * c * r2a;
+    const float nxb = (0.f - (dXx * xb + dXy * yb)) * icd + nx * c * r2b;
+    const float nya = (0.f - (dYx * xa + dYy * ya)) * icd + ny * c * r2a;
+    const float nyb = (1.f - (dYx * xb + dYy * yb)) * icd + ny * c * r2b;
+    x = nx * icd;
+    y = ny * icd;
+    xa = nxa; xb = nxb; ya = nya; yb = nyb;
+  }
+  *reinterpret_cast<float2*>(ud + i * 2) = make_float2(fx * x + cx, fy * y + cy);
+  // d(ud) / d(uo, vo) = diag(fx, fy) T diag(1 / fx, 1 / fy); times the inverse crop affine's 2 x 2 part
+  const float t00 = xa, t01 = xb * fx / fy, t10 = ya * fy / fx, t11 = yb;
+  *reinterpret_cast<f32x4*>(jac + i * 4) = f32x4{t00 * a00 + t01 * a10, t00 * a01 + t01 * a11, t10 * a00 + t11 * a10, t10 * a01 + t11 * a11};
+}
+
 extern "C" {
 
 int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W, int S, int start,
@@ -1182,6 +1233,16 @@ int mvg_triangulate_project(const float* r, const float* o, const float* cams, c
   if (e) return e;
   return launch_triangulate(r, o, cams, valid, any_valid, new_ref, ref2d, proj2d, V, B, NQ, J, lv, r_next, ref_lvl_next,
                             inside_next, stream);
+}
+
+int mvg_uncrop_undistort_jac(const float* ref2d, const float* cams, float* ud, float* jac, int V, int B, int Lq, void* stream) {
+  if (!ref2d || !cams || !ud || !jac || V <= 0 || B <= 0 || Lq < 0) return MVG_E_BADARG;
+  const long total = (long)B * V * Lq;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(uncrop_undistort_jac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref2d, cams, ud,
+                     jac, V, B, Lq);
+  MVG_LAUNCH_CHECK();
+  return 0;
 }
 
 int mvg_sym4_eigh(const double* G, double* evals, double* evecs, long n, void* stream) {

@@ -457,14 +457,32 @@ class DQDecoderLayer(MvPDecoderLayer):
             X = X.detach()                                                    # dq_decoder.py:338-339
         WH = src_spatial_shapes.flip(-1).float()
         x = self.with_pos_embed(tgt, query_pos)
+        # Per-forward constants of the geometry (packed camera records, level table, projection matrices): built once and kept on the
+        # DecoderContext when the layer runs inside DQDecoder.forward -- as torch ops per layer they were ~40 launches each.
+        ctx = self._ctx
+        tc = getattr(ctx, "_train_cache", None) if ctx is not None else None
+        if tc is None:
+            cam = {k: torch.stack([meta[v]["camera"][k].to(dev) for v in range(V)], 1)
+                   for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
+            tc = dict(cams=ctx.cams if ctx is not None else ops.pack_cameras(meta, self.img_size, dev),
+                      levels=ctx.levels if ctx is not None else ops.Levels(src_spatial_shapes, level_start_index),
+                      Pm=G.proj_matrices(cam))
+            if ctx is not None:
+                ctx._train_cache = tc
         # all V views as ONE batch of V*B images (image n = v*B + b, the order of src_views): one projection, one ProjAttn
         # call and one pose MLP instead of V of each -- the training step is launch-bound (5 800 launches per step at cfg-2)
-        cam_all = {k: torch.cat([meta[v]["camera"][k].to(dev) for v in range(V)], 0)
-                   for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
-        center_all = torch.cat([meta[v]["center"].to(dev) for v in range(V)], 0)
-        A_crop = torch.cat([G.crop_affine(meta[v]["center"], meta[v]["scale"], self.img_size, dev) for v in range(V)], 0)
-        r_all, inside_all = G.project_points(X.repeat(V, 1, 1), cam_all, center_all, A_crop, self.img_size, views=V)
-        ref_lvl = r_all.unsqueeze(2) * WH / (WH - 1)                               # dq_decoder.py:570-573
+        if not X.requires_grad:
+            # the reference points do not carry a gradient into the projection (detach_refpoints_cameraprj, every shipped YAML):
+            # the inference kernel projects them (one launch, same arithmetic: tests/test_hip_parity.py)
+            r_all, ref_lvl, inside_u8 = ops.project(X.float().contiguous(), tc["cams"], tc["levels"], V, B)
+            inside_all = inside_u8.bool()
+        else:
+            cam_all = {k: torch.cat([meta[v]["camera"][k].to(dev) for v in range(V)], 0)
+                       for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
+            center_all = torch.cat([meta[v]["center"].to(dev) for v in range(V)], 0)
+            A_crop = torch.cat([G.crop_affine(meta[v]["center"], meta[v]["scale"], self.img_size, dev) for v in range(V)], 0)
+            r_all, inside_all = G.project_points(X.repeat(V, 1, 1), cam_all, center_all, A_crop, self.img_size, views=V)
+            ref_lvl = r_all.unsqueeze(2) * WH / (WH - 1)                           # dq_decoder.py:570-573
         a_all = self.proj_attn(x.repeat(V, 1, 1), ref_lvl, src_views, None, src_spatial_shapes, level_start_index)
         a_all = inside_all.unsqueeze(-1).to(a_all.dtype) * a_all                   # dq_decoder.py:585-586
         from .functions import linear as lin
@@ -475,7 +493,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             if self.activation_name != "relu":
                 h1 = self.activation(h1)
             tgt_update = self.norm3(tgt_update + self.dropout4(lin(self.dropout3(h1), self.linear2.weight, self.linear2.bias)))
-        prob = self.class_embed(tgt_update).view(B, NQ, J, 2).sigmoid().mean(2)
+        prob = lin(tgt_update, self.class_embed.weight, self.class_embed.bias).view(B, NQ, J, 2).sigmoid().mean(2)
         if not self.filter_query or self.query_filter_method == "all":
             valid = torch.ones((B, NQ), dtype=torch.bool, device=dev)
         elif indices is not None:
@@ -494,14 +512,12 @@ class DQDecoderLayer(MvPDecoderLayer):
         ref2d = ((r_all + off / img) * img).view(V, B, Lq, 2).transpose(0, 1)    # (B,V,Lq,2)
         proj2d = (r_all * img).view(V, B, Lq, 2).transpose(0, 1)
         conf = torch.softmax(cl.reshape(V, B, Lq).transpose(0, 1), 1)
-        cam = {k: torch.stack([meta[v]["camera"][k].to(dev) for v in range(V)], 1)
-               for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
-        Ainv = torch.stack([meta[v]["inv_affine_trans"][:, :2, :].to(dev) for v in range(V)], 1).float()   # (B,V,2,3)
-        uo = torch.matmul(torch.cat([ref2d, torch.ones_like(ref2d[..., :1])], -1), Ainv.transpose(2, 3))
+        # un-crop + undistortion (dq_decoder.py:414-420, 119-204): one launch forward (with every point's Jacobian), one small
+        # product backward (geometry_torch.UncropUndistort) -- as torch ops ~80 launches forward and ~160 backward per layer
         # Only the matched queries are triangulated, like the reference (dq_decoder.py:929-967): an unmatched query
         # with a degenerate DLT (homogeneous w == 0, an Inf 2D point) would otherwise put 0 * inf = NaN into the
         # gradients of the parameters all queries share.
-        ud, Pm = G.undistort(uo, cam), G.proj_matrices(cam)
+        ud, Pm = G.UncropUndistort.apply(ref2d, tc["cams"], V, B), tc["Pm"]
         bi, ti = valid.view(B, NQ, 1).expand(B, NQ, J).reshape(B, Lq).nonzero(as_tuple=True)
         Xv = G.dlt(Pm[bi], ud[bi, :, ti].unsqueeze(2), conf[bi, :, ti].unsqueeze(2))[:, 0]     # (n_valid_tokens, 3)
         new_ref = torch.zeros((B, Lq, 3), dtype=Xv.dtype, device=dev).index_put((bi, ti), Xv)

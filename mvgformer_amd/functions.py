@@ -88,8 +88,14 @@ def linear(x, weight, bias=None, relu=False):
     in_features % 32 == 0, out_features % 32 == 0 -- every 256 / 1024 / 192-wide Linear of the decoder), torch elsewhere (the
     2- and 3-output heads)."""
     N, K = weight.shape
-    if (TRAIN_GEMM == "f32s" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 32 == 0
-            and N % 32 == 0 and x.numel() > 0):
-        return LinearF32S.apply(x, weight, bias, relu)
+    if TRAIN_GEMM == "f32s" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 32 == 0 and x.numel() > 0:
+        if N % 32 == 0:
+            return LinearF32S.apply(x, weight, bias, relu)
+        # the 2- and 3-output heads (class_embed, the last pose layer): zero rows up to 32 outputs, result sliced back -- the
+        # padding is differentiable (cat), so the gradients land on the real rows
+        pad = (-N) % 32
+        wp = torch.cat([weight, weight.new_zeros(pad, K)], 0)
+        bp = None if bias is None else torch.cat([bias, bias.new_zeros(pad)], 0)
+        return LinearF32S.apply(x, wp, bp, relu)[..., :N]
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y

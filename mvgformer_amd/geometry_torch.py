@@ -72,6 +72,23 @@ def undistort(uo, cam, iters=5):
     return torch.stack([fx * x + cx, fy * y + cy], -1)
 
 
+class UncropUndistort(torch.autograd.Function):
+    """ref2d (B,V,Lq,2) network-image px -> undistorted original-image px: the inverse crop affine + undistort() above as one HIP
+    launch that also returns every point's 2 x 2 Jacobian (csrc/geom.hip: uncrop_undistort_jac_kernel); backward = J^T g."""
+
+    @staticmethod
+    def forward(ctx, ref2d, cams, V, B):
+        from . import ops
+        ud, jac = ops.uncrop_undistort_jac(ref2d.detach(), cams, V, B)
+        ctx.save_for_backward(jac)
+        return ud
+
+    @staticmethod
+    def backward(ctx, g):
+        (jac,) = ctx.saved_tensors
+        return (jac.transpose(-1, -2) @ g.unsqueeze(-1)).squeeze(-1), None, None, None
+
+
 def proj_matrices(cam):
     R = cam["R"].float()
     T = cam["T"].float().reshape(*R.shape[:2], 3, 1)

@@ -796,6 +796,19 @@ def pack_cameras(meta, img_size, device):
     return torch.from_numpy(rec.reshape(V * B, L.CAM_STRIDE)).to(device)
 
 
+def uncrop_undistort_jac(ref2d, cams, V, B):
+    """ref2d (B, V, Lq, 2) f32 -> (ud (B, V, Lq, 2), jac (B, V, Lq, 2, 2) = d ud / d ref2d) (mvg_uncrop_undistort_jac)."""
+    if ref2d.dtype != torch.float32 or tuple(ref2d.shape[:2]) != (B, V) or ref2d.shape[-1] != 2:
+        raise RuntimeError("mvg_uncrop_undistort_jac: (B, V, Lq, 2) float32 expected")
+    ref2d = ref2d.contiguous()
+    Lq = ref2d.shape[2]
+    ud = torch.empty_like(ref2d)
+    jac = torch.empty((B, V, Lq, 2, 2), dtype=torch.float32, device=ref2d.device)
+    L.check(L.load().mvg_uncrop_undistort_jac(L.ptr(ref2d), L.ptr(cams), L.ptr(ud), L.ptr(jac), V, B, Lq, L.stream_ptr()),
+            "mvg_uncrop_undistort_jac")
+    return ud, jac
+
+
 def sym4_eigh(G):
     """eigen-decomposition of symmetric 4x4 matrices G (..., 4, 4) fp64 on the GPU: (evals (..., 4), evecs (..., 4, 4),
     eigenvectors as columns, no particular order)."""
