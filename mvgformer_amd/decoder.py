@@ -483,7 +483,11 @@ class DQDecoderLayer(MvPDecoderLayer):
             A_crop = torch.cat([G.crop_affine(meta[v]["center"], meta[v]["scale"], self.img_size, dev) for v in range(V)], 0)
             r_all, inside_all = G.project_points(X.repeat(V, 1, 1), cam_all, center_all, A_crop, self.img_size, views=V)
             ref_lvl = r_all.unsqueeze(2) * WH / (WH - 1)                           # dq_decoder.py:570-573
-        a_all = self.proj_attn(x.repeat(V, 1, 1), ref_lvl, src_views, None, src_spatial_shapes, level_start_index)
+        self.proj_attn._packed_feat = ctx.feat if (ctx is not None and ctx.feat is not None) else None
+        try:
+            a_all = self.proj_attn(x.repeat(V, 1, 1), ref_lvl, src_views, None, src_spatial_shapes, level_start_index)
+        finally:
+            self.proj_attn._packed_feat = None
         a_all = inside_all.unsqueeze(-1).to(a_all.dtype) * a_all                   # dq_decoder.py:585-586
         from .functions import linear as lin
         mean = a_all.view(V, B, Lq, C).mean(0)

@@ -86,7 +86,8 @@ class UncropUndistort(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (jac,) = ctx.saved_tensors
-        return (jac.transpose(-1, -2) @ g.unsqueeze(-1)).squeeze(-1), None, None, None
+        # grad_ref[j] = sum_i jac[i][j] g[i]  (elementwise: a batched 2 x 2 matmul went to a 625-us rocBLAS kernel)
+        return (jac * g.unsqueeze(-1)).sum(-2), None, None, None
 
 
 def proj_matrices(cam):

@@ -409,7 +409,14 @@ class ProjAttn(nn.Module):
                                       1, n_views)
             return out.view(n_views, Len_q, c).to(query.dtype)
         sample_grid = torch.clamp(reference_points * 2.0 - 1.0, -1.1, 1.1)
-        input_flatten = torch.cat([s.flatten(2) for s in src_views], dim=-1).permute(0, 2, 1)
+        packed = getattr(self, "_packed_feat", None)
+        if (packed is not None and packed.dtype == torch.float32 and packed.shape[0] == n_views and packed.shape[2] == c
+                and not any(s.requires_grad for s in src_views)):
+            # the channels-last pyramid the decoder packed once per forward IS cat + permute of the maps (projattn.py:160); only
+            # when no gradient flows into the feature maps (the packing kernel is not differentiable)
+            input_flatten = packed
+        else:
+            input_flatten = torch.cat([s.flatten(2) for s in src_views], dim=-1).permute(0, 2, 1)
         assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == input_flatten.shape[1]
         if self.ref_gather_native and input_flatten.dtype == torch.float32:
             # reference-point features through the sampling op itself (forward AND deterministic backward kernels) instead
