@@ -31,7 +31,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("\n== PMC (mean per dispatch)")
 for k in sorted(acc, key=lambda k: -sum(acc[k].get("GRBM_GUI_ACTIVE", [0]))):
-    if not any(s in k for s in ("msda", "samp_chain", "linear", "chain", "wreg", "gather", "triang", "pack", "add_ln", "mean_views", "class_head", "rowdot", "project")):
+    if not any(s in k for s in ("msda", "samp_chain", "linear", "chain", "wreg", "gather", "triang", "pack", "add_ln", "mean_views", "class_head", "rowdot", "project", "pyramid", "f32s", "wgrad", "bin_")):
         continue
     print(k)
     for c in sorted(acc[k]):
