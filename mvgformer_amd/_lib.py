@@ -63,6 +63,7 @@ SIGNATURES = {
 }
 
 _lib = None
+TUNING = {}     # knob values set through mvg_set_tuning in this process (library defaults are not listed)
 
 
 class MvgError(RuntimeError):
@@ -87,6 +88,16 @@ def load():
     lib.mvg_bin_pairs_workspace.restype = C.c_size_t
     lib.mvg_msda_backward_det_workspace.restype = C.c_size_t
     lib.mvg_version.argtypes = []
+    # every knob change goes through this wrapper, so that host-side caches that depend on a knob (DQDecoderLayer's rows of
+    # all-masked tiles: computed by the GEMM form that is active) can key on its value: TUNING[key] = last value set
+    raw_set = lib.mvg_set_tuning
+
+    def set_tuning(key, value):
+        rc = raw_set(key, value)
+        if rc == 0:
+            TUNING[key.decode() if isinstance(key, bytes) else str(key)] = int(value)
+        return rc
+    lib.mvg_set_tuning = set_tuning
     _lib = lib
     # A/B knobs for measurements: MVG_TUNE="chain_rm=128,gsamp_threads=256"
     for item in filter(None, os.environ.get("MVG_TUNE", "").split(",")):

@@ -313,7 +313,9 @@ class DQDecoderLayer(MvPDecoderLayer):
                 cur = ops.linear(cur, lin.weight.detach().to(f32).contiguous(), lin.bias.detach().to(f32).contiguous(), relu=True)
                 rows.append(cur[0])
             return torch.stack(rows)
-        return self._w("pose_masked_rows", params, f32, build)
+        # keyed on the active GEMM form as well: the rows must come from the form that computes the unmasked tiles
+        from . import _lib
+        return self._w("pose_masked_rows/f32_split=%d" % _lib.TUNING.get("f32_split", 1), params, f32, build)
 
     def _chain_b_weights(self, dt):
         f32 = torch.float32
