@@ -35,11 +35,16 @@ __device__ unsigned long long f32s_stamps[4096 * 64];
   do {                                                                                             \
     if (threadIdx.x == 0 && blockIdx.x < 4096) f32s_stamps[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#define STAMPW(i)                                                                                  \
+  do {                                                                                             \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) f32s_stamps[blockIdx.x * 64 + (i) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 extern "C" int mvg_f32s_read_stamps(unsigned long long* host, int n_blocks) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(f32s_stamps), sizeof(unsigned long long) * 64 * n_blocks);
 }
 #else
 #define STAMP(i)
+#define STAMPW(i)
 #endif
 
 namespace {
@@ -517,8 +522,10 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
       }
     }
     if (it == 1) STAMP(5);
+    if (it == 1) STAMPW(32);
     // pose_embed MLP layers 0, 1 (ReLU)
     stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp2, 65536, acc, nullptr, true, (rot + 5) & 15, lane, pf, prio);
+    if (it == 1) STAMPW(40);
     if (it == 1) STAMP(6);
     load_bias(bias_s + 256 + 32 * w, bvr, lane);
     ring_prefetch<16, 4>(wp3, 65536, pf, (rot + 10) & 15);

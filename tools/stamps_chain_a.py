@@ -32,3 +32,10 @@ names = ["order / inside -> rid, barrier", "samp rows -> planes, barrier", "stag
 for i in range(10):
     print("%-34s %8.0f  (%6.0f .. %6.0f)" % (names[i], np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
 print("one tile: %.0f cycles (median); MFMA floor 3 x 12288 per SIMD" % np.median(t[:, 10] - t[:, 0]))
+
+w = tall[:, 40:48] - tall[:, 32:40]
+st = tall[:, 32:40] - tall[:, 32:33]
+en = tall[:, 40:48] - tall[:, 32:33]
+print("stage 2 per wavefront (median over workgroups): start offset / duration / end offset, cycles relative to wavefront 0's start")
+for k in range(8):
+    print("  wavefront %d: %6.0f %6.0f %6.0f" % (k, np.median(st[:, k]), np.median(w[:, k]), np.median(en[:, k])))
