@@ -504,9 +504,11 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
       ridb[(cur ^ 1) * RM + tid] = g_n;
       keepb[(cur ^ 1) * RM + tid] = k_n;
     }
+    uint2 pk[2][4][3];
+    split_planes<2>(pk, acc, bvr, false, keep);                 // under the other wavefronts' k loops; only the stores wait
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, false, keep, lane);
+    store_planes<2, PLP>(act, PLANE, 0, 32 * w, pk, lane);
     __syncthreads();
     if (it == 1) STAMP(4);
 #pragma unroll
@@ -529,11 +531,12 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
     if (it == 1) STAMP(6);
     load_bias(bias_s + 256 + 32 * w, bvr, lane);
     ring_prefetch<16, 4>(wp3, 65536, pf, (rot + 10) & 15);
+    split_planes<2>(pk, acc, bvr, true, all);
     __builtin_amdgcn_sched_barrier(0);
     if (it == 1) STAMP(20);
     __syncthreads();
     if (it == 1) STAMP(21);
-    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
+    store_planes<2, PLP>(act, PLANE, 0, 32 * w, pk, lane);
     if (it == 1) STAMP(22);
     __syncthreads();
     if (it == 1) STAMP(7);
@@ -541,8 +544,10 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
     if (it == 1) STAMP(8);
     load_bias(bias_s + 512 + 32 * w, bvr, lane);
     if (nxt_tile < ntiles) request_rows(ridb + (cur ^ 1) * RM);    // the next tile's rows, in flight under the rest of this tile
+    split_planes<2>(pk, acc, bvr, true, all);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    write_planes<2, PLP>(act, PLANE, 0, 32 * w, acc, bvr, true, all, lane);
+    store_planes<2, PLP>(act, PLANE, 0, 32 * w, pk, lane);
     __syncthreads();
     if (it == 1) STAMP(9);
     // last layer (3 outputs): 8 threads per row, 32 columns each in column order, then the balanced tree over the 8 lanes

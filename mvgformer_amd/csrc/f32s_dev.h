@@ -188,4 +188,38 @@ __device__ __forceinline__ void write_planes(char* __restrict__ act, int plane_b
     }
 }
 
+// write_planes in two halves: the arithmetic (bias, ReLU, keep mask, split) into registers BEFORE the barrier that frees the
+// planes -- it then runs while the slower wavefront of the SIMD is still in its k loop -- and the LDS stores after it.
+template <int MT>
+__device__ __forceinline__ void split_planes(uint2 (&pk)[MT][4][3], const f32x16 (&acc)[MT], const f32x4 (&bv)[4], bool relu,
+                                             const bool (&keep)[MT]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float x = acc[mt][4 * g + t] + bv[g][t];
+        v[t] = keep[mt] ? (relu ? fmaxf(x, 0.f) : x) : 0.f;
+      }
+      split4(v, pk[mt][g]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(pk[mt][g][s].x), "+v"(pk[mt][g][s].y));     // computed HERE, not sunk to the stores
+    }
+}
+
+template <int MT, int PITCH>
+__device__ __forceinline__ void store_planes(char* __restrict__ act, int plane_bytes, int row0, int col0, const uint2 (&pk)[MT][4][3],
+                                             int lane) {
+  const int rl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        *reinterpret_cast<uint2*>(act + s * plane_bytes + (row0 + mt * 32 + rl) * PITCH + (col0 + 8 * g + 4 * h) * 2) = pk[mt][g][s];
+}
+
 }  // namespace f32s
