@@ -595,46 +595,40 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
 // Row statistics (LayerNorm, class head) live in the accumulator layout -- lane (rl, h) of wavefront w holds columns
 // 32 w + 8 g + 4 h + t of rows rl and 32 + rl -- and are completed across the 8 wavefronts through a (64 x 8) LDS table
 // summed in wavefront order by every reader (a fixed order: results do not depend on timing).
-constexpr int HPLANE = RM * PLP128;          // bytes per plane of the FFN's hidden chunk (128 columns)
-constexpr int FCH = 128;                     // hidden columns per FFN chunk
-
 __device__ __forceinline__ float row_total(const float* __restrict__ part, int row) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(part + row * 8), b = *reinterpret_cast<const f32x4*>(part + row * 8 + 4);
   return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
 }
 
-// x[mt][g] (4 columns each) of rows rl, 32 + rl -> LayerNorm over the 256 columns of the row, in place
-__device__ __forceinline__ void layernorm_rows(f32x4 (&x)[2][4], const float* __restrict__ gamma_cb, const float* __restrict__ beta_cb,
+// x[mt][g] (4 columns each) of rows 32 mt + rl -> LayerNorm over the 256 columns of the row, in place
+template <int MT>
+__device__ __forceinline__ void layernorm_rows(f32x4 (&x)[MT][4], const float* __restrict__ gamma_cb, const float* __restrict__ beta_cb,
                                                float* __restrict__ part, float* __restrict__ part2, int lane, int w) {
   const int rl = lane & 31, h = lane >> 5;
-  float s[2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     float v = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) v += (x[mt][g][0] + x[mt][g][1]) + (x[mt][g][2] + x[mt][g][3]);
     v += __shfl_xor(v, 32, 64);
-    s[mt] = v;
     if (h == 0) part[(mt * 32 + rl) * 8 + w] = v;
   }
   __syncthreads();
-  float q[2], mean[2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    mean[mt] = row_total(part, mt * 32 + rl) * (1.f / 256.f);
+  for (int mt = 0; mt < MT; ++mt) {
+    const float mean = row_total(part, mt * 32 + rl) * (1.f / 256.f);
     float v = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      x[mt][g] = x[mt][g] - mean[mt];
+      x[mt][g] = x[mt][g] - mean;
       v += (x[mt][g][0] * x[mt][g][0] + x[mt][g][1] * x[mt][g][1]) + (x[mt][g][2] * x[mt][g][2] + x[mt][g][3] * x[mt][g][3]);
     }
     v += __shfl_xor(v, 32, 64);
-    q[mt] = v;
     if (h == 0) part2[(mt * 32 + rl) * 8 + w] = v;
   }
   __syncthreads();
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const float rstd = 1.f / sqrtf(row_total(part2, mt * 32 + rl) * (1.f / 256.f) + 1e-5f);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -644,6 +638,11 @@ __device__ __forceinline__ void layernorm_rows(f32x4 (&x)[2][4], const float* __
   }
 }
 
+// RMT = 64: 4 persons per tile (60 rows), the launch is one workgroup per CU at 1024 queries.  RMT = 32: 2 persons per tile -- launches
+// with few rows (cfg-4's 512 queries: 128 tiles of 64 rows on 256 CUs; a rank's shard of a query-sharded run) fill twice as many CUs.
+// Both sum every row in exactly the same order (the hidden dimension in 128-column chunks, k-steps rotated by the column block
+// only, one accumulator per row block): a row's result does not depend on the tile size, the launcher may pick it by the row count.
+template <int RMT>
 __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     const float* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu,
     const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
@@ -652,15 +651,18 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
     float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
     const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
-    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn, int g_skew) {
+    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
+  constexpr int MT = RMT / 32, APLANE = RMT * PLP;
+  // hidden chunk held in LDS: 128 columns (two row blocks) | 256 columns (one row block) -- 8 units of 32 x 32 for the 8 wavefronts
+  constexpr int HCOLS = RMT == 64 ? 128 : 256, HP = RMT == 64 ? PLP128 : PLP, HPL = RMT * HP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;                                   // 3 planes x 64 rows x 256 columns: mean, then t1, then tgt' + query_pos
-  char* hb = smem + 3 * PLANE;                        // 3 planes x 64 rows x 128 columns: FFN hidden chunk
-  float* part = reinterpret_cast<float*>(hb + 3 * HPLANE);
-  float* part2 = part + RM * 8;
-  float* pr = part2 + RM * 8;                         // per-row class probabilities (64 x 2)
+  char* act = smem;                                   // 3 planes x RMT rows x 256 columns: mean, then t1, then tgt' + query_pos
+  char* hb = smem + 3 * APLANE;                       // 3 planes x RMT rows x HCOLS columns: FFN hidden chunk
+  float* part = reinterpret_cast<float*>(hb + 3 * HPL);
+  float* part2 = part + RMT * 8;
+  float* pr = part2 + RMT * 8;                        // per-row class probabilities (RMT x 2)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
-  const int qpt = RM / J, rpt = qpt * J;
+  const int qpt = RMT / J, rpt = qpt * J;
   const int q0 = blockIdx.x * qpt, r0 = q0 * J;
   const int nrow = min(rpt, rows - r0);
   const int rot = (w * 3) & 15;
@@ -668,143 +670,148 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
 
   STAMP(0);
   // residual rows in the accumulator layout, requested long before their use
-  f32x4 tg[2][4];
+  f32x4 tg[MT][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       tg[mt][g] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(mt * 32 + rl, nrow - 1)) * 256 + colb + 8 * g + 4 * h);
 
   // ---- mean over views (dq_decoder.py:770) -> planes
   {
-    f32x4 s[8];
+    constexpr int NCH = RMT * 64 / NT;                 // 16-byte chunks per thread
+    f32x4 s[NCH];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < V; v += 2) {                 // two views per round: 16 loads of 16 B in flight per thread
-      f32x4 xv[2][8];
+    for (int i = 0; i < NCH; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < V; v += 2) {                 // two views per round
+      f32x4 xv[2][NCH];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NCH; ++i) {
           const int c = i * NT + tid;
           xv[u][i] = *reinterpret_cast<const f32x4*>(attn + ((long)min(v + u, V - 1) * rows + r0 + min(c >> 6, nrow - 1)) * 256 + (c & 63) * 4);
         }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         s[i] += xv[0][i];
         if (v + 1 < V) s[i] += xv[1][i];
       }
     }
     const float Vf = (float)V;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = i * NT + tid, row = c >> 6;
       f32x4 m = {s[i][0] / Vf, s[i][1] / Vf, s[i][2] / Vf, s[i][3] / Vf};
       if (row >= nrow) m = f32x4{0.f, 0.f, 0.f, 0.f};
-      store_split4<PLP>(act, PLANE, row, (c & 63) * 4, m);
+      store_split4<PLP>(act, APLANE, row, (c & 63) * 4, m);
     }
   }
   __syncthreads();
   STAMP(1);
 
-  // All workgroups walk the same weights; started together they request the same L2 lines at the same time.  The 32
-  // workgroups of an XCD (blockIdx >> 3) start their first stage up to 15 k-steps apart -- a skew in TIME: the arithmetic of
-  // a row does not depend on where it is computed.
-  if (g_skew) for (int i = ((blockIdx.x >> 3) & 15) * g_skew; i > 0; --i) __builtin_amdgcn_s_sleep(8);
   // ---- t1 = LN2(tgt + feature_update_mlp(mean))   (dq_decoder.py:773-778)
-  f32x16 acc[2];
+  f32x16 acc[MT];
   f32x4 bvr[4];
-  stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, nullptr, true, rot, lane);
+  stage<MT, 16, PLP, 4, false, false>(act, APLANE, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, nullptr, true, rot, lane);
   load_bias(bu + colb, bvr, lane);
   STAMP(2);
   {
-    f32x4 t1[2][4];
+    f32x4 t1[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) t1[mt][g][t] = acc[mt][4 * g + t] + bvr[g][t];
         if (mt * 32 + rl < nrow) t1[mt][g] += tg[mt][g];
       }
-    layernorm_rows(t1, g2 + colb, be2 + colb, part, part2, lane, w);    // (its first barrier: every wavefront is done reading `act`)
+    layernorm_rows<MT>(t1, g2 + colb, be2 + colb, part, part2, lane, w);    // (its first barrier: every wavefront is done reading `act`)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
+      for (int g = 0; g < 4; ++g) store_split4<PLP>(act, APLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
   }
   __syncthreads();
   STAMP(3);
 
-  f32x4 y[2][4];
+  f32x4 y[MT][4];
   if (has_ffn) {
-    // ---- FFN (mvp_decoder.py:94-98): Y = sum_c relu(t1 W1_c^T + b1_c) W2[:, c]^T over hidden chunks of 128 columns.
-    // First GEMM of a chunk: wavefront = (row block w & 1, 32 hidden columns w >> 1); second: all 64 rows x output block w.
-    f32x16 accy[2];
-    const int mt1 = w & 1, cb4 = w >> 1;
+    // ---- FFN (mvp_decoder.py:94-98): Y = sum over the hidden columns of relu(t1 W1^T + b1) W2^T.
+    // RMT = 64: hidden chunks of 128; first GEMM of a chunk: wavefront = (row block w & 1, 32 hidden columns w >> 1), second: all 64
+    // rows x output block w over the chunk's 8 k-steps.  RMT = 32: hidden chunks of 256 (wavefront w = hidden block w), the second
+    // GEMM as two 8-k-step halves in chunk order.  Hidden column j of a row is always summed with the rotation of j's 32-column block
+    // inside its 128-column chunk, and Y over the hidden columns in the same order.
+    f32x16 accy[MT];
+    const int mt1 = RMT == 64 ? (w & 1) : 0, cb4 = RMT == 64 ? (w >> 1) : (w & 3);
     const bool one[1] = {true};
     const bf16_t* wp2 = frag_ptr(W2, 0, w, 64, lane);
+    const int rot1 = (cb4 * 5) & 15;
+    auto w1_ptr = [&](int c) {       // fragments of this wavefront's 32 hidden columns of chunk c
+      return RMT == 64 ? frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane) : frag_ptr(W1, c, w, 16, lane);
+    };
     // every stage's first fragments are requested one stage ahead, before the barriers in front of it (ring_prefetch)
     f32x4 pf1[4][3], pf2[4][3];
-    // (the k-step rotation of a stage follows the COLUMN block only: rows of both row blocks -- and hence of every tile position --
-    // are summed in the same order)
-    const int rot1 = (cb4 * 5) & 15;
-    ring_prefetch<16, 4>(frag_ptr(W1, 0, cb4, 16, lane), 1024 * 256, pf1, rot1);
+    ring_prefetch<16, 4>(w1_ptr(0), 1024 * 256, pf1, rot1);
+    constexpr int NCHUNK = 1024 / HCOLS;
 #pragma unroll 1
-    for (int c = 0; c < 1024 / FCH; ++c) {
+    for (int c = 0; c < NCHUNK; ++c) {
       f32x16 a1[1], a2;
       STAMP(4 + 4 * c);
-      stage<1, 16, PLP, 4, true>(act, PLANE, 32 * mt1, frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane), 1024 * 256, a1, &a2, true,
-                                 rot1, lane, pf1);
+      stage<1, 16, PLP, 4, true>(act, APLANE, 32 * mt1, w1_ptr(c), 1024 * 256, a1, &a2, true, rot1, lane, pf1);
       a1[0] += a2;
       STAMP(5 + 4 * c);
-      load_bias(b1 + c * FCH + 32 * cb4, bvr, lane);
-      ring_prefetch<8, 4>(wp2 + (long)c * 8 * 1024, 256 * 1024, pf2, rot & 7);
+      load_bias(b1 + c * HCOLS + (RMT == 64 ? 32 * cb4 : 32 * w), bvr, lane);
+      ring_prefetch<8, 4>(wp2 + (long)c * (HCOLS / 16) * 1024, 256 * 1024, pf2, rot & 7);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                                              // the previous chunk's second GEMM has read hb
-      write_planes<1, PLP128>(hb, HPLANE, 32 * mt1, 32 * cb4, a1, bvr, true, one, lane);
-      if (c + 1 < 1024 / FCH)
-        ring_prefetch<16, 4>(frag_ptr(W1, (c + 1) >> 1, 4 * ((c + 1) & 1) + cb4, 16, lane), 1024 * 256, pf1, rot1);
+      write_planes<1, HP>(hb, HPL, 32 * mt1, RMT == 64 ? 32 * cb4 : 32 * w, a1, bvr, true, one, lane);
+      if (c + 1 < NCHUNK) ring_prefetch<16, 4>(w1_ptr(c + 1), 1024 * 256, pf1, rot1);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       STAMP(6 + 4 * c);
-      stage<2, 8, PLP128, 4, true>(hb, HPLANE, 0, wp2 + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
+      if (RMT == 64) {
+        stage<MT, 8, HP, 4, true, false>(hb, HPL, 0, wp2 + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
+      } else {
+        stage<MT, 8, HP, 4, true, false>(hb, HPL, 0, wp2 + (long)c * 16 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
+        stage<MT, 8, HP, 4, false, false>(hb + 256, HPL, 0, wp2 + (long)(c * 16 + 8) * 1024, 256 * 1024, accy, nullptr, false, rot & 7, lane);
+      }
     }
     load_bias(b2 + colb, bvr, lane);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[mt][g][t] = accy[mt][4 * g + t] + bvr[g][t];
     // + t1, re-read from the planes (h + m + l is exactly the fp32 value that was split): 32 registers less across the FFN
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const char* src = act + (mt * 32 + rl) * PLP + (colb + 8 * g + 4 * h) * 2;
-        y[mt][g] += join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + PLANE),
-                          *reinterpret_cast<const uint2*>(src + 2 * PLANE));
+        y[mt][g] += join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + APLANE),
+                          *reinterpret_cast<const uint2*>(src + 2 * APLANE));
       }
     STAMP(36);
-    layernorm_rows(y, g3 + colb, be3 + colb, part, part2, lane, w);
+    layernorm_rows<MT>(y, g3 + colb, be3 + colb, part, part2, lane, w);
     STAMP(37);
   } else {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const char* src = act + (mt * 32 + rl) * PLP + (colb + 8 * g + 4 * h) * 2;
-        y[mt][g] = join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + PLANE),
-                         *reinterpret_cast<const uint2*>(src + 2 * PLANE));
+        y[mt][g] = join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + APLANE),
+                         *reinterpret_cast<const uint2*>(src + 2 * APLANE));
       }
   }
 
   // ---- tgt' -> global; class head (dq_decoder.py:889-893): per-row logits, completed across the wavefronts
   {
-    float c0[2], c1[2];
+    float c0[MT], c1[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -823,13 +830,13 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     __syncthreads();                                                // part / part2 of the last LayerNorm have been read
     if (h == 0) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         part[(mt * 32 + rl) * 8 + w] = c0[mt];
         part2[(mt * 32 + rl) * 8 + w] = c1[mt];
       }
     }
     __syncthreads();
-    if (tid < RM) {
+    if (tid < RMT) {
       pr[2 * tid] = 1.f / (1.f + expf(-(row_total(part, tid) + bc[0])));
       pr[2 * tid + 1] = 1.f / (1.f + expf(-(row_total(part2, tid) + bc[1])));
     }
@@ -855,22 +862,22 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
     // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets / logits Linear
     //      (projattn.py:180-181) while the rows are still on the CU.  Every wavefront passed the barriers above: `act` is free.
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 x = y[mt][g];
         if (qpos)
           x += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(mt * 32 + rl, nrow - 1)) * 256 + colb + 8 * g + 4 * h);
-        store_split4<PLP>(act, PLANE, mt * 32 + rl, colb + 8 * g + 4 * h, x);
+        store_split4<PLP>(act, APLANE, mt * 32 + rl, colb + 8 * g + 4 * h, x);
       }
     __syncthreads();
     STAMP(39);
     if (colb < n_next) {
-      stage<2, 16, PLP>(act, PLANE, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, nullptr, true, (rot + 7) & 15, lane);
+      stage<MT, 16, PLP, 4, false, false>(act, APLANE, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, nullptr, true, (rot + 7) & 15, lane);
       STAMP(40);
       load_bias(bn + colb, bvr, lane);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           if (mt * 32 + rl < nrow) {
@@ -910,7 +917,6 @@ int cu_count() {
 
 }  // namespace
 
-int g_f32s_skew = 6;      // tuning knob "f32s_skew": start-up skew between the workgroups of an XCD, in s_sleep(8) units per phase step
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
 
@@ -961,6 +967,27 @@ extern "C" int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside
   return 0;
 }
 
+template <int RMT>
+static int launch_chain_b_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu, const float* g2,
+                               const float* be2, const void* W1, const float* b1, const void* W2, const float* b2, const float* g3,
+                               const float* be3, const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
+                               float* tgt_out, float* prob, uint8_t* valid, int* any_valid, const float* query_pos, const void* W_next,
+                               const float* b_next, float* xw_next, int n_next, int nq_total, int rows, int J, int has_ffn,
+                               hipStream_t st) {
+  constexpr int HP = RMT == 64 ? PLP128 : PLP;
+  const int qpt = RMT / J;
+  const size_t lds = 3 * RMT * PLP + 3 * RMT * HP + 2 * RMT * 8 * sizeof(float) + RMT * 2 * sizeof(float);
+  static bool configured[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&chain_b_f32s_kernel<RMT>, lds, configured)) return rc;
+  hipLaunchKernelGGL(chain_b_f32s_kernel<RMT>, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, st, attn, V, tgt, (const bf16_t*)Wu, bu,
+                     g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc, threshold, forced_valid, tgt_out, prob,
+                     valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next, n_next, rows, J, nq_total, has_ffn);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int g_f32s_b_rows = 0;    // tuning knob "f32s_b_rows": rows per tile of the fp32 chain B (0 = by the row count, 32, 64)
+
 extern "C" int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu,
                                                const float* g2, const float* be2, const void* W1, const float* b1,
                                                const void* W2, const float* b2, const float* g3, const float* be3,
@@ -970,18 +997,19 @@ extern "C" int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const f
                                                float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream) {
   if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
   if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
-  if (V <= 0 || J <= 0 || J > 64 || B < 0 || NQ < 0) return MVG_E_BADARG;
+  if (V <= 0 || J <= 0 || J > 32 || B < 0 || NQ < 0) return MVG_E_BADARG;
   if (W_next && (!b_next || !xw_next || n_next <= 0 || n_next > 256 || n_next % 32 != 0)) return MVG_E_BADARG;
   const int nq_total = B * NQ, rows = nq_total * J;
   if (rows == 0) return 0;
-  const int qpt = RM / J;
-  const size_t lds = 3 * PLANE + 3 * HPLANE + 2 * RM * 8 * sizeof(float) + RM * 2 * sizeof(float);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&chain_b_f32s_kernel, lds, configured)) return rc;
-  hipLaunchKernelGGL(chain_b_f32s_kernel, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, (hipStream_t)stream, attn, V, tgt,
-                     (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc, threshold,
-                     forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next, n_next,
-                     rows, J, nq_total, has_ffn, g_f32s_skew);
-  MVG_LAUNCH_CHECK();
-  return 0;
+  // every tile size computes a row bit-identically (chain_b_f32s_kernel): 32-row tiles while 64-row tiles would leave a
+  // quarter of the CUs without a workgroup
+  const int tiles64 = (nq_total + 64 / J - 1) / (64 / J);
+  const bool small = g_f32s_b_rows == 32 || (g_f32s_b_rows == 0 && tiles64 <= (cu_count() * 3) / 4);
+#define MVG_CBF(R)                                                                                                          \
+  return launch_chain_b_f32s<R>(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, forced_valid, tgt_out, \
+                                prob, valid, any_valid, query_pos, W_next, b_next, xw_next, n_next, nq_total, rows, J, has_ffn,  \
+                                (hipStream_t)stream)
+  if (small) MVG_CBF(32);
+  MVG_CBF(64);
+#undef MVG_CBF
 }

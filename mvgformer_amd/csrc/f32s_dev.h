@@ -79,9 +79,10 @@ __device__ __forceinline__ void ring_prefetch(const bf16_t* __restrict__ wp, lon
 
 // Stage GEMM for one wavefront: rows [row0, row0 + 32 MT) of the activation planes x the 32 weight rows behind `wp`
 // (frag_ptr of plane 0; plane s at wp + s * wplane elements; k-steps are 1024 elements apart).  acc[mt][4 g + t] =
-// out[row0 + 32 mt + rl][8 g + 4 h + t] of the column block, lane = 32 h + rl.  MT = 1 alternates two accumulators (acc2)
-// so that consecutive MFMAs never depend on each other; the caller adds them (merge).
-template <int MT, int KSTEPS, int PITCH, int RING = 4, bool PRE = false>
+// out[row0 + 32 mt + rl][8 g + 4 h + t] of the column block, lane = 32 h + rl.  ALT (default for MT = 1) alternates two accumulators
+// (acc2) so that consecutive MFMAs never depend on each other; the caller adds them.  ALT = false with MT = 1 sums a row exactly as an
+// MT = 2 stage does (one accumulator per row block, the six products in order): the 32-row and 64-row tiles of chain B agree bit for bit.
+template <int MT, int KSTEPS, int PITCH, int RING = 4, bool PRE = false, bool ALT = (MT == 1)>
 __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_bytes, int row0, const bf16_t* __restrict__ wp,
                                       long wplane, f32x16 (&acc)[MT], f32x16* acc2, bool zero, int rot, int lane,
                                       f32x4 (*pre)[3] = nullptr, int prio_half = -1) {
@@ -92,7 +93,7 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
-    if (MT == 1) {
+    if (ALT) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) (*acc2)[e] = 0.f;
     }
@@ -152,7 +153,7 @@ __device__ __forceinline__ void stage(const char* __restrict__ act, int plane_by
           acc[mt][t] += __builtin_bit_cast(f32x4, b[TB[t]])[0] * __builtin_bit_cast(f32x4, a[mt][TA[t]])[1];
           continue;
         }
-        if (MT == 1 && (t & 1))
+        if (ALT && (t & 1))
           *acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[TB[t]], a[mt][TA[t]], *acc2, 0, 0, 0);
         else
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[TB[t]], a[mt][TA[t]], acc[mt], 0, 0, 0);

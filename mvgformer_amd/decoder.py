@@ -364,7 +364,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         fuse_a = (ok and len(pose_layers) == 3 and pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256
                   and pose_layers[0].in_features == 256 and self.proj_attn.f32_fused
                   and (levels is None or self.proj_attn.f32_g_form(Lq, levels.L, levels.S)))
-        fuse_b = (ok and self.num_joints <= 64 and (not self.open_forward_ffn or (self.linear1.out_features == 1024 and
+        fuse_b = (ok and self.num_joints <= 32 and (not self.open_forward_ffn or (self.linear1.out_features == 1024 and
                                                                                    self.linear1.in_features == 256)))
         return fuse_a, fuse_b
 

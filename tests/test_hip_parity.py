@@ -1652,3 +1652,38 @@ def test_linear_wgrad_and_autograd_function_vs_fp64(rows, N, K):
         y64.backward(dy.double())
         for got, ref in ((y, y64), (xi.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
             assert float((got.double() - ref.detach()).abs().max()) < 3e-6 * max(1.0, float(ref.detach().abs().max())) * (rows ** 0.5 if got is w.grad or got is b.grad else 1.0)
+
+
+def test_fp32_chain_b_tile_sizes_agree_bit_for_bit():
+    """mvg_chain_update_ffn_class_f32s picks 32-row tiles for launches that would leave CUs idle with 64-row tiles (cfg-4, a rank's
+    query shard).  Both variants sum every row in the same order: identical outputs, so a sharded run (small launch) and the
+    single-rank run (large launch) keep agreeing bit for bit.  Also against fp64 (the bars of tools/check_f32s.py)."""
+    from mvgformer_amd import _lib, ops
+    gen = torch.Generator().manual_seed(11)
+    B, NQ, J, V = 1, 41, 15, 3
+    rows = B * NQ * J
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    mk = lambda n, k: (rnd(n, k) / k ** 0.5, rnd(n) * 0.1)
+    attn, tgt, qpos = rnd(V * rows, 256), rnd(rows, 256), rnd(rows, 256)
+    (Wu, bu), (Wf1, bf1), (Wf2, bf2), (Wc, bc), (Wn, bn) = mk(256, 256), mk(1024, 256), mk(256, 1024), mk(2, 256), mk(192, 256)
+    g2, be2, g3, be3 = (1 + 0.1 * rnd(256) for _ in range(4))
+    args = (ops.split_swizzle_weight(Wu), bu, g2, be2, ops.split_swizzle_weight(Wf1), bf1, ops.split_swizzle_weight(Wf2), bf2, g3, be3,
+            Wc.contiguous(), bc)
+    nxt = (qpos, ops.split_swizzle_weight(Wn), torch.cat([bn, bn.new_zeros(64)]), 192)
+    lib = _lib.load()
+    res = {}
+    try:
+        for r in (64, 32):
+            assert lib.mvg_set_tuning(b"f32s_b_rows", r) == 0
+            res[r] = [t.clone() for t in ops.chain_update_ffn_class_f32s(attn, V, tgt, *args, 0.5, B, NQ, J, next_query_proj=nxt)]
+    finally:
+        lib.mvg_set_tuning(b"f32s_b_rows", 0)
+    torch.cuda.synchronize()
+    for a, b in zip(res[64], res[32]):
+        assert torch.equal(a, b)
+    ln = lambda x, g, b: torch.nn.functional.layer_norm(x, (256,), g.double(), b.double(), 1e-5)
+    lin = lambda x, W, b: x @ W.double().t() + b.double()
+    t1 = ln(tgt.double() + lin(attn.double().view(V, rows, 256).mean(0), Wu, bu), g2, be2)
+    y = ln(t1 + lin(torch.relu(lin(t1, Wf1, bf1)), Wf2, bf2), g3, be3)
+    assert float((res[32][0].double() - y).abs().max()) < 2e-5
+    assert float((res[32][4].double() - lin(y + qpos.double(), Wn, bn)).abs().max()) < 3e-5
