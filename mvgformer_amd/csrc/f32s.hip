@@ -23,6 +23,9 @@
 #ifndef F32S_PRIO
 #define F32S_PRIO 1           // the two wavefronts of a SIMD alternate issue priority per k-step (f32s_dev.h: stage)
 #endif
+#ifndef F32S_PYR_BALANCE
+#define F32S_PYR_BALANCE 1    // tiled pyramid kernel: the G stage's 12 (row block, column block) units over all 8 wavefronts
+#endif
 #ifndef F32S_PYR_WIDE
 #define F32S_PYR_WIDE 0       // tiled pyramid kernel: 16-byte stores from the (row, 4 columns) accumulator layout
 #endif
@@ -58,12 +61,12 @@ constexpr int NT = 512;
 // ------------------------------------------------------------------------------------------------------------------
 // pyramid products.  The MFMA operands are swapped against the chains (activations first): a lane then holds one output
 // COLUMN and 16 rows of it, so every store instruction writes two full 128-byte lines of the row-major outputs.
-template <int KSTEPS, int RING>
+template <int KSTEPS, int RING, int MT = 2>
 __device__ __forceinline__ void stage_swapped(const char* __restrict__ act, const bf16_t* __restrict__ wp, long wplane,
-                                              f32x16 (&acc)[2], int rot, int lane) {
+                                              f32x16 (&acc)[MT], int rot, int lane, int row0 = 0) {
   const int rl = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
   f32x4 ring[RING][3];
@@ -73,24 +76,24 @@ __device__ __forceinline__ void stage_swapped(const char* __restrict__ act, cons
 #pragma unroll
     for (int s = 0; s < 3; ++s) ring[p][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
   }
-  const char* arow = act + rl * PLP + 16 * h;
-  f32x4 a_nxt[2][3];
+  const char* arow = act + (row0 + rl) * PLP + 16 * h;
+  f32x4 a_nxt[MT][3];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int s = 0; s < 3; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * PLANE + mt * 32 * PLP + (rot & (KSTEPS - 1)) * 32);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    bf16x8 a[2][3], b[3];
+    bf16x8 a[MT][3], b[3];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int s = 0; s < 3; ++s) a[mt][s] = __builtin_bit_cast(bf16x8, a_nxt[mt][s]);
     if (ks + 1 < KSTEPS) {
       const int kn = (ks + 1 + rot) & (KSTEPS - 1);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int s = 0; s < 3; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * PLANE + mt * 32 * PLP + kn * 32);
     }
@@ -105,28 +108,29 @@ __device__ __forceinline__ void stage_swapped(const char* __restrict__ act, cons
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][TA[t]], b[TB[t]], acc[mt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // acc[mt][4 g + t] = out[row 32 mt + 8 g + 4 h + t][column rl of the block]
-__device__ __forceinline__ void store_swapped(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[2],
-                                              float bias, int lane) {
+template <int MT = 2>
+__device__ __forceinline__ void store_swapped(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[MT],
+                                              float bias, int lane, int row0 = 0) {
   const int h = lane >> 5;
-  float* dst = out + (r0 + 4 * h) * ld + col;
+  float* dst = out + (r0 + row0 + 4 * h) * ld + col;
   if (r0 + RM <= rows) {             // every tile but the last: no per-row predicate (32 exec regions per stage and wavefront)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
   } else {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        if (r0 + 4 * h + 32 * mt + 8 * (e >> 2) + (e & 3) < rows) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
+        if (r0 + row0 + 4 * h + 32 * mt + 8 * (e >> 2) + (e & 3) < rows) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
   }
 }
 
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restric
   const int rot = (w * 3) & 15;
   const bf16_t* wpv = frag_ptr(Wv, 0, w, 16, lane);
   const bf16_t* wpg = frag_ptr(Wg, 0, w, 16, lane);
+  const bf16_t* wpg2 = frag_ptr(Wg, 0, w < 4 ? w : 4 + ((w - 4) >> 1), 16, lane);     // balanced G stage (below)
   const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
   f32x4 bias4[4], zero4[4];          // (row, 4 columns) layout: the value bias of this lane's columns, held for the whole launch
 #pragma unroll
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restric
   int it = 0;
   for (; tile < ntiles; tile += gridDim.x, ++it) {
     const long r0 = tile * RM;
-    asm volatile("" : "+v"(wpv), "+v"(wpg));
+    asm volatile("" : "+v"(wpv), "+v"(wpg), "+v"(wpg2));
     if (it == 2) STAMP(0);
     __syncthreads();                               // the previous tile's stages have read the planes
     if (it == 2) STAMP(1);
@@ -213,7 +218,21 @@ __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restric
     store_swapped(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, lane);
 #endif
     if (it == 2) STAMP(5);
-    if (has_g) {
+    if (F32S_PYR_BALANCE && !F32S_PYR_WIDE && ng == 192) {
+      // G has 6 column blocks for 8 wavefronts: wavefronts 0..3 take blocks 0..3 with both row blocks, wavefronts 4..7 ONE row block
+      // of block 4 or 5 each -- 3 units on every SIMD instead of 4 on two of them and 2 on the others.  A row's sum is the same
+      // either way: one accumulator per row block, the six products in order, the rotation of its column block.
+      if (w < 4) {
+        stage_swapped<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+        if (it == 2) STAMP(6);
+        store_swapped(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, lane);
+      } else {
+        const int cbg = 4 + ((w - 4) >> 1), mtg = (w - 4) & 1;
+        f32x16 a1[1];
+        stage_swapped<16, 4, 1>(act, wpg2, 65536, a1, (cbg * 3 + 7) & 15, lane, 32 * mtg);
+        store_swapped<1>(G, ng, r0, rows, 32 * cbg + (lane & 31), a1, 0.f, lane, 32 * mtg);
+      }
+    } else if (has_g) {
 #if F32S_PYR_WIDE
       stage<2, 16, PLP>(act, PLANE, 0, wpg, 65536, acc, nullptr, true, (rot + 7) & 15, lane);
       if (it == 2) STAMP(6);
