@@ -99,3 +99,20 @@ def linear(x, weight, bias=None, relu=False):
         return LinearF32S.apply(x, wp, bp, relu)[..., :N]
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y
+
+
+class RefGatherAdd(Function):
+    """xin[n, q, l] = bilinear(feat[n], level l, reference point (n, q, l)) + query[n, q]  (projattn.py:134-141,180: grid_sample at the
+    clamped reference points, zeros padding, align_corners=False) through mvg_gather_ref; differentiable in `query` only."""
+
+    @staticmethod
+    def forward(ctx, query, feat, ref_lvl, levels):
+        n, Lq, C = query.shape
+        ain = ops.gather_ref(feat, ref_lvl, query.detach(), levels, 1, n)
+        ctx.shape = (n, Lq, levels.L, C)
+        return ain.view(n, Lq, levels.L, C)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g.reshape(ctx.shape).sum(2), None, None, None

@@ -24,6 +24,12 @@ from . import ops
 from .functions import DeformFunction
 
 
+def ops_host_levels_pair(spatial_shapes, level_start_index):
+    """(shapes, starts) as host lists, through ops.host_levels' per-tensor cache (no D2H sync after the first look-up)"""
+    sc, st = ops.host_levels(spatial_shapes, level_start_index)
+    return [[sc[2 * i], sc[2 * i + 1]] for i in range(len(st))], list(st)
+
+
 def _is_power_of_2(n):
     if (not isinstance(n, int)) or (n < 0):
         raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
@@ -418,7 +424,17 @@ class ProjAttn(nn.Module):
         else:
             input_flatten = torch.cat([s.flatten(2) for s in src_views], dim=-1).permute(0, 2, 1)
         assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == input_flatten.shape[1]
-        if self.ref_gather_native and input_flatten.dtype == torch.float32:
+        xin = None
+        if (self.ref_gather_native and input_flatten.dtype == torch.float32 and not input_flatten.requires_grad
+                and not reference_points.requires_grad and c % 4 == 0):
+            # neither the maps nor the reference points carry a gradient (run/train_3d.py with a frozen backbone and
+            # detach_refpoints_cameraprj, every shipped YAML): the inference path's gather kernel forms feats + query in one launch
+            # (the sampling op with one-hot level weights sampled every level three times: 380 us against ~100); the only gradient,
+            # d / d query, is the sum over the levels
+            from .functions import RefGatherAdd
+            levels = ops.Levels(*ops_host_levels_pair(input_spatial_shapes, input_level_start_index))
+            xin = RefGatherAdd.apply(query.contiguous(), input_flatten.contiguous(), reference_points.detach().float().contiguous(), levels)
+        elif self.ref_gather_native and input_flatten.dtype == torch.float32:
             # reference-point features through the sampling op itself (forward AND deterministic backward kernels) instead
             # of L grid_sample launches on the NCHW maps (projattn.py:134-141; 17 % of a training step): the channels-last
             # pyramid is the op's value with M heads of C / M channels, token (q, l) samples level l at the clamped
@@ -433,7 +449,8 @@ class ProjAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(n_views, -1, self.n_heads, self.d_model // self.n_heads)
-        xin = feats + query.unsqueeze(2)
+        if xin is None:
+            xin = feats + query.unsqueeze(2)
         n_off = self.sampling_offsets.out_features
         oa = lin(xin, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),      # one GEMM for both heads
                  torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
