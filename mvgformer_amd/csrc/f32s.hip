@@ -610,6 +610,138 @@ __global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// chain A, 32-row tiles, several workgroups per CU (knob f32s_a_rows = 32).  The 64-row kernel above holds a CU alone (101 KB of
+// planes, 256 registers per wavefront): every phase between its stage GEMMs -- tile load, three epilogues, the barriers' waits for
+// the slower wavefront of each SIMD -- is exposed, and they add up to as much as the GEMMs (s_memtime).  A 32-row tile is 51 KB:
+// two or three workgroups share a CU (128 registers per wavefront) and one's serial phases run under the others' matrix work; the
+// price is a fragment load per 6 MFMAs instead of per 12.  One workgroup per tile, no software pipeline (the neighbours are it).
+template <int RING>
+__global__ __launch_bounds__(NT, 4) void chain_a_f32s_small_kernel(const float* __restrict__ samp, const uint8_t* __restrict__ inside,
+                                                                   const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
+                                                                   const bf16_t* __restrict__ W0, const float* __restrict__ b0,
+                                                                   const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                                   const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                   float* __restrict__ attn, float* __restrict__ o,
+                                                                   const int* __restrict__ order, const float* __restrict__ o_masked,
+                                                                   int R) {
+  constexpr int RMS = 32, SPLANE = RMS * PLP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;
+  int* rid = reinterpret_cast<int*>(smem + 3 * SPLANE);
+  int* keepf = rid + RMS;
+  float* w2s = reinterpret_cast<float*>(keepf + RMS);
+  float* bias_s = w2s + 768;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31;
+  const int r0 = blockIdx.x * RMS;
+  const int rot = (w * 3) & 15;
+  for (int i = tid; i < 768; i += NT) {
+    w2s[i] = W2[i];
+    bias_s[i] = (i < 256 ? bp : i < 512 ? b0 : b1)[i & 255];
+  }
+  bool mine = false;
+  if (tid < RMS) {
+    const int slot = r0 + tid;
+    const int g = slot < R ? (order ? order[slot] : slot) : -1;
+    rid[tid] = g;
+    mine = g >= 0 && inside[g] != 0;
+    keepf[tid] = mine ? 1 : 0;
+  }
+  const bool any_inside = __syncthreads_or(mine) != 0;
+  if (!any_inside && o_masked) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = i * NT + tid, g = rid[c >> 6];
+      if (g >= 0) *reinterpret_cast<f32x4*>(attn + (long)g * 256 + (c & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < RMS && rid[tid] >= 0) {
+      float* og = o + (long)rid[tid] * 3;
+      og[0] = o_masked[0];
+      og[1] = o_masked[1];
+      og[2] = o_masked[2];
+    }
+    return;
+  }
+  {
+    f32x4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = i * NT + tid;
+      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid[c >> 6], 0) * 256 + (c & 63) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = i * NT + tid;
+      store_split4<PLP>(act, SPLANE, c >> 6, (c & 63) * 4, rid[c >> 6] >= 0 ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+  const bool keep[1] = {keepf[rl] != 0}, all[1] = {true};
+  __syncthreads();
+  f32x16 acc[1];
+  f32x4 bvr[4];
+  uint2 pk[1][4][3];
+  const bf16_t* wps[3] = {frag_ptr(Wp, 0, w, 16, lane), frag_ptr(W0, 0, w, 16, lane), frag_ptr(W1, 0, w, 16, lane)};
+#pragma unroll
+  for (int st = 0; st < 3; ++st) {
+    stage<1, 16, PLP, RING, false, false>(act, SPLANE, 0, wps[st], 65536, acc, nullptr, true, (rot + 5 * st) & 15, lane);
+    load_bias(bias_s + 256 * st + 32 * w, bvr, lane);
+    split_planes<1>(pk, acc, bvr, st > 0, st == 0 ? keep : all);
+    __syncthreads();
+    store_planes<1, PLP>(act, SPLANE, 0, 32 * w, pk, lane);
+    __syncthreads();
+    if (st == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                             // attn rows -> global: 32 B per thread
+        const int c = i * NT + tid, row = c >> 5, ch = c & 31, g = rid[row];
+        const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + ch * 16);
+        const uint4 mm = *reinterpret_cast<const uint4*>(act + SPLANE + row * PLP + ch * 16);
+        const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * SPLANE + row * PLP + ch * 16);
+        if (g >= 0) {
+          float* dst = attn + (long)g * 256 + ch * 8;
+          *reinterpret_cast<f32x4*>(dst) = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
+          *reinterpret_cast<f32x4*>(dst + 4) = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
+        }
+      }
+    }
+  }
+  // last layer (3 outputs): 16 threads per row, 16 columns each in column order, then a balanced tree over the 16 lanes
+  {
+    const int row = tid >> 4, part = tid & 15;
+    float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 16; c += 8) {
+      const int col = part * 16 + c;
+      const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + col * 2);
+      const uint4 mm = *reinterpret_cast<const uint4*>(act + SPLANE + row * PLP + col * 2);
+      const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * SPLANE + row * PLP + col * 2);
+      const f32x4 va = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
+      const f32x4 vb = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col + 4);
+        a3[k] += va[0] * wa[0] + va[1] * wa[1] + va[2] * wa[2] + va[3] * wa[3] + vb[0] * wb[0] + vb[1] * wb[1] + vb[2] * wb[2] + vb[3] * wb[3];
+        asm volatile("" : "+v"(a3[k]));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v = a3[k];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror: lanes 0..7 <-> 15..8
+      a3[k] = v;
+    }
+    if (part == 0 && rid[row] >= 0) {
+      float* og = o + (long)rid[row] * 3;
+      og[0] = a3[0] + b2[0];
+      og[1] = a3[1] + b2[1];
+      og[2] = a3[2] + b2[2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // chain B: one workgroup = 4 person-queries x 15 joints (60 token rows in a 64-row tile).
 // Row statistics (LayerNorm, class head) live in the accumulator layout -- lane (rl, h) of wavefront w holds columns
 // 32 w + 8 g + 4 h + t of rows rl and 32 + rl -- and are completed across the 8 wavefronts through a (64 x 8) LDS table
@@ -936,6 +1068,8 @@ int cu_count() {
 
 }  // namespace
 
+int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two workgroups per CU (default: cfg-2 184 -> 140 us in the forward), 64 = one
+                          // persistent 64-row workgroup per CU, 31 = the 32-row kernel with a 2-deep fragment ring
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
 
@@ -975,6 +1109,20 @@ extern "C" int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside
                                         void* stream) {
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
+  if (g_f32s_a_rows == 32 || g_f32s_a_rows == 31) {       // (31: the same kernel with a 2-k-step fragment ring, for measurements)
+    const size_t lds32 = 3 * 32 * PLP + 2 * 32 * sizeof(int) + 2 * 768 * sizeof(float);
+    static bool configured32[MVG_MAX_DEVICES] = {}, configured31[MVG_MAX_DEVICES] = {};
+    if (int rc = configure_lds(&chain_a_f32s_small_kernel<4>, lds32, configured32)) return rc;
+    if (int rc = configure_lds(&chain_a_f32s_small_kernel<2>, lds32, configured31)) return rc;
+    if (g_f32s_a_rows == 32)
+      hipLaunchKernelGGL(chain_a_f32s_small_kernel<4>, dim3((rows + 31) / 32), dim3(NT), lds32, (hipStream_t)stream, samp, inside,
+                         (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows);
+    else
+      hipLaunchKernelGGL(chain_a_f32s_small_kernel<2>, dim3((rows + 31) / 32), dim3(NT), lds32, (hipStream_t)stream, samp, inside,
+                         (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows);
+    MVG_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = 3 * PLANE + 4 * RM * sizeof(int) + 2 * 768 * sizeof(float);
   static bool configured[MVG_MAX_DEVICES] = {};
   if (int rc = configure_lds(&chain_a_f32s_kernel, lds, configured)) return rc;

@@ -340,7 +340,9 @@ class DQDecoderLayer(MvPDecoderLayer):
                self._w("Wpe1_f32s", (pose_layers[1].weight,), bf, sp), self._w("bpe1", (pose_layers[1].bias,), f32),
                self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
         pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
-        o_masked = self._w("o_masked_f32s", pose_params, f32, lambda *_: ops.chain_masked_row_output_f32s(*wts))
+        from . import _lib      # (the tile variants sum the last pose layer in different orders: the constant comes from the active one)
+        o_masked = self._w("o_masked_f32s/a_rows=%d" % _lib.TUNING.get("f32s_a_rows", 32), pose_params, f32,
+                           lambda *_: ops.chain_masked_row_output_f32s(*wts))
         return wts, o_masked
 
     def _chain_b_weights_f32s(self):
