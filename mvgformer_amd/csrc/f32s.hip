@@ -629,15 +629,16 @@ __global__ __launch_bounds__(NT, 4) void chain_a_f32s_small_kernel(const float* 
   char* act = smem;
   int* rid = reinterpret_cast<int*>(smem + 3 * SPLANE);
   int* keepf = rid + RMS;
-  float* w2s = reinterpret_cast<float*>(keepf + RMS);
-  float* bias_s = w2s + 768;
+  float* w2l = reinterpret_cast<float*>(keepf + RMS);
+  float* bias_l = w2l + 768;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31;
   const int r0 = blockIdx.x * RMS;
   const int rot = (w * 3) & 15;
   for (int i = tid; i < 768; i += NT) {
-    w2s[i] = W2[i];
-    bias_s[i] = (i < 256 ? bp : i < 512 ? b0 : b1)[i & 255];
+    w2l[i] = W2[i];
+    bias_l[i] = (i < 256 ? bp : i < 512 ? b0 : b1)[i & 255];
   }
+  const float* w2s = w2l;
   bool mine = false;
   if (tid < RMS) {
     const int slot = r0 + tid;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(NT, 4) void chain_a_f32s_small_kernel(const float* 
 #pragma unroll
   for (int st = 0; st < 3; ++st) {
     stage<1, 16, PLP, RING, false, false>(act, SPLANE, 0, wps[st], 65536, acc, nullptr, true, (rot + 5 * st) & 15, lane);
-    load_bias(bias_s + 256 * st + 32 * w, bvr, lane);
+    load_bias(bias_l + 256 * st + 32 * w, bvr, lane);
     split_planes<1>(pk, acc, bvr, st > 0, st == 0 ? keep : all);
     __syncthreads();
     store_planes<1, PLP>(act, SPLANE, 0, 32 * w, pk, lane);
@@ -1109,17 +1110,17 @@ extern "C" int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside
                                         void* stream) {
   if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
-  if (g_f32s_a_rows == 32 || g_f32s_a_rows == 31) {       // (31: the same kernel with a 2-k-step fragment ring, for measurements)
+  if (g_f32s_a_rows != 64) {       // 32: the default; 31: measurement variant with a 2-deep fragment ring
     const size_t lds32 = 3 * 32 * PLP + 2 * 32 * sizeof(int) + 2 * 768 * sizeof(float);
-    static bool configured32[MVG_MAX_DEVICES] = {}, configured31[MVG_MAX_DEVICES] = {};
-    if (int rc = configure_lds(&chain_a_f32s_small_kernel<4>, lds32, configured32)) return rc;
-    if (int rc = configure_lds(&chain_a_f32s_small_kernel<2>, lds32, configured31)) return rc;
-    if (g_f32s_a_rows == 32)
-      hipLaunchKernelGGL(chain_a_f32s_small_kernel<4>, dim3((rows + 31) / 32), dim3(NT), lds32, (hipStream_t)stream, samp, inside,
-                         (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows);
-    else
-      hipLaunchKernelGGL(chain_a_f32s_small_kernel<2>, dim3((rows + 31) / 32), dim3(NT), lds32, (hipStream_t)stream, samp, inside,
-                         (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows);
+    static bool c32[MVG_MAX_DEVICES] = {}, c31[MVG_MAX_DEVICES] = {};
+    if (int rc = configure_lds(&chain_a_f32s_small_kernel<4>, lds32, c32)) return rc;
+    if (int rc = configure_lds(&chain_a_f32s_small_kernel<2>, lds32, c31)) return rc;
+#define MVG_CAS(K)                                                                                                            \
+    hipLaunchKernelGGL(K, dim3((rows + 31) / 32), dim3(NT), lds32, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp, bp,  \
+                       (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows)
+    if (g_f32s_a_rows == 31) MVG_CAS(chain_a_f32s_small_kernel<2>);
+    else MVG_CAS(chain_a_f32s_small_kernel<4>);
+#undef MVG_CAS
     MVG_LAUNCH_CHECK();
     return 0;
   }
