@@ -183,6 +183,13 @@ int mvg_linear_splitk_f32(const float* A, int lda, const float* W, int ldw, floa
 int mvg_linear_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, int rows, int N, int K, int splits,
                          void* stream);
 
+/* The same with the bias gradient and the sum over the slices: dW (N, K) = dY^T X and, when db is not NULL, db (N) = the column sums
+ * of dY (what autograd's Linear backward returns for weight and bias, lib/models/dq_decoder.py:659-717 under run/train_3d.py).
+ * `partial` (splits, N, K) and `partial_db` (splits, N) are workspaces; a second small launch adds them in slice order
+ * (deterministic; dW equals mvg_linear_wgrad_f32's partials summed slice 0 first). */
+int mvg_linear_wgrad_bias_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, float* partial_db, float* dW, float* db,
+                              int rows, int N, int K, int splits, void* stream);
+
 /* mvg_linear with the activation formed as A + A2 on load (A2: fp32, same shape and leading dimension as A, or NULL):
  * the query term of the first layer, Linear(tgt + query_pos) (dq_decoder.py:580 `with_pos_embed` + projattn.py:180-181),
  * without a separate elementwise pass over the two (B*Lq, 256) tensors. */
@@ -366,6 +373,20 @@ int mvg_triangulate_project(const float* r, const float* o, const float* cams, c
  * iterations, K) and jac (B, V, Lq, 4) = the row-major 2 x 2 Jacobian d(ud) / d(ref2d) of every point (forward mode through the
  * same iterations): the backward of this step is grad_ref2d = jac^T grad_ud.  cams: the packed records, image n = v * B + b. */
 int mvg_uncrop_undistort_jac(const float* ref2d, const float* cams, float* ud, float* jac, int V, int B, int Lq, void* stream);
+
+/* The differentiable triangulation of the training path (lib/models/multiview.py:170-228 as called by
+ * lib/models/dq_decoder.py:929-967 under autograd), dense over the (B, NQ * J) tokens: X (B, NQ*J, 3) = v0[:3] / v0[3], v0 the
+ * eigenvector of the smallest eigenvalue of A^T A, A's rows conf[b,v,t] * (P[b,v,2] * ud[b,v,t,c] - P[b,v,c]) (rows, Gram
+ * matrix and Jacobi eigen-solve in fp64).  ud (B, V, Lq, 2), conf (B, V, Lq), Pm (B, V, 3, 4) fp32; valid (B, NQ) uint8: tokens of
+ * queries with valid == 0 are skipped and get X = 0 (the reference triangulates the matched queries only).  V <= 32. */
+int mvg_dlt_forward(const float* ud, const float* conf, const float* Pm, const uint8_t* valid, float* X, int V, int B, int NQ, int J,
+                    void* stream);
+
+/* Its backward: g_ud (B, V, Lq, 2), g_conf (B, V, Lq) from gX (B, Lq, 3); the decomposition is recomputed from the inputs
+ * (dL/dG = sym(m v0^T), m = sum_{i != 0} v_i (v_i^T g) / (l0 - l_i); pairs with |l0 - l_i| <= 1e-14 max|l| contribute nothing);
+ * zero gradients for skipped tokens. */
+int mvg_dlt_backward(const float* ud, const float* conf, const float* Pm, const uint8_t* valid, const float* gX, float* g_ud,
+                     float* g_conf, int V, int B, int NQ, int J, void* stream);
 
 /* Batched eigen-decomposition of n symmetric 4x4 fp64 matrices G (n,4,4): evals (n,4) in no particular order, evecs
  * (n,4,4) with the eigenvectors as columns (G v_k = evals_k v_k, v_k = evecs[:, :, k]).  fp64 cyclic Jacobi, one lane

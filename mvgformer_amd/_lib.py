@@ -37,6 +37,9 @@ SIGNATURES = {
     "mvg_linear": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "mvg_linear_splitk_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "mvg_linear_wgrad_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "mvg_dlt_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvg_dlt_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvg_linear_wgrad_bias_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_linear_ordered": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mvg_linear_sum": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "mvg_msda_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

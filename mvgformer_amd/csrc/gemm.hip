@@ -386,8 +386,14 @@ __device__ __forceinline__ void split8_store(char* lds, int row, int slot, const
   }
 }
 
+// FUSED: the workgroups of the first column of tiles also publish the column sums of their dY slices (the bias gradient's partials);
+// wgrad_reduce_kernel then adds the slices' partials of both in slice order.  (Adding them inside this launch -- the workgroup that
+// draws a tile's last ticket sums the tile -- was built and measured: the last workgroup of each tile reads `splits` x 64 KB alone,
+// 30 ms of tails per training step.)
+template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void wgrad_f32s_kernel(const float* __restrict__ dY, long ldy, const float* __restrict__ X, long ldx,
-                                                            float* __restrict__ partial, int rows, int N, int K, int rows_per_split) {
+                                                            float* __restrict__ partial, int rows, int N, int K, int rows_per_split,
+                                                            float* __restrict__ partial_db) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * SPITCH];
   char* ldsA = lds;                 // dY^T tile: row = output feature n (of dY), 32 reduction rows per slab
@@ -411,11 +417,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32s_kernel(const float* __restr
       x[i] = (r < r_end && c0 < width) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};      // FUSED: this thread's share of the column sums of dY (8 rows x 4 columns per slab)
   auto lstore = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float v[8] = {x[0][c], x[1][c], x[2][c], x[3][c], x[4][c], x[5][c], x[6][c], x[7][c]};
       split8_store(dst, 4 * cgrp + c, rgrp, v);
+      if constexpr (FUSED) bsum[c] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
   };
   f32x16 acc[2][2];
@@ -473,6 +481,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32s_kernel(const float* __restr
         if (m < N && n < K)
           *reinterpret_cast<f32x4*>(outz + (long)m * K + n) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
       }
+  }
+  if constexpr (FUSED) {
+    if (partial_db != nullptr && blockIdx.x == 0) {
+      float* red = reinterpret_cast<float*>(lds);       // the operand tiles are dead (barrier at the end of the last slab)
+      if (opnd == 0)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[rgrp * BM + 4 * cgrp + c] = bsum[c];
+      __syncthreads();
+      if (tid < BM && m0 + tid < N)
+        partial_db[(long)blockIdx.z * N + m0 + tid] = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
+    }
+  }
+}
+
+// dW = sum over the slices of partial (Z, N*K) and db = sum of partial_db (Z, N), slice 0 first: one float4 (or one bias entry) per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
+                                                           float* __restrict__ dW, float* __restrict__ db, int Z, long nk4, int N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < nk4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial) + i;
+    f32x4 sum = src[0];
+    int z = 1;
+    for (; z + 4 <= Z; z += 4) {
+      const f32x4 a = src[(long)z * nk4], b = src[(long)(z + 1) * nk4], c = src[(long)(z + 2) * nk4], d = src[(long)(z + 3) * nk4];
+      sum = (((sum + a) + b) + c) + d;
+    }
+    for (; z < Z; ++z) sum += src[(long)z * nk4];
+    reinterpret_cast<f32x4*>(dW)[i] = sum;
+  } else if (db != nullptr && i - nk4 < N) {
+    const long n = i - nk4;
+    float sum = partial_db[n];
+    for (int z = 1; z < Z; ++z) sum += partial_db[(long)z * N + n];
+    db[n] = sum;
   }
 }
 
@@ -554,7 +595,27 @@ extern "C" int mvg_linear_wgrad_f32(const float* dY, int ldy, const float* X, in
   if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(partial)) % 16 != 0) return MVG_E_BADARG;
   const int rps = ((rows + splits - 1) / splits + 31) / 32 * 32;          // whole 32-row slabs per slice
   dim3 grid((K + 127) / 128, (N + 127) / 128, splits);
-  hipLaunchKernelGGL(wgrad_f32s_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, X, (long)ldx, partial, rows, N, K, rps);
+  hipLaunchKernelGGL(wgrad_f32s_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, X, (long)ldx, partial, rows, N, K, rps,
+                     (float*)nullptr);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mvg_linear_wgrad_bias_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, float* partial_db, float* dW,
+                                         float* db, int rows, int N, int K, int splits, void* stream) {
+  if (!dY || !X || !partial || !dW || rows <= 0 || N <= 0 || K <= 0 || splits <= 0) return MVG_E_BADARG;
+  if (db && !partial_db) return MVG_E_BADARG;
+  if (N % 4 != 0 || K % 4 != 0 || ldy % 4 != 0 || ldx % 4 != 0 || ldy < N || ldx < K) return MVG_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(dW)) % 16 != 0)
+    return MVG_E_BADARG;
+  const int rps = ((rows + splits - 1) / splits + 31) / 32 * 32;
+  dim3 grid((K + 127) / 128, (N + 127) / 128, splits);
+  hipLaunchKernelGGL(wgrad_f32s_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, X, (long)ldx, partial, rows, N, K, rps,
+                     db ? partial_db : (float*)nullptr);
+  MVG_LAUNCH_CHECK();
+  const long nk4 = (long)N * K / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + (db ? N : 0) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     partial_db, dW, db, splits, nk4, N);
   MVG_LAUNCH_CHECK();
   return 0;
 }

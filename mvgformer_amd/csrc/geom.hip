@@ -1013,6 +1013,180 @@ __global__ __launch_bounds__(256) void uncrop_undistort_jac_kernel(const float* 
   *reinterpret_cast<f32x4*>(jac + i * 4) = f32x4{t00 * a00 + t01 * a10, t00 * a01 + t01 * a11, t10 * a00 + t11 * a10, t10 * a01 + t11 * a11};
 }
 
+// ------------------------------------------------------------------------------------------
+// Training path: the differentiable triangulation (multiview.py:170-228 under autograd; geometry_torch.dlt as torch ops) as one launch
+// forward and one backward over the DENSE (B, Lq) token grid -- tokens of unmatched queries are skipped (zeros out, zero gradients), so
+// the caller needs no nonzero / index / index_put round trip (a host sync and ~30 sort launches in their backward).  Per token: the
+// 2V x 4 row matrix A (rows conf * (P[2] * u - P[0|1])), its Gram matrix and the Jacobi eigen-solve, all in fp64,
+// X = v0[:3] / v0[3] (v0: eigenvector of the smallest eigenvalue).  The backward recomputes the decomposition and applies
+//   dL/dG = sym(m v0^T),  m = sum_{i != 0} v_i (v_i^T g) / (l0 - l_i);   dA = A (dG + dG^T);   A's rows -> (u, conf).
+constexpr int DLT_MAX_VIEWS = 32;
+
+struct DltEig {
+  double w[4], Vm[4][4];
+  int k;
+};
+
+__device__ __forceinline__ void dlt_row(const float* __restrict__ P, const float u, const int c, double (&row)[4]) {
+  // P: one view's (3, 4) projection matrix; row = P[2] * u - P[c].  In fp64: the torch form rounds the rows to fp32, which costs its
+  // confidence gradients (sums that cancel to 1e-3 of their terms) three digits against the SVD's autograd in fp64
+#pragma unroll
+  for (int e = 0; e < 4; ++e) row[e] = __builtin_fma((double)P[8 + e], (double)u, -(double)P[4 * c + e]);
+}
+
+__device__ __forceinline__ void dlt_decompose(const float* __restrict__ ud, const float* __restrict__ conf, const float* __restrict__ Pm,
+                                              const int b, const long t, const int V, const long Lq, DltEig& E) {
+  double G[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      G[a][c] = 0.0;
+      E.Vm[a][c] = (a == c) ? 1.0 : 0.0;
+    }
+  for (int v = 0; v < V; ++v) {
+    const long pv = ((long)b * V + v) * Lq + t;
+    const float2 u = *reinterpret_cast<const float2*>(ud + pv * 2);
+    const float cf = conf[pv];
+    const float* P = Pm + ((long)b * V + v) * 12;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      double row[4];
+      dlt_row(P, c ? u.y : u.x, c, row);
+      double rd[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rd[e] = row[e] * (double)cf;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = a; e < 4; ++e) G[a][e] = __builtin_fma(rd[a], rd[e], G[a][e]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < a; ++e) G[a][e] = G[e][a];
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(G[0][1]) + fabs(G[0][2]) + fabs(G[0][3]) + fabs(G[1][2]) + fabs(G[1][3]) + fabs(G[2][3]);
+    const double lg = fmax(fmax(fabs(G[0][0]), fabs(G[1][1])), fmax(fabs(G[2][2]), fabs(G[3][3])));
+    if (off <= 2e-16 * lg) break;
+    jacobi_rotate2(G, E.Vm, 0, 1, 2, 3);
+    jacobi_rotate2(G, E.Vm, 0, 2, 1, 3);
+    jacobi_rotate2(G, E.Vm, 0, 3, 1, 2);
+  }
+  E.k = 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    E.w[a] = G[a][a];
+    if (a > 0 && E.w[a] < E.w[E.k]) E.k = a;
+  }
+}
+
+__device__ __forceinline__ double pick4(const double (&x)[4], const int k) {
+  return k == 0 ? x[0] : k == 1 ? x[1] : k == 2 ? x[2] : x[3];
+}
+
+__global__ __launch_bounds__(64) void dlt_fwd_kernel(const float* __restrict__ ud, const float* __restrict__ conf,
+                                                     const float* __restrict__ Pm, const uint8_t* __restrict__ valid,
+                                                     float* __restrict__ X, int V, int B, long Lq, int J) {
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= (long)B * Lq) return;
+  const int b = (int)(i / Lq);
+  const long t = i - (long)b * Lq;
+  float* out = X + i * 3;
+  if (!valid[(long)b * (Lq / J) + t / J]) {
+    out[0] = out[1] = out[2] = 0.f;
+    return;
+  }
+  DltEig E;
+  dlt_decompose(ud, conf, Pm, b, t, V, Lq, E);
+  float xh[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) xh[a] = (float)pick4(E.Vm[a], E.k);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) out[a] = xh[a] / xh[3];
+}
+
+__global__ __launch_bounds__(64) void dlt_bwd_kernel(const float* __restrict__ ud, const float* __restrict__ conf,
+                                                     const float* __restrict__ Pm, const uint8_t* __restrict__ valid,
+                                                     const float* __restrict__ gX, float* __restrict__ g_ud, float* __restrict__ g_conf,
+                                                     int V, int B, long Lq, int J) {
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= (long)B * Lq) return;
+  const int b = (int)(i / Lq);
+  const long t = i - (long)b * Lq;
+  if (!valid[(long)b * (Lq / J) + t / J]) {
+    for (int v = 0; v < V; ++v) {
+      const long pv = ((long)b * V + v) * Lq + t;
+      *reinterpret_cast<float2*>(g_ud + pv * 2) = make_float2(0.f, 0.f);
+      g_conf[pv] = 0.f;
+    }
+    return;
+  }
+  DltEig E;
+  dlt_decompose(ud, conf, Pm, b, t, V, Lq, E);
+  double v0[4], g[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) v0[a] = pick4(E.Vm[a], E.k);
+  {
+    // X = xh[:3] / xh[3] in fp32 (xh = v0 rounded to fp32): its gradient with respect to xh
+    float xh[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) xh[a] = (float)v0[a];
+    const double iw = 1.0 / (double)xh[3];
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      g[a] = (double)gX[i * 3 + a] * iw;
+      s += (double)gX[i * 3 + a] * (double)xh[a];
+    }
+    g[3] = -s * iw * iw;
+  }
+  const double l0 = pick4(E.w, E.k);
+  const double scale = fmax(fmax(fmax(fabs(E.w[0]), fabs(E.w[1])), fmax(fabs(E.w[2]), fabs(E.w[3]))), 1e-300);
+  double m[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double den = l0 - E.w[e];
+    const bool safe = fabs(den) > 1e-14 * scale && e != E.k;
+    const double dot = E.Vm[0][e] * g[0] + E.Vm[1][e] * g[1] + E.Vm[2][e] * g[2] + E.Vm[3][e] * g[3];
+    const double coef = safe ? dot / den : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) m[a] = __builtin_fma(E.Vm[a][e], coef, m[a]);
+  }
+  for (int v = 0; v < V; ++v) {
+    const long pv = ((long)b * V + v) * Lq + t;
+    const float2 u = *reinterpret_cast<const float2*>(ud + pv * 2);
+    const float cf = conf[pv];
+    const float* P = Pm + ((long)b * V + v) * 12;
+    double gu[2], gc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      double row[4];
+      dlt_row(P, c ? u.y : u.x, c, row);
+      // a = conf * row;  da = (a . m) v0 + (a . v0) m
+      double am = 0.0, av = 0.0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double a = row[e] * (double)cf;
+        am = __builtin_fma(a, m[e], am);
+        av = __builtin_fma(a, v0[e], av);
+      }
+      double d_row = 0.0, d_p2 = 0.0;         // da . row (-> conf), da . P[2] (-> u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double da = am * v0[e] + av * m[e];
+        d_row = __builtin_fma(da, row[e], d_row);
+        d_p2 = __builtin_fma(da, (double)P[8 + e], d_p2);
+      }
+      gc += d_row;
+      gu[c] = (double)cf * d_p2;
+    }
+    *reinterpret_cast<float2*>(g_ud + pv * 2) = make_float2((float)gu[0], (float)gu[1]);
+    g_conf[pv] = (float)gc;
+  }
+}
+
 extern "C" {
 
 int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W, int S, int start,
@@ -1241,6 +1415,29 @@ int mvg_uncrop_undistort_jac(const float* ref2d, const float* cams, float* ud, f
   if (total == 0) return 0;
   hipLaunchKernelGGL(uncrop_undistort_jac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref2d, cams, ud,
                      jac, V, B, Lq);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_dlt_forward(const float* ud, const float* conf, const float* Pm, const uint8_t* valid, float* X, int V, int B, int NQ, int J,
+                    void* stream) {
+  if (!ud || !conf || !Pm || !valid || !X || V <= 0 || V > DLT_MAX_VIEWS || B <= 0 || NQ < 0 || J <= 0) return MVG_E_BADARG;
+  const long total = (long)B * NQ * J;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(dlt_fwd_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, ud, conf, Pm, valid, X, V, B,
+                     (long)NQ * J, J);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
+
+int mvg_dlt_backward(const float* ud, const float* conf, const float* Pm, const uint8_t* valid, const float* gX, float* g_ud,
+                     float* g_conf, int V, int B, int NQ, int J, void* stream) {
+  if (!ud || !conf || !Pm || !valid || !gX || !g_ud || !g_conf || V <= 0 || V > DLT_MAX_VIEWS || B <= 0 || NQ < 0 || J <= 0)
+    return MVG_E_BADARG;
+  const long total = (long)B * NQ * J;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(dlt_bwd_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream, ud, conf, Pm, valid, gX, g_ud,
+                     g_conf, V, B, (long)NQ * J, J);
   MVG_LAUNCH_CHECK();
   return 0;
 }

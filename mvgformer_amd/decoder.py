@@ -466,11 +466,9 @@ class DQDecoderLayer(MvPDecoderLayer):
         ctx = self._ctx
         tc = getattr(ctx, "_train_cache", None) if ctx is not None else None
         if tc is None:
-            cam = {k: torch.stack([meta[v]["camera"][k].to(dev) for v in range(V)], 1)
-                   for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p")}
-            tc = dict(cams=ctx.cams if ctx is not None else ops.pack_cameras(meta, self.img_size, dev),
-                      levels=ctx.levels if ctx is not None else ops.Levels(src_spatial_shapes, level_start_index),
-                      Pm=G.proj_matrices(cam))
+            cams = ctx.cams if ctx is not None else ops.pack_cameras(meta, self.img_size, dev)
+            tc = dict(cams=cams, levels=ctx.levels if ctx is not None else ops.Levels(src_spatial_shapes, level_start_index),
+                      Pm=G.proj_matrices_from_records(cams, V, B))
             if ctx is not None:
                 ctx._train_cache = tc
         # all V views as ONE batch of V*B images (image n = v*B + b, the order of src_views): one projection, one ProjAttn
@@ -510,25 +508,23 @@ class DQDecoderLayer(MvPDecoderLayer):
                 valid[b, torch.as_tensor(q, dtype=torch.long, device=dev)] = True
         else:
             valid = prob[..., 1] > threshold
-        if not bool(valid.any()):
-            valid[0, 0] = True                                                 # dq_decoder.py:620-623
+        # no query kept -> the first one is (dq_decoder.py:620-623), decided on the device (no host sync in the step)
+        valid[0, 0] |= ~valid.any()
         hp = a_all                                                              # offset_net (dq_decoder.py:97-111)
         pl = self.pose_embed.MLP.layers
         for i, layer_ in enumerate(pl):
             hp = lin(hp, layer_.weight, layer_.bias, relu=i < len(pl) - 1)
-        off, cl = hp[..., :2], hp[..., -1]                                      # (V*B,Lq,2), (V*B,Lq)
+        off, cl = hp.split([2, 1], -1)                                          # (V*B,Lq,2), (V*B,Lq,1)
         ref2d = ((r_all + off / img) * img).view(V, B, Lq, 2).transpose(0, 1)    # (B,V,Lq,2)
         proj2d = (r_all * img).view(V, B, Lq, 2).transpose(0, 1)
         conf = torch.softmax(cl.reshape(V, B, Lq).transpose(0, 1), 1)
         # un-crop + undistortion (dq_decoder.py:414-420, 119-204): one launch forward (with every point's Jacobian), one small
-        # product backward (geometry_torch.UncropUndistort) -- as torch ops ~80 launches forward and ~160 backward per layer
-        # Only the matched queries are triangulated, like the reference (dq_decoder.py:929-967): an unmatched query
-        # with a degenerate DLT (homogeneous w == 0, an Inf 2D point) would otherwise put 0 * inf = NaN into the
-        # gradients of the parameters all queries share.
-        ud, Pm = G.UncropUndistort.apply(ref2d, tc["cams"], V, B), tc["Pm"]
-        bi, ti = valid.view(B, NQ, 1).expand(B, NQ, J).reshape(B, Lq).nonzero(as_tuple=True)
-        Xv = G.dlt(Pm[bi], ud[bi, :, ti].unsqueeze(2), conf[bi, :, ti].unsqueeze(2))[:, 0]     # (n_valid_tokens, 3)
-        new_ref = torch.zeros((B, Lq, 3), dtype=Xv.dtype, device=dev).index_put((bi, ti), Xv)
+        # product backward (geometry_torch.UncropUndistort) -- as torch ops ~80 launches forward and ~160 backward per layer.
+        # Triangulation (dq_decoder.py:929-967): one launch each way over the dense token grid (geometry_torch.DenseDLT).  Only the
+        # matched queries are triangulated, like the reference: an unmatched query with a degenerate DLT (homogeneous w == 0, an
+        # Inf 2D point) would otherwise put 0 * inf = NaN into the gradients of the parameters all queries share.
+        ud = G.UncropUndistort.apply(ref2d, tc["cams"], V, B)
+        new_ref = G.DenseDLT.apply(ud, conf, tc["Pm"], valid.to(torch.uint8), J)
         vm2 = valid.view(B, 1, NQ, 1, 1)
         zero = torch.zeros((), device=dev)
         ref2d_o = torch.where(vm2, ref2d.view(B, V, NQ, J, 2), zero).reshape(B, V, Lq, 2)

@@ -47,56 +47,73 @@ class LinearF32S(Function):
     """y = act(x W^T + b) with all three GEMMs of its autograd on mvg_linear's split form:
          forward  y  = x W^T              (rows, K) x (N, K)^T, bias + ReLU in the epilogue
          dgrad    dx = dy W               = mvg_linear(dy, W^T as an (K, N) "weight")
-         wgrad    dW = dy^T x             = mvg_linear_wgrad_f32 (the reduction runs over the rows; split into slices)
+         wgrad    dW = dy^T x, db = sum dy = mvg_linear_wgrad_bias_f32 (the reduction runs over the rows: split into slices, the
+                                            slices' partials and the bias gradient summed inside the same launch)
        (the Linear + ReLU + Linear chains of lib/models/dq_decoder.py:659-717,763-778, mvp_decoder.py:94-98 and
-       lib/models/ops/modules/projattn.py:169,180-181,203 under torch autograd)."""
+       lib/models/ops/modules/projattn.py:169,180-181,203 under torch autograd).  Output widths that are not a multiple of 32 (the
+       2- and 3-output heads) run with zero rows up to 32 outputs; the padding stays inside this Function."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x2 = x.reshape(-1, x.shape[-1])
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
-        y = ops.linear(x2, weight.contiguous(), bias, out_dtype=torch.float32, relu=bool(relu))
+        N, K = weight.shape
+        Np = (N + 31) // 32 * 32
+        if Np != N:
+            wp = weight.new_zeros((Np, K))
+            wp[:N] = weight
+            bp = None
+            if bias is not None:
+                bp = bias.new_zeros((Np,))
+                bp[:N] = bias
+        else:
+            wp, bp = weight.contiguous(), bias
+        y = ops.linear(x2, wp, bp, out_dtype=torch.float32, relu=bool(relu))
+        if Np != N:
+            y = y[:, :N].contiguous()
         ctx.relu = bool(relu)
         ctx.x_shape = x.shape
-        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.save_for_backward(x2, wp, y if relu else None)
         ctx.has_bias = bias is not None
-        return y.view(*x.shape[:-1], weight.shape[0])
+        ctx.n_out = N
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
-        x2, weight, y = ctx.saved_tensors
-        N, K = weight.shape
+        x2, wp, y = ctx.saved_tensors
+        Np, K = wp.shape
+        N = ctx.n_out
         dy = grad_y.reshape(-1, N)
         if ctx.relu:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)               # dy where y > 0, one launch
+        if Np != N:
+            dyp = dy.new_zeros((dy.shape[0], Np))
+            dyp[:, :N] = dy
+            dy = dyp
         elif not dy.is_contiguous():
             dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(dy, weight.t().contiguous(), None, out_dtype=torch.float32).view(ctx.x_shape)
+            dx = ops.linear(dy, wp.t().contiguous(), None, out_dtype=torch.float32).view(ctx.x_shape)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy, x2)          # no dy^T / x^T copies: transposed on the way into LDS
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0)
+            dw, db = ops.linear_wgrad_bias(dy, x2, want_bias=want_b)     # no dy^T / x^T copies: transposed on the way into LDS
+            if Np != N:
+                dw = dw[:N]
+                db = None if db is None else db[:N]
+        elif want_b:
+            db = dy.sum(0)[:N]
         return dx, dw, db, None
 
 
 def linear(x, weight, bias=None, relu=False):
     """nn.functional.linear (+ ReLU) for the training path: LinearF32S where mvg_linear's shape rules hold (fp32 on the GPU,
-    in_features % 32 == 0, out_features % 32 == 0 -- every 256 / 1024 / 192-wide Linear of the decoder), torch elsewhere (the
-    2- and 3-output heads)."""
+    in_features % 32 == 0 -- every Linear of the decoder), torch elsewhere."""
     N, K = weight.shape
     if TRAIN_GEMM == "f32s" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 32 == 0 and x.numel() > 0:
-        if N % 32 == 0:
-            return LinearF32S.apply(x, weight, bias, relu)
-        # the 2- and 3-output heads (class_embed, the last pose layer): zero rows up to 32 outputs, result sliced back -- the
-        # padding is differentiable (cat), so the gradients land on the real rows
-        pad = (-N) % 32
-        wp = torch.cat([weight, weight.new_zeros(pad, K)], 0)
-        bp = None if bias is None else torch.cat([bias, bias.new_zeros(pad)], 0)
-        return LinearF32S.apply(x, wp, bp, relu)[..., :N]
+        return LinearF32S.apply(x, weight, bias, relu)
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y
 

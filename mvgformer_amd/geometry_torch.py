@@ -90,11 +90,35 @@ class UncropUndistort(torch.autograd.Function):
         return (jac * g.unsqueeze(-1)).sum(-2), None, None, None
 
 
-def proj_matrices(cam):
-    R = cam["R"].float()
-    T = cam["T"].float().reshape(*R.shape[:2], 3, 1)
-    K = torch.zeros(R.shape[:2] + (3, 3), dtype=torch.float32, device=R.device)
-    K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2] = (cam[k_].float() for k_ in ("fx", "fy", "cx", "cy"))
+class DenseDLT(torch.autograd.Function):
+    """new reference points (B, Lq, 3) of all tokens from ud (B,V,Lq,2), conf (B,V,Lq), Pm (B,V,3,4): dlt() below for the tokens of the
+    queries flagged in valid (B, NQ) uint8, zeros elsewhere -- one HIP launch forward, one backward (csrc/geom.hip: dlt_fwd_kernel /
+    dlt_bwd_kernel) instead of nonzero + index + ~20 torch launches forward and ~60 backward per decoder layer."""
+
+    @staticmethod
+    def forward(ctx, ud, conf, Pm, valid, J):
+        from . import ops
+        ud, conf = ud.detach().contiguous(), conf.detach().contiguous()
+        ctx.save_for_backward(ud, conf, Pm, valid)
+        ctx.J = J
+        return ops.dlt_forward(ud, conf, Pm, valid, J)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        ud, conf, Pm, valid = ctx.saved_tensors
+        g_ud, g_conf = ops.dlt_backward(ud, conf, Pm, valid, ctx.J, g.contiguous().float())
+        return g_ud, g_conf, None, None, None
+
+
+def proj_matrices_from_records(cams, V, B):
+    """(B, V, 3, 4) projection matrices K [R | -R T] from the packed camera records (ops.pack_cameras: image n = v * B + b; R at 0:9,
+    T at 9:12, fx fy cx cy at 12:16) -- the same fp32 products as proj_matrices, without touching the per-view meta dicts again."""
+    rec = cams.view(V, B, -1).transpose(0, 1)
+    R = rec[..., 0:9].reshape(B, V, 3, 3)
+    T = rec[..., 9:12].reshape(B, V, 3, 1)
+    K = torch.zeros((B, V, 3, 3), dtype=torch.float32, device=cams.device)
+    K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2] = rec[..., 12], rec[..., 13], rec[..., 14], rec[..., 15]
     K[..., 2, 2] = 1
     return K @ torch.cat([R, -R @ T], -1)
 

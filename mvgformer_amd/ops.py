@@ -297,12 +297,35 @@ def linear_wgrad(dy, x, splits=None):
         raise RuntimeError("mvg_linear_wgrad: fp32 row-major (rows, N) / (rows, K) operands with N, K multiples of 4 required")
     if splits is None:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min((rows + 255) // 256, (768 + tiles - 1) // tiles))
+        # ~512 workgroups (two per CU), at most 128 slices, at least 256 rows per slice (tools/bench_wgrad.py)
+        splits = max(1, min((rows + 255) // 256, 128, (512 + tiles - 1) // tiles))
     partial = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
     with _timed("linear_wgrad_%dx%dx%d" % (N, K, rows)):
       L.check(L.load().mvg_linear_wgrad_f32(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(partial), rows, N, K, splits,
                                             L.stream_ptr()), "mvg_linear_wgrad_f32")
     return partial.sum(0) if splits > 1 else partial[0]
+
+
+def linear_wgrad_bias(dy, x, want_bias=True, splits=None):
+    """(dW (N, K), db (N) | None) = (dy^T x, column sums of dy) (mvg_linear_wgrad_bias_f32): the weight-gradient launch also leaves the
+    bias gradient's per-slice partials, a second small launch adds both in slice order."""
+    rows, N = dy.shape
+    K = x.shape[1]
+    if (dy.dtype != torch.float32 or x.dtype != torch.float32 or dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != rows
+            or N % 4 or K % 4):
+        raise RuntimeError("mvg_linear_wgrad_bias: fp32 row-major (rows, N) / (rows, K) operands with N, K multiples of 4 required")
+    if splits is None:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        # ~512 workgroups (two per CU), at most 128 slices, at least 256 rows per slice (tools/bench_wgrad.py)
+        splits = max(1, min((rows + 255) // 256, 128, (512 + tiles - 1) // tiles))
+    partial = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    pdb = torch.empty((splits, N), dtype=torch.float32, device=dy.device) if want_bias else None
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    with _timed("linear_wgrad_bias_%dx%dx%d" % (N, K, rows)):
+      L.check(L.load().mvg_linear_wgrad_bias_f32(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(partial), L.ptr(pdb), L.ptr(dw),
+                                                 L.ptr(db), rows, N, K, splits, L.stream_ptr()), "mvg_linear_wgrad_bias_f32")
+    return dw, db
 
 
 def linear_ordered(a, w, bias, order, inside, masked_row, relu=False, rowmask=None, out=None):
@@ -807,6 +830,37 @@ def uncrop_undistort_jac(ref2d, cams, V, B):
     L.check(L.load().mvg_uncrop_undistort_jac(L.ptr(ref2d), L.ptr(cams), L.ptr(ud), L.ptr(jac), V, B, Lq, L.stream_ptr()),
             "mvg_uncrop_undistort_jac")
     return ud, jac
+
+
+def _dlt_args(ud, conf, Pm, valid, J):
+    B, V, Lq = conf.shape
+    if (ud.dtype != torch.float32 or conf.dtype != torch.float32 or Pm.dtype != torch.float32 or valid.dtype != torch.uint8
+            or tuple(ud.shape) != (B, V, Lq, 2) or tuple(Pm.shape) != (B, V, 3, 4) or Lq % J or valid.numel() != B * (Lq // J)):
+        raise RuntimeError("mvg_dlt: ud (B,V,Lq,2) / conf (B,V,Lq) / Pm (B,V,3,4) float32 and valid (B,NQ) uint8 expected")
+    return B, V, Lq
+
+
+def dlt_forward(ud, conf, Pm, valid, J):
+    """X (B, Lq, 3) of the dense differentiable triangulation (mvg_dlt_forward); zeros for the tokens of queries with valid == 0."""
+    B, V, Lq = _dlt_args(ud, conf, Pm, valid, J)
+    ud, conf, Pm, valid = ud.contiguous(), conf.contiguous(), Pm.contiguous(), valid.contiguous()
+    X = torch.empty((B, Lq, 3), dtype=torch.float32, device=ud.device)
+    L.check(L.load().mvg_dlt_forward(L.ptr(ud), L.ptr(conf), L.ptr(Pm), L.ptr(valid), L.ptr(X), V, B, Lq // J, J, L.stream_ptr()),
+            "mvg_dlt_forward")
+    return X
+
+
+def dlt_backward(ud, conf, Pm, valid, J, gX):
+    """(g_ud, g_conf) of dlt_forward for gX (B, Lq, 3) (mvg_dlt_backward)."""
+    B, V, Lq = _dlt_args(ud, conf, Pm, valid, J)
+    if gX.dtype != torch.float32 or tuple(gX.shape) != (B, Lq, 3):
+        raise RuntimeError("mvg_dlt_backward: gX (B, Lq, 3) float32 expected")
+    ud, conf, Pm, valid, gX = ud.contiguous(), conf.contiguous(), Pm.contiguous(), valid.contiguous(), gX.contiguous()
+    g_ud = torch.empty_like(ud)
+    g_conf = torch.empty_like(conf)
+    L.check(L.load().mvg_dlt_backward(L.ptr(ud), L.ptr(conf), L.ptr(Pm), L.ptr(valid), L.ptr(gX), L.ptr(g_ud), L.ptr(g_conf), V, B,
+                                      Lq // J, J, L.stream_ptr()), "mvg_dlt_backward")
+    return g_ud, g_conf
 
 
 def sym4_eigh(G):

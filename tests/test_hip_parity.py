@@ -1654,6 +1654,69 @@ def test_linear_wgrad_and_autograd_function_vs_fp64(rows, N, K):
             assert float((got.double() - ref.detach()).abs().max()) < 3e-6 * max(1.0, float(ref.detach().abs().max())) * (rows ** 0.5 if got is w.grad or got is b.grad else 1.0)
 
 
+@pytest.mark.parametrize("rows,N,K", [(76800, 256, 256), (15360, 1024, 256), (777, 256, 1024), (4000, 32, 256), (33, 64, 32)])
+def test_linear_wgrad_with_bias_gradient(rows, N, K):
+    """mvg_linear_wgrad_bias_f32: dW against fp64 (the bar of mvg_linear_wgrad_f32) and bit-identical run after run (the slices'
+    partials are added in slice order); db = column sums of dY against fp64."""
+    from mvgformer_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(rows + 3 * N)
+    dy = torch.randn(rows, N, generator=gen).to(DEV)
+    x = torch.randn(rows, K, generator=gen).to(DEV)
+    dw, db = ops.linear_wgrad_bias(dy, x)
+    want_w = dy.double().t() @ x.double()
+    assert float(((dw.double() - want_w).abs() / (dy.double().abs().t() @ x.double().abs())).max()) < 2e-6
+    want = dy.double().sum(0)
+    assert float((db.double() - want).abs().max()) < 2e-6 * float(dy.double().abs().sum(0).max())
+    for _ in range(5):
+        dw2, db2 = ops.linear_wgrad_bias(dy, x)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw3, none = ops.linear_wgrad_bias(dy, x, want_bias=False)
+    assert none is None and torch.equal(dw, dw3)
+
+
+@pytest.mark.parametrize("frac_valid", [1.0, 0.4, 0.0])
+def test_dense_dlt_function_matches_the_torch_form(frac_valid):
+    """geometry_torch.DenseDLT (mvg_dlt_forward / mvg_dlt_backward: one launch each way over the dense token grid) against
+    geometry_torch.dlt on the tokens of the valid queries (itself pinned to the SVD's autograd above): points and the gradients
+    w.r.t. the 2D points and confidences; zeros for the tokens of the other queries."""
+    from mvgformer_amd import geometry_torch as G
+    torch.manual_seed(9)
+    B, V, NQ, J = 2, 5, 37, 15
+    Lq = NQ * J
+    K = torch.tensor([[1400.0, 0, 960], [0, 1400.0, 540], [0, 0, 1]], dtype=torch.float64)
+    Pm = []
+    for v in range(V):
+        a = 2 * np.pi * v / V
+        R = torch.tensor([[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]], dtype=torch.float64)
+        C = torch.tensor([4000 * np.sin(a), 200.0 * v, -4000 * np.cos(a)], dtype=torch.float64)
+        Pm.append(K @ torch.cat([R, (-R @ C)[:, None]], 1))
+    Pm = torch.stack(Pm)[None].repeat(B, 1, 1, 1)
+    X = torch.randn(B, Lq, 3, dtype=torch.float64) * 500.0
+    uvw = torch.einsum("bvij,bnj->bvni", Pm, torch.cat([X, torch.ones(B, Lq, 1, dtype=torch.float64)], -1))
+    pts = (uvw[..., :2] / uvw[..., 2:3] + torch.randn(B, V, Lq, 2, dtype=torch.float64) * 2.0).float().to(DEV)
+    conf = torch.softmax(torch.randn(B, V, Lq), 1).to(DEV)
+    Pm = Pm.float().to(DEV)
+    wgt = torch.randn(B, Lq, 3, device=DEV)
+    valid = (torch.rand(B, NQ) < frac_valid).to(DEV)
+    tok = valid.view(B, NQ, 1).expand(B, NQ, J).reshape(B, Lq)
+    p1, c1 = pts.clone().requires_grad_(True), conf.clone().requires_grad_(True)
+    out = G.DenseDLT.apply(p1, c1, Pm, valid.to(torch.uint8), J)
+    (out * wgt).sum().backward()
+    assert bool((out[~tok] == 0).all()) and bool((p1.grad.transpose(1, 2)[~tok] == 0).all()) and bool((c1.grad.transpose(1, 2)[~tok] == 0).all())
+    if not bool(tok.any()):
+        return
+    # truth: the SVD form and its autograd in fp64 on the CPU, from the same fp32 inputs
+    bi, ti = tok.cpu().nonzero(as_tuple=True)
+    p2, c2 = pts.double().cpu().requires_grad_(True), conf.double().cpu().requires_grad_(True)
+    ref = G.dlt(Pm.double().cpu()[bi], p2[bi, :, ti].unsqueeze(2), c2[bi, :, ti].unsqueeze(2))[:, 0]
+    (ref * wgt.double().cpu()[bi, ti]).sum().backward()
+    assert float((out.cpu()[bi, ti] - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    for nm, a, b in (("pts", p1.grad, p2.grad), ("conf", c1.grad, c2.grad)):
+        err = float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        print("dense dlt dL/d%-5s rel err %.2e" % (nm, err))
+        assert err < 1e-6, nm      # the torch form (fp32 rows) is at 1e-4 for the confidences
+
+
 def test_fp32_chain_b_tile_sizes_agree_bit_for_bit():
     """mvg_chain_update_ffn_class_f32s picks 32-row tiles for launches that would leave CUs idle with 64-row tiles (cfg-4, a rank's
     query shard).  Both variants sum every row in the same order: identical outputs, so a sharded run (small launch) and the
