@@ -608,6 +608,204 @@ __global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __
   if (live) store_acc<float, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
 }
 
+// msda_gfused_f32_hp_kernel -- the same unit of work (one (pair, head) on 8 lanes: identical operations in identical order, bit-identical
+// rows) under the bf16 kernel's decomposition (round 4): a wavefront takes 8 NEIGHBOURING pairs of ONE head instead of the 8 heads of one
+// pair.  The 8 heads of a pair follow 8 different rays, so no two lanes groups of a gather instruction shared a 128-byte line and the
+// lines in flight (16 loads x 8 heads per wavefront) turned the 32-KB L1 over before a neighbour could reuse them: 43 % L1 hits, 29.8 M
+// L2 requests per launch against the bf16 kernel's 7.3 M (profiles/r04_rocprofv3_summary_fp32.txt).  Neighbouring pairs of one head sample
+// the same or adjacent pixels: the lane groups of one instruction coalesce, and a workgroup's footprint is one head's patch.
+template <int L>
+__global__ __launch_bounds__(256, 4) void msda_gfused_f32_hp_kernel(const float* __restrict__ value, const float* __restrict__ G,
+                                                                 const float* __restrict__ xw, const float* __restrict__ r,
+                                                                 LevelTable lv, float* __restrict__ samp,
+                                                                 const uint8_t* __restrict__ pair_mask,
+                                                                 const int* __restrict__ order, int n_pairs,
+                                                                 int Lq, int S, int B) {
+  constexpr int D = 32, P = 8, C = 256, LP = L * P, NCHK = 3 * L, NB = 4, CPL = 4, SCP = 3 * LP + 8;
+  typedef RawVec<float, CPL> RV;
+  __shared__ __attribute__((aligned(16))) float scratch[4][8][SCP];
+  // one head per workgroup, blockIdx & 7 = head = the XCD the hardware dispatches the block to: an XCD's L2 sees one head's lines;
+  // blockIdx >> 3 walks the processing order in blocks of 32 pairs, a wavefront = 8 neighbouring pairs x 8 lanes
+  const int m = blockIdx.x & 7, pb = blockIdx.x >> 3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 3, sub = lane & 7;
+  const int slot = pb * 32 + wave * 8 + g;
+  if (slot >= n_pairs) return;                         // whole 8-lane groups leave (the exchanges below stay inside a group)
+  const int pair = order ? order[slot] : slot;
+  if (pair_mask && !pair_mask[pair]) {
+    *reinterpret_cast<f32x4*>(samp + (long)pair * C + m * D + sub * CPL) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const bool live = true;
+  const int n = pair / Lq, q = pair - n * Lq, b = n % B;
+  float* sc = &scratch[wave][g][0];
+
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk, one chunk per lane.
+  // All loads of the lane's (NCHK + 7) / 8 chunks are requested before the first is used (lanes without a last chunk fetch
+  // chunk NCHK - 1 again and do not store it), the reference points once per lane: see gsamp_unit (same transformation).
+  constexpr int NK = (NCHK + 7) / 8;
+  float2 rr[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
+  f32x4 ga[NK][2], gb[NK][2], gc[NK][2], gd[NK][2], gx4[NK][2];
+  float w00[NK], w10[NK], w01[NK], w11[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int ci = min(sub + 8 * k, NCHK - 1);
+    const int t = ci / 3, part = ci - 3 * t;           // group t of the head (= level of its samples), 16 offsets | 8 logits
+    const int fg = m * L + t;
+    const int l = fg >> 3;                             // level row of the reinterpreted view (projattn.py:180-184)
+    const int col = 24 * (fg & 7) + 8 * part;
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    float refx = rr[0].x, refy = rr[0].y;
+#pragma unroll
+    for (int ll = 1; ll < L; ++ll) {
+      refx = l == ll ? rr[ll].x : refx;
+      refy = l == ll ? rr[ll].y : refy;
+    }
+    const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
+    const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+    const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;    // grid_sample, align_corners=False
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - x0f, ty = iy - y0f;
+    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+    w00[k] = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
+    w10[k] = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
+    w01[k] = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
+    w11[k] = (x1ok && y1ok) ? tx * ty : 0.f;
+    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
+    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+    const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
+    const float* p00 = gp + (long)(y0c * W + x0c) * 192;
+    const float* p10 = gp + (long)(y0c * W + x1c) * 192;
+    const float* p01 = gp + (long)(y1c * W + x0c) * 192;
+    const float* p11 = gp + (long)(y1c * W + x1c) * 192;
+    const float* xq = xw + ((long)b * Lq + q) * 192 + col;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      ga[k][hlf] = *reinterpret_cast<const f32x4*>(p00 + 4 * hlf);
+      gb[k][hlf] = *reinterpret_cast<const f32x4*>(p10 + 4 * hlf);
+      gc[k][hlf] = *reinterpret_cast<const f32x4*>(p01 + 4 * hlf);
+      gd[k][hlf] = *reinterpret_cast<const f32x4*>(p11 + 4 * hlf);
+      gx4[k][hlf] = *reinterpret_cast<const f32x4*>(xq + 4 * hlf);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int ci = sub + 8 * k;
+    const int cc = min(ci, NCHK - 1);
+    const int t = cc / 3, part = cc - 3 * t;
+    if (ci < NCHK) {
+      float* dst = sc + (part == 2 ? 8 * t : LP + 16 * t + 8 * part);
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf)
+        *reinterpret_cast<f32x4*>(dst + 4 * hlf) = w00[k] * ga[k][hlf] + w10[k] * gb[k][hlf] + w01[k] * gc[k][hlf] + w11[k] * gd[k][hlf] + gx4[k][hlf];
+    }
+  }
+  // head-private scratch rows inside one wavefront: LDS operations of a wavefront execute in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- pass 1: max and sum of the head's L*P logits (softmax denominator), redundantly on the 8 lanes of a head
+  float mx = -INFINITY;
+  {
+    f32x4 lg[LP / 4];
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i) {
+      lg[i] = *reinterpret_cast<const f32x4*>(sc + 4 * i);
+      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP / 4; ++i)
+      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
+    mx += __logf(sum);                                   // fold 1/sum into the exponent: w = exp(x - mx - log(sum))
+  }
+
+  const float* vbase = value + (long)n * S * C + m * D + sub * CPL;
+  float acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  // ---- pass 2 (round 3).  The first form computed every sample's coordinates, zero padding and softmax weight on all 8 lanes of
+  // the head (PMC: 2 425 VALU instructions per wavefront, the VALU 57 % busy -- the kernel's bound).  Now lane `sub` computes ONE of
+  // the 8 samples of a level (P = 8) and the 8 lanes exchange the results with ds_swizzle (crossbar only, no LDS memory): 4 corner
+  // weights + 3 element offsets per sample; two half batches of 4 samples = 16 gathers in flight as before.  Same operations in
+  // the same order for every sample and every accumulation: bit-identical to the first form.
+  static_assert(P == 8 && NB == 4, "one sample per lane of the head's 8");
+#define MVG_SW8(K, X) __builtin_amdgcn_ds_swizzle((X), 24 | ((K) << 5))      /* value of lane K of every group of 8 lanes */
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    const float Wf = (float)W, Hf = (float)H;
+    float refx = rr[0].x, refy = rr[0].y;
+#pragma unroll
+    for (int ll = 1; ll < L; ++ll) {
+      refx = l == ll ? rr[ll].x : refx;
+      refy = l == ll ? rr[ll].y : refy;
+    }
+    const float* lvl = vbase + (long)lv.start[l] * C;
+    int my_w[4], my_t, my_b, my_x;
+    {
+      const float lgs = sc[l * P + sub];
+      const float2 of = *reinterpret_cast<const float2*>(sc + LP + (l * P + sub) * 2);
+      const float lx = refx + of.x * lv.invW[l];                         // projattn.py:186-191
+      const float ly = refy + of.y * lv.invH[l];
+      const float h_raw = ly * Hf - 0.5f;                                // cuh:295-296
+      const float w_raw = lx * Wf - 0.5f;
+      const bool inside = (h_raw > -1.f) && (w_raw > -1.f) && (h_raw < Hf) && (w_raw < Wf);   // cuh:298
+      const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
+      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+      const int h_low = (int)hl_f, w_low = (int)wl_f;
+      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
+      const float a = inside ? __expf(lgs - mx) : 0.f;                   // softmax weight (projattn.py:184)
+      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
+      my_w[0] = __float_as_int((hl_ok && wl_ok) ? hh * hw * a : 0.f);   // cuh:66-88 zero padding
+      my_w[1] = __float_as_int((hl_ok && wh_ok) ? hh * lw * a : 0.f);
+      my_w[2] = __float_as_int((hh_ok && wl_ok) ? lh * hw * a : 0.f);
+      my_w[3] = __float_as_int((hh_ok && wh_ok) ? lh * lw * a : 0.f);
+      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
+      const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
+      my_t = (hl_c * W + wl_c) * C;
+      my_b = (hh_c * W + wl_c) * C;
+      my_x = (wh_c - wl_c) * C;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float cw[NB][4];
+      typename RV::type raw[NB][4];
+#define MVG_GS8(S_, K)                                                                                \
+      {                                                                                               \
+        const int et = MVG_SW8(K, my_t), eb = MVG_SW8(K, my_b), ex = MVG_SW8(K, my_x);                \
+        cw[S_][0] = __int_as_float(MVG_SW8(K, my_w[0]));                                              \
+        cw[S_][1] = __int_as_float(MVG_SW8(K, my_w[1]));                                              \
+        cw[S_][2] = __int_as_float(MVG_SW8(K, my_w[2]));                                              \
+        cw[S_][3] = __int_as_float(MVG_SW8(K, my_w[3]));                                              \
+        raw[S_][0] = RV::load(lvl + et);                                                              \
+        raw[S_][1] = RV::load(lvl + (et + ex));                                                       \
+        raw[S_][2] = RV::load(lvl + eb);                                                              \
+        raw[S_][3] = RV::load(lvl + (eb + ex));                                                       \
+      }
+      if (half == 0) {
+        MVG_GS8(0, 0) MVG_GS8(1, 1) MVG_GS8(2, 2) MVG_GS8(3, 3)
+      } else {
+        MVG_GS8(0, 4) MVG_GS8(1, 5) MVG_GS8(2, 6) MVG_GS8(3, 7)
+      }
+#undef MVG_GS8
+      __builtin_amdgcn_sched_barrier(0);   // all 16 loads are issued before the first blend
+#pragma unroll
+      for (int s_ = 0; s_ < NB; ++s_)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s_][k], cw[s_][k]);
+    }
+  }
+#undef MVG_SW8
+  if (live) store_acc<float, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
+}
+
 // ------------------------------------------------------------------------------------------
 // msda_gsamp_kernel -- the bf16 sampling kernel of the decoder (the kernel bench.py's roofline reports).
 //
@@ -815,6 +1013,7 @@ int g_auto_small = 1;              // tuning knob "auto_small": small launches p
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
 static int g_gsamp_occ5 = 0;      // tuning knob "gsamp_occ5": the 5-wavefronts-per-SIMD build of the 256-thread kernel
+static int g_gfused_map = 1;       // tuning knob "gfused_map": fp32 G-sampling kernel, 0 = a wavefront takes the 8 heads of one pair, 1 = 8 neighbouring pairs of one head
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
@@ -1133,6 +1332,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
+  if (!strcmp(key, "gfused_map") && (value == 0 || value == 1)) { g_gfused_map = value; return 0; }
   if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
@@ -1148,8 +1348,20 @@ int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, con
   const long pairs = (long)N_img * Lq;
   if (pairs > 0x7fffffffL / 4 || (long)N_img * S * 256 > 0x7fffffffL) return MVG_E_BADARG;     // int pixel offsets x C
   if (pairs == 0) return 0;
-  const int grid = (int)((pairs + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
+  if (g_gfused_map == 1) {
+    const int grid_hp = 8 * (int)((pairs + 31) / 32);
+    switch (L) {
+      case 1: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<1>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+      case 2: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<2>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+      case 3: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<3>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+      case 4: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<4>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+      default: return MVG_E_BADARG;
+    }
+    MVG_LAUNCH_CHECK();
+    return 0;
+  }
+  const int grid = (int)((pairs + 3) / 4);
   switch (L) {
     case 1: hipLaunchKernelGGL((msda_gfused_f32_kernel<1>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
     case 2: hipLaunchKernelGGL((msda_gfused_f32_kernel<2>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
