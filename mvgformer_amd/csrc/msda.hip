@@ -112,6 +112,80 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   }
 }
 
+// The same units of work (one (n, q, m) on D / 4 lanes, identical operations in identical order: bit-identical outputs) with a
+// workgroup on ONE head: its 256 lanes are 256 / (D / 4) consecutive queries of head m = block % M (round 4).  In the mapping above a
+// wavefront is one query's M heads -- M different sampling patterns, M different lines per gather instruction, nothing for the 32-KB
+// L1 to reuse; consecutive queries of one head (the joints of a person, neighbouring persons) sample the same or adjacent pixels.
+// With M = 8 a head's blocks all land on one XCD (block % 8), so each L2 serves one head's channels.  Needs 256 % (D / 4) == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_hp_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+    const float* __restrict__ loc, const float* __restrict__ wgt, T* __restrict__ out,
+    int N, int S, int M, int D, int L, int Lq, int P, int n_qblocks) {
+  const int dv_per = D / 4, qpb = 256 / dv_per;
+  const long row_stride = (long)M * D;
+  const long n_blocks = (long)N * n_qblocks * M;
+  const int dv = threadIdx.x % dv_per, qs = threadIdx.x / dv_per;
+  for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int m = (int)(blk % M);
+    const long t = blk / M;
+    const int q = (int)(t % n_qblocks) * qpb + qs;
+    const int n = (int)(t / n_qblocks);
+    if (q >= Lq) continue;
+    const long qm = ((long)n * Lq + q) * M + m;
+    const float* locp = loc + qm * L * P * 2;
+    const float* wp = wgt + qm * L * P;
+    const T* vbase = value + (long)n * S * row_stride + (long)m * D + dv * 4;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    // batches of NB samples: coordinates, zero padding and weights of all NB first, their 4 * NB corner loads issued back to back,
+    // then the blends in bilinear4's order (as a plain loop the compiler keeps 4-6 loads in flight; the kernel is latency-bound)
+    constexpr int NB = 4;
+    const int LP = L * P;
+    for (int s0 = 0; s0 < LP; s0 += NB) {
+      f32x4 raw[NB][4];
+      float cw[NB][4], sc[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int sidx = min(s0 + k, LP - 1);
+        const int l = sidx / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const T* lvl = vbase + (long)starts[l] * row_stride;
+        const float2 lxy = *reinterpret_cast<const float2*>(locp + sidx * 2);
+        const float aw = wp[sidx];
+        float h_im = lxy.y * (float)H - 0.5f;   // cuh:295
+        float w_im = lxy.x * (float)W - 0.5f;   // cuh:296
+        const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W) && (s0 + k < LP);
+        h_im = index_safe(h_im, (float)H);
+        w_im = index_safe(w_im, (float)W);
+        const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+        const int h_low = (int)hl_f, w_low = (int)wl_f;
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hl_f, lw = w_im - wl_f;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        sc[k] = inside ? aw : 0.f;
+        const bool hl_ok = h_low >= 0, hh_ok = h_high <= H - 1, wl_ok = w_low >= 0, wh_ok = w_high <= W - 1;
+        cw[k][0] = (hl_ok && wl_ok) ? hh * hw : 0.f;
+        cw[k][1] = (hl_ok && wh_ok) ? hh * lw : 0.f;
+        cw[k][2] = (hh_ok && wl_ok) ? lh * hw : 0.f;
+        cw[k][3] = (hh_ok && wh_ok) ? lh * lw : 0.f;
+        const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_high, 0), H - 1);
+        const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_high, 0), W - 1);
+        raw[k][0] = Vec4<T>::load(lvl + ((long)hl_c * W + wl_c) * row_stride);
+        raw[k][1] = Vec4<T>::load(lvl + ((long)hl_c * W + wh_c) * row_stride);
+        raw[k][2] = Vec4<T>::load(lvl + ((long)hh_c * W + wl_c) * row_stride);
+        raw[k][3] = Vec4<T>::load(lvl + ((long)hh_c * W + wh_c) * row_stride);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const f32x4 val = cw[k][0] * raw[k][0] + cw[k][1] * raw[k][1] + cw[k][2] * raw[k][2] + cw[k][3] * raw[k][3];
+        acc4 += val * sc[k];
+      }
+    }
+    Vec4<T>::store(out + qm * D + dv * 4, acc4);
+  }
+}
+
 // fp64 drop-in (the `double` case of AT_DISPATCH_FLOATING_TYPES, deform_cuda.cu:75: gradcheck-style calls): one thread
 // per (n, q, m, channel), everything in double.  No fast path -- nothing on the decoder's inference path is fp64.
 __global__ __launch_bounds__(256) void msda_fwd_f64_kernel(
@@ -212,6 +286,7 @@ __global__ __launch_bounds__(256) void msda_bwd_f64_kernel(
   }
 }
 
+static int g_fwd_map = 1;          // tuning knob "fwd_map": mvg_msda_forward, 0 = a wavefront takes the M heads of a query, 1 = one head per workgroup
 template <typename T>
 static int launch_msda_fwd(const T* value, const int64_t* shapes, const int64_t* starts, const float* loc,
                            const float* wgt, T* out, int N, int S, int M, int D, int L, int Lq, int P,
@@ -223,7 +298,13 @@ static int launch_msda_fwd(const T* value, const int64_t* shapes, const int64_t*
   const int block = 256;
   long grid = (total + block - 1) / block;
   if (grid > (1L << 22)) grid = 1L << 22;
-  if (vec)
+  if (vec && g_fwd_map == 1 && 256 % (D / 4) == 0) {
+    const int qpb = 256 / (D / 4), n_qblocks = (Lq + qpb - 1) / qpb;
+    long blocks = (long)N * n_qblocks * M;
+    if (blocks > (1L << 22)) blocks = (1L << 22) / M * M;        // grid-stride, a whole number of heads per stride
+    hipLaunchKernelGGL((msda_fwd_hp_kernel<T>), dim3((unsigned)blocks), dim3(block), 0, st, value, shapes, starts, loc, wgt, out, N, S,
+                       M, D, L, Lq, P, n_qblocks);
+  } else if (vec)
     hipLaunchKernelGGL((msda_fwd_kernel<T, 4>), dim3((unsigned)grid), dim3(block), 0, st, value, shapes, starts, loc,
                        wgt, out, N, S, M, D, L, Lq, P);
   else
@@ -1332,6 +1413,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
+  if (!strcmp(key, "fwd_map") && (value == 0 || value == 1)) { g_fwd_map = value; return 0; }
   if (!strcmp(key, "gfused_map") && (value == 0 || value == 1)) { g_gfused_map = value; return 0; }
   if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }

@@ -1627,6 +1627,57 @@ def test_every_kernel_variant_behind_a_tuning_knob(key, value, exact):
     assert lib.mvg_set_tuning(b"no_such_knob", 1) != 0 and lib.mvg_set_tuning(key.encode(), -7) != 0
 
 
+@pytest.mark.parametrize("N,Lq,M,D,L,P,dt", [(2, 77, 8, 32, 3, 8, torch.float32), (1, 1000, 8, 32, 3, 8, torch.bfloat16), (3, 33, 4, 16, 2, 3, torch.float32),
+                                             (1, 5, 2, 64, 1, 5, torch.float32), (2, 50, 3, 24, 2, 4, torch.float32)])
+def test_forward_operator_mappings_agree_bit_for_bit(N, Lq, M, D, L, P, dt):
+    """mvg_msda_forward (Deformable.deform_forward's drop-in): fwd_map = 1 (default: one head per workgroup, loads in batches of 4
+    samples; needs 256 % (D / 4) == 0, other D fall back) against fwd_map = 0 (a wavefront takes a query's heads): identical outputs,
+    with locations that leave the maps, L * P not a multiple of the batch and query counts that do not fill the last workgroup."""
+    from mvgformer_amd import _lib
+    from mvgformer_amd import deformable as DF
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(N * 1000 + Lq)
+    shapes = torch.tensor([[20, 31], [11, 16], [5, 8]][:L], dtype=torch.long)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = torch.randn(N, S, M, D, generator=gen).to(DEV).to(dt)
+    loc = (torch.rand(N, Lq, M, L, P, 2, generator=gen) * 1.3 - 0.15).to(DEV)
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=gen), -1).view(N, Lq, M, L, P).to(DEV)
+    out = {}
+    try:
+        for mp in (1, 0):
+            assert lib.mvg_set_tuning(b"fwd_map", mp) == 0
+            out[mp] = DF.deform_forward(value, shapes.to(DEV), starts.to(DEV), loc, attn, 64).clone()
+    finally:
+        assert lib.mvg_set_tuning(b"fwd_map", 1) == 0
+    assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("cfg,kw", [("cfg2", dict(NQ=160, layers=2)), ("cfg4", dict(layers=2)), ("cfg2", dict(NQ=3, layers=1))],
+                         ids=["cfg2_160q", "cfg4", "cfg2_3q"])
+def test_fp32_sampler_mappings_agree_bit_for_bit(cfg, kw):
+    """mvg_msda_gfused_f32 has two decompositions of the same (pair, head) units: gfused_map = 1 (default: a wavefront takes 8
+    neighbouring pairs of one head, one head per workgroup) and 0 (the 8 heads of one pair).  Same operations in the same order per
+    unit: the fp32 decoder outputs are identical, also for a launch whose last wavefronts are partly out of range (3 queries)."""
+    from mvgformer_amd import _lib
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    lib = _lib.load()
+    case = build_case(cfg, seed=5, **kw)
+    dec = build_decoder_for_case(case, DEV, dtype=torch.float32)
+    gc = case_to_device(case, DEV)
+    run = lambda: [t.float().clone() for t in dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes,
+                                                  gc.level_start_index, None, query_pos=gc.query_pos, threshold=0.1)[:4]]
+    with torch.no_grad():
+        ref = run()
+        assert lib.mvg_set_tuning(b"gfused_map", 0) == 0
+        try:
+            got = run()
+        finally:
+            assert lib.mvg_set_tuning(b"gfused_map", 1) == 0
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("rows,N,K", [(76800, 256, 256), (1000, 192, 256), (15360, 1024, 256), (777, 256, 1024), (33, 64, 32)])
 def test_linear_wgrad_and_autograd_function_vs_fp64(rows, N, K):
     """mvg_linear_wgrad_f32 (dW = dY^T X from row-major operands, split over row slices) and the LinearF32S autograd Function
