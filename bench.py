@@ -92,7 +92,7 @@ def measure_traffic_live(argv_tail, kernel_prefix):
 
 
 SAMPLER_KERNELS = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel",
-                   "msda_gfused_f32": "msda_gfused_f32_kernel", "msda_fused": "msda_fused_kernel"}
+                   "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
 
 # the workloads measured next to the headline in the driver's one command: (name, config, dtype, inside, batch)
 SECONDARY = (("cfg2_fp32", "cfg2", "fp32", "grid", 1), ("cfg4_fp32", "cfg4", "fp32", "grid", 1),
@@ -592,7 +592,7 @@ def main():
     # the generic fused sampling kernel (fp32); its algorithmic bytes are SURVEY 8(d)'s sampling figure in all three cases
     # (the chain-A half of the fused kernel adds no bytes to the numerator)
     kernel_names = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel",
-                    "msda_gfused_f32": "msda_gfused_f32_kernel", "msda_fused": "msda_fused_kernel"}
+                    "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
     samp_key = next((k for k in kernel_names if k in prof), "msda_fused")
     samp_name = kernel_names[samp_key]
     if world == 1 and args.traffic != "off" and args.inflight == 1:

@@ -695,8 +695,11 @@ __global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __
 // lines in flight (16 loads x 8 heads per wavefront) turned the 32-KB L1 over before a neighbour could reuse them: 43 % L1 hits, 29.8 M
 // L2 requests per launch against the bf16 kernel's 7.3 M (profiles/r04_rocprofv3_summary_fp32.txt).  Neighbouring pairs of one head sample
 // the same or adjacent pixels: the lane groups of one instruction coalesce, and a workgroup's footprint is one head's patch.
+#ifndef MVG_GFUSED_HP_OCC
+#define MVG_GFUSED_HP_OCC 4
+#endif
 template <int L>
-__global__ __launch_bounds__(256, 4) void msda_gfused_f32_hp_kernel(const float* __restrict__ value, const float* __restrict__ G,
+__global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_kernel(const float* __restrict__ value, const float* __restrict__ G,
                                                                  const float* __restrict__ xw, const float* __restrict__ r,
                                                                  LevelTable lv, float* __restrict__ samp,
                                                                  const uint8_t* __restrict__ pair_mask,
