@@ -36,6 +36,9 @@ def _is_power_of_2(n):
     return (n & (n - 1) == 0) and n != 0
 
 
+# fp32 value / G products of the inline schedule: one pair per (device, stream), shared by every layer (project_pyramid)
+_SHARED_F32 = {}
+
 class WeightCache:
     """Contiguous copies of module parameters in the compute dtype, rebuilt when a parameter
     is modified in place (``_version``) or replaced."""
@@ -200,9 +203,22 @@ class ProjAttn(nn.Module):
         if dt == torch.float32:      # fp32 G-sampling form: plain (rows, 256) / (rows, 192) fp32 products, kept across calls
             Wv, bv = self.weights(dt)[:2]
             Wq, _ = self._fast_query_weights(dt)
-            if self._vp is None or self._vp.dtype != dt or tuple(self._vp.shape) != (n_img, S, Cc) or self._vp.device != feat.device:
-                self._vp = torch.empty((n_img, S, Cc), dtype=dt, device=feat.device)
-                self._G = torch.empty((n_img * S, 192), dtype=dt, device=feat.device)
+            if record_event:
+                # side-stream schedule: every layer's products exist at the same time -> one pair of buffers per layer
+                if (self._vp is None or self._vp.dtype != dt or tuple(self._vp.shape) != (n_img, S, Cc) or self._vp.device != feat.device
+                        or any(self._vp is pair[0] for pair in _SHARED_F32.values())):
+                    self._vp = torch.empty((n_img, S, Cc), dtype=dt, device=feat.device)
+                    self._G = torch.empty((n_img * S, 192), dtype=dt, device=feat.device)
+            else:
+                # inline (overlap off, or under autograd): a layer's products are dead once its sampler ran, the next layer's are
+                # written behind it on the same stream -> ONE pair for all layers of the decoders on this stream (0.36 GB at cfg-2
+                # instead of 0.36 GB per layer held for the model's lifetime)
+                slot = (feat.device, torch.cuda.current_stream(feat.device).cuda_stream)      # streams do not share (decoders in flight)
+                cur = _SHARED_F32.get(slot)
+                if cur is None or tuple(cur[0].shape) != (n_img, S, Cc):
+                    cur = _SHARED_F32[slot] = (torch.empty((n_img, S, Cc), dtype=dt, device=feat.device),
+                                               torch.empty((n_img * S, 192), dtype=dt, device=feat.device))
+                self._vp, self._G = cur
             if self.f32_fused and Cc == 256 and feat.is_contiguous():
                 Wv_pl, Wg_pl = self.pyramid_planes_f32s()
                 ops.pyramid_f32s(feat, Wv_pl, bv, Wg_pl, 192, value=self._vp, G=self._G)        # projattn.py:169 + 180-181
