@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
                                                                  const uint8_t* __restrict__ pair_mask,
                                                                  const int* __restrict__ order, int n_pairs,
                                                                  int Lq, int S, int B) {
-  constexpr int D = 32, P = 8, C = 256, LP = L * P, NCHK = 3 * L, NB = 4, CPL = 4, SCP = 3 * LP + 8;
+  constexpr int D = 32, P = 8, C = 256, LP = L * P, NB = 4, CPL = 4, SCP = 3 * LP + 8;
   typedef RawVec<float, CPL> RV;
   __shared__ __attribute__((aligned(16))) float scratch[4][8][SCP];
   // one head per workgroup, blockIdx & 7 = head = the XCD the hardware dispatches the block to: an XCD's L2 sees one head's lines;
@@ -724,22 +724,24 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
   float* sc = &scratch[wave][g][0];
 
-  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk, one chunk per lane.
-  // All loads of the lane's (NCHK + 7) / 8 chunks are requested before the first is used (lanes without a last chunk fetch
-  // chunk NCHK - 1 again and do not store it), the reference points once per lane: see gsamp_unit (same transformation).
-  constexpr int NK = (NCHK + 7) / 8;
+  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw.  The head's 3 * L chunks of 8 columns are 6 * L pieces
+  // of 16 bytes; lane `sub` takes pieces sub, sub + 8, ...: the 8 lanes of a gather instruction read 128 CONTIGUOUS bytes of one corner's
+  // G row (two 64-byte accesses) where the chunk-per-lane form of msda_gfused_f32_kernel read 8 x 16 bytes at a 32-byte stride, twice
+  // (four accesses each), plus a second round in which only lane 0 had a chunk.  Per element the same products in the same order.
+  constexpr int NPC = 6 * L, NK = (NPC + 7) / 8;
   float2 rr[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
-  f32x4 ga[NK][2], gb[NK][2], gc[NK][2], gd[NK][2], gx4[NK][2];
+  f32x4 ga[NK], gb[NK], gc[NK], gd[NK], gx4[NK];
   float w00[NK], w10[NK], w01[NK], w11[NK];
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const int ci = min(sub + 8 * k, NCHK - 1);
+    const int pj = min(sub + 8 * k, NPC - 1);          // piece: chunk pj >> 1, half pj & 1
+    const int ci = pj >> 1;
     const int t = ci / 3, part = ci - 3 * t;           // group t of the head (= level of its samples), 16 offsets | 8 logits
     const int fg = m * L + t;
     const int l = fg >> 3;                             // level row of the reinterpreted view (projattn.py:180-184)
-    const int col = 24 * (fg & 7) + 8 * part;
+    const int col = 24 * (fg & 7) + 8 * part + 4 * (pj & 1);
     const int H = lv.H[l], W = lv.W[l];
     const float Wf = (float)W, Hf = (float)H;
     float refx = rr[0].x, refy = rr[0].y;
@@ -762,31 +764,21 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
     const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
     const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
     const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
-    const float* p00 = gp + (long)(y0c * W + x0c) * 192;
-    const float* p10 = gp + (long)(y0c * W + x1c) * 192;
-    const float* p01 = gp + (long)(y1c * W + x0c) * 192;
-    const float* p11 = gp + (long)(y1c * W + x1c) * 192;
-    const float* xq = xw + ((long)b * Lq + q) * 192 + col;
-#pragma unroll
-    for (int hlf = 0; hlf < 2; ++hlf) {
-      ga[k][hlf] = *reinterpret_cast<const f32x4*>(p00 + 4 * hlf);
-      gb[k][hlf] = *reinterpret_cast<const f32x4*>(p10 + 4 * hlf);
-      gc[k][hlf] = *reinterpret_cast<const f32x4*>(p01 + 4 * hlf);
-      gd[k][hlf] = *reinterpret_cast<const f32x4*>(p11 + 4 * hlf);
-      gx4[k][hlf] = *reinterpret_cast<const f32x4*>(xq + 4 * hlf);
-    }
+    ga[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y0c * W + x0c) * 192);
+    gb[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y0c * W + x1c) * 192);
+    gc[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y1c * W + x0c) * 192);
+    gd[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y1c * W + x1c) * 192);
+    gx4[k] = *reinterpret_cast<const f32x4*>(xw + ((long)b * Lq + q) * 192 + col);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const int ci = sub + 8 * k;
-    const int cc = min(ci, NCHK - 1);
-    const int t = cc / 3, part = cc - 3 * t;
-    if (ci < NCHK) {
-      float* dst = sc + (part == 2 ? 8 * t : LP + 16 * t + 8 * part);
-#pragma unroll
-      for (int hlf = 0; hlf < 2; ++hlf)
-        *reinterpret_cast<f32x4*>(dst + 4 * hlf) = w00[k] * ga[k][hlf] + w10[k] * gb[k][hlf] + w01[k] * gc[k][hlf] + w11[k] * gd[k][hlf] + gx4[k][hlf];
+    const int pj = sub + 8 * k;
+    const int ci = min(pj, NPC - 1) >> 1;
+    const int t = ci / 3, part = ci - 3 * t;
+    if (pj < NPC) {
+      float* dst = sc + (part == 2 ? 8 * t : LP + 16 * t + 8 * part) + 4 * (pj & 1);
+      *reinterpret_cast<f32x4*>(dst) = w00[k] * ga[k] + w10[k] * gb[k] + w01[k] * gc[k] + w11[k] * gd[k] + gx4[k];
     }
   }
   // head-private scratch rows inside one wavefront: LDS operations of a wavefront execute in order
