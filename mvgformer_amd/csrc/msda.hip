@@ -704,13 +704,22 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
                                                                  LevelTable lv, float* __restrict__ samp,
                                                                  const uint8_t* __restrict__ pair_mask,
                                                                  const int* __restrict__ order, int n_pairs,
-                                                                 int Lq, int S, int B) {
+                                                                 int Lq, int S, int B, int map_ch) {
   constexpr int D = 32, P = 8, C = 256, LP = L * P, NB = 4, CPL = 4, SCP = 3 * LP + 8;
   typedef RawVec<float, CPL> RV;
   __shared__ __attribute__((aligned(16))) float scratch[4][8][SCP];
   // one head per workgroup, blockIdx & 7 = head = the XCD the hardware dispatches the block to: an XCD's L2 sees one head's lines;
   // blockIdx >> 3 walks the processing order in blocks of 32 pairs, a wavefront = 8 neighbouring pairs x 8 lanes
-  const int m = blockIdx.x & 7, pb = blockIdx.x >> 3;
+  int m, pb;
+  if (map_ch == 0) {
+    m = blockIdx.x & 7;
+    pb = blockIdx.x >> 3;
+  } else {                     // chunks of map_ch pair blocks per XCD, their 8 heads back to back (msda_gsamp_kernel's mapping)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    m = j & 7;
+    const int t = j >> 3;
+    pb = ((t / map_ch) * 8 + xcd) * map_ch + t % map_ch;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 3, sub = lane & 7;
   const int slot = pb * 32 + wave * 8 + g;
@@ -1090,6 +1099,7 @@ static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD 
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
 static int g_gsamp_occ5 = 0;      // tuning knob "gsamp_occ5": the 5-wavefronts-per-SIMD build of the 256-thread kernel
 static int g_gfused_map = 1;       // tuning knob "gfused_map": fp32 G-sampling kernel, 0 = a wavefront takes the 8 heads of one pair, 1 = 8 neighbouring pairs of one head
+static int g_gfused_chunk = 4;     // tuning knob "gfused_chunk": hp kernel, 0 = one head per XCD (270 us at cfg-2), n > 0 = chunks of n pair blocks per XCD with their 8 heads back to back (1..4: 252 us, 16: 263)
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
@@ -1409,6 +1419,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
   if (!strcmp(key, "fwd_map") && (value == 0 || value == 1)) { g_fwd_map = value; return 0; }
+  if (!strcmp(key, "gfused_chunk") && value >= 0 && value <= 4096) { g_gfused_chunk = value; return 0; }
   if (!strcmp(key, "gfused_map") && (value == 0 || value == 1)) { g_gfused_map = value; return 0; }
   if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
@@ -1427,12 +1438,15 @@ int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, con
   if (pairs == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (g_gfused_map == 1) {
-    const int grid_hp = 8 * (int)((pairs + 31) / 32);
+    int npb = (int)((pairs + 31) / 32);
+    const int mc = g_gfused_chunk;
+    if (mc > 0) npb = (npb + 8 * mc - 1) / (8 * mc) * (8 * mc);
+    const int grid_hp = 8 * npb;
     switch (L) {
-      case 1: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<1>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-      case 2: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<2>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-      case 3: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<3>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-      case 4: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<4>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
+      case 1: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<1>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B, mc); break;
+      case 2: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<2>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B, mc); break;
+      case 3: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<3>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B, mc); break;
+      case 4: hipLaunchKernelGGL((msda_gfused_f32_hp_kernel<4>), dim3(grid_hp), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B, mc); break;
       default: return MVG_E_BADARG;
     }
     MVG_LAUNCH_CHECK();

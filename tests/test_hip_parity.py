@@ -1657,8 +1657,8 @@ def test_forward_operator_mappings_agree_bit_for_bit(N, Lq, M, D, L, P, dt):
                          ids=["cfg2_160q", "cfg4", "cfg2_3q"])
 def test_fp32_sampler_mappings_agree_bit_for_bit(cfg, kw):
     """mvg_msda_gfused_f32 has two decompositions of the same (pair, head) units: gfused_map = 1 (default: a wavefront takes 8
-    neighbouring pairs of one head, one head per workgroup) and 0 (the 8 heads of one pair).  Same operations in the same order per
-    unit: the fp32 decoder outputs are identical, also for a launch whose last wavefronts are partly out of range (3 queries)."""
+    neighbouring pairs of one head, one head per workgroup; gfused_chunk = which pair blocks an XCD takes) and 0 (the 8 heads of one
+    pair).  Same operations in the same order per unit: the fp32 decoder outputs are identical, also for a launch whose last wavefronts are partly out of range (3 queries)."""
     from mvgformer_amd import _lib
     from mvgformer_amd.factory import build_decoder_for_case, case_to_device
     lib = _lib.load()
@@ -1669,13 +1669,14 @@ def test_fp32_sampler_mappings_agree_bit_for_bit(cfg, kw):
                                                   gc.level_start_index, None, query_pos=gc.query_pos, threshold=0.1)[:4]]
     with torch.no_grad():
         ref = run()
-        assert lib.mvg_set_tuning(b"gfused_map", 0) == 0
-        try:
-            got = run()
-        finally:
-            assert lib.mvg_set_tuning(b"gfused_map", 1) == 0
-    for a, b in zip(ref, got):
-        assert torch.equal(a, b)
+        for key, value, default in ((b"gfused_map", 0, 1), (b"gfused_chunk", 0, 4), (b"gfused_chunk", 1, 4), (b"gfused_chunk", 16, 4)):
+            assert lib.mvg_set_tuning(key, value) == 0
+            try:
+                got = run()
+            finally:
+                assert lib.mvg_set_tuning(key, default) == 0
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), (key, value)
 
 
 @pytest.mark.parametrize("rows,N,K", [(76800, 256, 256), (1000, 192, 256), (15360, 1024, 256), (777, 256, 1024), (33, 64, 32)])
