@@ -306,6 +306,13 @@ int mvg_msda_gsamp_chain(const void* vh, const void* G, const float* xw, const f
  * a multiple of 256 with zero rows (mvgformer_amd.ops.split_swizzle_weight).  A non-finite or > 3.39e38 input value makes its
  * output row NaN (as in mvg_linear's split form). */
 
+/* mvg_pyramid_f32s on two-part fp16 operands: every product as three fp16 MFMAs (l*h + h*l + h*h, fp32 accumulate) instead of six bf16
+ * ones.  W?_planes: the weight times 2^w?_scale as two fp16 planes (h, l), each in mvg_swizzle order, N padded to 256
+ * (ops.split_swizzle_weight_h2); activation rows are scaled by the kernel (a power of two per row from the row's maximum).  Same
+ * outputs as mvg_pyramid_f32s to the accuracy either form has against fp64 (the fp32 accumulation's, ~3e-7 of sum|a||w|). */
+int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv_scale, const float* bv, const void* Wg_planes, int wg_scale,
+                     float* value, float* G, int64_t rows, int n_g, void* stream);
+
 /* value = feat @ Wv^T + bv  (rows, 256)  and  G = feat @ Wg^T  (rows, n_g)  in one pass over the packed pyramid feat (rows, 256):
  * the value projection of projattn.py:169 and the pyramid side of the offsets / logits Linear (projattn.py:180-181 through
  * Linear(bilinear(feat) + x) = bilinear(feat W^T) + (x W^T + b), see mvg_msda_gfused_f32).  n_g: multiple of 32, <= 256. */

@@ -249,6 +249,169 @@ __global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// pyramid products on TWO-part fp16 operands ("f32h", round 4): x 2^s = h + l with h = fp16(x 2^s), l = fp16(x 2^s - h) -- 22 bits
+// of each operand -- and a * w as THREE fp16 MFMAs  l*h + h*l + h*h  with fp32 accumulation, half the matrix work of the six-product
+// bf16 form.  fp16 has 5 exponent bits, so every operand carries a power-of-two scale (exact to apply and to remove): an activation
+// row is scaled so that its largest entry lies in [2^13, 2^14) (s_row from the exponent of the row maximum, found by the wavefront that
+// holds the row), a weight tensor once on the host (ops.split_swizzle_weight_h2).  What is dropped: l*l (2^-22 |a w|) and the parts'
+// rounding (2^-23 of an entry, or 2^-25 of the row / tensor maximum for entries in fp16's subnormal range) -- measured against fp64 on
+// operands with exact accumulation 4e-8 of sum|a||w| (six-product bf16 form: 3e-9), an order of magnitude under the 3e-7 the fp32
+// accumulation itself leaves in either form.  A row's scale depends on that row only: results are position-independent as before.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+constexpr int HPLANE = RM * PLP;             // bytes per fp16 activation plane (same pitch as the bf16 planes)
+
+template <int KSTEPS, int RING, int MT = 2>
+__device__ __forceinline__ void stage_swapped_h2(const char* __restrict__ act, const bf16_t* __restrict__ wp, long wplane,
+                                                 f32x16 (&acc)[MT], int rot, int lane, int row0 = 0) {
+  const int rl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+  f32x4 ring[RING][2];
+#pragma unroll
+  for (int p = 0; p < RING; ++p) {
+    const int kq = (p + rot) & (KSTEPS - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) ring[p][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
+  }
+  const char* arow = act + (row0 + rl) * PLP + 16 * h;
+  f32x4 a_nxt[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * HPLANE + mt * 32 * PLP + (rot & (KSTEPS - 1)) * 32);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    half8 a[MT][2], b[2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a[mt][s] = __builtin_bit_cast(half8, a_nxt[mt][s]);
+    if (ks + 1 < KSTEPS) {
+      const int kn = (ks + 1 + rot) & (KSTEPS - 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * HPLANE + mt * 32 * PLP + kn * 32);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b[s] = __builtin_bit_cast(half8, ring[ks % RING][s]);
+    if (ks + RING < KSTEPS) {
+      const int kq = (ks + RING + rot) & (KSTEPS - 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ring[ks % RING][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
+    }
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};        // smallest terms first
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][TA[t]], b[TB[t]], acc[mt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// acc[mt][4 g + t] = 2^(s_row + s_w) out[row 32 mt + 8 g + 4 h + t][column rl of the block]; rs = the tile's s_row table in LDS
+template <int MT = 2>
+__device__ __forceinline__ void store_swapped_h2(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[MT],
+                                                 float bias, const int* __restrict__ rs, int sw, int lane, int row0 = 0) {
+  const int h = lane >> 5;
+  float* dst = out + (r0 + row0 + 4 * h) * ld + col;
+  const bool whole = r0 + RM <= rows;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int4 sr = *reinterpret_cast<const int4*>(rs + row0 + 32 * mt + 8 * g + 4 * h);
+      const int se[4] = {sr.x, sr.y, sr.z, sr.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v = __builtin_ldexpf(acc[mt][4 * g + t], -(se[t] + sw)) + bias;
+        if (whole || r0 + row0 + 4 * h + 32 * mt + 8 * g + t < rows) dst[(long)(32 * mt + 8 * g + t) * ld] = v;
+      }
+    }
+}
+
+__global__ __launch_bounds__(NT) void pyramid_f32h_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv, int swv,
+                                                          const float* __restrict__ bv, const bf16_t* __restrict__ Wg, int swg,
+                                                          float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;                                             // 2 fp16 planes x RM rows
+  int* rs = reinterpret_cast<int*>(smem + 2 * HPLANE);          // s_row of the tile's rows
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long ntiles = (rows + RM - 1) / RM;
+  const int rot = (w * 3) & 15;
+  const bf16_t* wpv = frag_ptr(Wv, 0, w, 16, lane);
+  const bf16_t* wpg = frag_ptr(Wg, 0, w, 16, lane);
+  const bf16_t* wpg2 = frag_ptr(Wg, 0, w < 4 ? w : 4 + ((w - 4) >> 1), 16, lane);
+  const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
+  const bool has_g = 32 * w < ng;
+  f32x4 x[8];
+  long tile = blockIdx.x;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * NT + tid;
+      x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
+    }
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * RM;
+    asm volatile("" : "+v"(wpv), "+v"(wpg), "+v"(wpg2));
+    __syncthreads();                               // the previous tile's stages have read the planes and the scale table
+    // chunk i of this thread is 4 columns of row 8 i + w: a wavefront holds one whole row per chunk -> its maximum by a butterfly
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float m = fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fmaxf(fabsf(x[i][2]), fabsf(x[i][3])));
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+      // s_row: the row maximum lands in [2^13, 2^14); rows of zeros / subnormals: capped (their scaled entries stay tiny, which is exact)
+      const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+      const int sr = min(13 - e, 100);
+      const int row = 8 * i + w, col = lane * 4;
+      float xs[4], rr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(x[i][t], sr);
+      const half2_t h0 = {(_Float16)xs[0], (_Float16)xs[1]}, h1 = {(_Float16)xs[2], (_Float16)xs[3]};
+      rr[0] = xs[0] - (float)h0[0]; rr[1] = xs[1] - (float)h0[1]; rr[2] = xs[2] - (float)h1[0]; rr[3] = xs[3] - (float)h1[1];
+      const half2_t l0 = {(_Float16)rr[0], (_Float16)rr[1]}, l1 = {(_Float16)rr[2], (_Float16)rr[3]};
+      *reinterpret_cast<uint2*>(act + row * PLP + col * 2) = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+      *reinterpret_cast<uint2*>(act + HPLANE + row * PLP + col * 2) = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+      if (lane == 0) rs[row] = sr;
+    }
+    __syncthreads();
+    const long nxt = tile + gridDim.x;
+    f32x16 acc[2];
+    stage_swapped_h2<16, 4>(act, wpv, 65536, acc, rot, lane);
+    if (nxt < ntiles) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid;
+        x[i] = *reinterpret_cast<const f32x4*>(feat + min(nxt * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
+      }
+    }
+    store_swapped_h2(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, rs, swv, lane);
+    if (ng == 192) {                               // balanced G stage, as in pyramid_f32s_kernel
+      if (w < 4) {
+        stage_swapped_h2<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+        store_swapped_h2(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, rs, swg, lane);
+      } else {
+        const int cbg = 4 + ((w - 4) >> 1), mtg = (w - 4) & 1;
+        f32x16 a1[1];
+        stage_swapped_h2<16, 4, 1>(act, wpg2, 65536, a1, (cbg * 3 + 7) & 15, lane, 32 * mtg);
+        store_swapped_h2<1>(G, ng, r0, rows, 32 * cbg + (lane & 31), a1, 0.f, rs, swg, lane, 32 * mtg);
+      }
+    } else if (has_g) {
+      stage_swapped_h2<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+      store_swapped_h2(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, rs, swg, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // pyramid products, weight-stationary.  The tiled kernel above streams 672 KB of weight planes per 64-row tile through the
 // CU's vector-memory path -- 672 one-KB fragment loads per tile next to 24.6 k cycles of MFMA: the path is as busy as the
 // matrix pipe, and every queueing delay stalls it (s_memtime: 45 k cycles per tile).  Here a workgroup keeps ONE of the two
@@ -1073,6 +1236,25 @@ int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two w
                           // persistent 64-row workgroup per CU, 31 = the 32-row kernel with a 2-deep fragment ring
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
+
+extern "C" int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv_scale, const float* bv, const void* Wg_planes,
+                                int wg_scale, float* value, float* G, int64_t rows, int n_g, void* stream) {
+  if (!feat || !Wv_planes || !Wg_planes || !value || !G || rows < 0 || n_g <= 0 || n_g > 256 || n_g % 32 != 0) return MVG_E_BADARG;
+  if (wv_scale < -100 || wv_scale > 100 || wg_scale < -100 || wg_scale > 100) return MVG_E_BADARG;
+  if (rows == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(G) |
+       reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
+    return MVG_E_BADARG;
+  const size_t lds = 2 * HPLANE + RM * sizeof(int);
+  static bool configured[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&pyramid_f32h_kernel, lds, configured)) return rc;
+  const long ntiles = (rows + RM - 1) / RM;
+  const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
+  hipLaunchKernelGGL(pyramid_f32h_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale, bv,
+                     (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
                                 float* G, int64_t rows, int n_g, void* stream) {

@@ -397,6 +397,9 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self.proj_attn._fast_query_weights(dt)      # the fp32 G-sampling branch of native_sample (Woa_perm / boa_perm)
                 if self.proj_attn.f32_fused and self.proj_attn.rayconv.weight.shape == (256, 256):
                     self.proj_attn.query_term_weights_f32s()
+                    from . import projattn as _pa
+                    if _pa.F32_H2:
+                        self.proj_attn.pyramid_planes_f32h()
             fa32, fb32 = self._fuses_chains_f32(dt)
             if fa32:
                 self._chain_a_weights_f32s()

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import math
+
 import numpy as np
 import torch
 
@@ -545,6 +547,44 @@ def split_swizzle_weight(w, pad_rows_to=256):
     m = r1.to(torch.bfloat16)
     l = (r1 - m.float()).to(torch.bfloat16)
     return torch.cat([swizzle_weight(p) for p in (h, m, l)])
+
+
+def split_swizzle_weight_h2(w, pad_rows_to=256):
+    """fp32 nn.Linear weight (N, K) -> the operand of the two-part fp16 kernels (csrc/f32s.hip, "f32h"): (planes, s) with
+    w 2^s = h + l, h = fp16(w 2^s), l = fp16(w 2^s - h), s chosen so that max |w| 2^s lies in [2^13, 2^14); each plane in swizzle_weight
+    order, concatenated (N zero-padded to a multiple of 256).  One host sync (the tensor's maximum) when the operand cache is built."""
+    w = w.detach().float()
+    N, K = w.shape
+    Np = (N + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+    if Np != N:
+        w = torch.cat([w, w.new_zeros(Np - N, K)], 0)
+    mx = float(w.abs().max())
+    s = 0 if not (mx > 0 and math.isfinite(mx)) else max(-100, min(100, 13 - math.frexp(mx)[1] + 1))
+    ws = torch.ldexp(w, torch.tensor(s, device=w.device))
+    h = ws.to(torch.float16)
+    l = (ws - h.float()).to(torch.float16)
+    return torch.cat([swizzle_weight(p) for p in (h, l)]), s
+
+
+def pyramid_f32h(feat, Wv_planes, wv_scale, bv, Wg_planes, wg_scale, n_g, value=None, G=None):
+    """pyramid_f32s on two-part fp16 operands (include/mvg_decoder.h: mvg_pyramid_f32h); weights from split_swizzle_weight_h2."""
+    n_img, S, Cc = feat.shape
+    if feat.dtype != torch.float32 or Cc != 256 or not feat.is_contiguous():
+        raise RuntimeError("mvg_pyramid_f32h: contiguous fp32 (n_img, S, 256) pyramid required")
+    rows = n_img * S
+    for t in (Wv_planes, Wg_planes):
+        if t.dtype != torch.float16 or t.numel() != 2 * 256 * 256 or not t.is_contiguous():
+            raise RuntimeError("mvg_pyramid_f32h: weight planes from split_swizzle_weight_h2 required")
+    if value is None:
+        value = torch.empty((n_img, S, 256), dtype=torch.float32, device=feat.device)
+    if G is None:
+        G = torch.empty((rows, n_g), dtype=torch.float32, device=feat.device)
+    assert value.dtype == torch.float32 and value.numel() == rows * 256 and value.is_contiguous()
+    assert G.dtype == torch.float32 and tuple(G.shape) == (rows, n_g) and G.is_contiguous()
+    with _timed("pyramid_f32s"):
+      L.check(L.load().mvg_pyramid_f32h(L.ptr(feat), L.ptr(Wv_planes), int(wv_scale), L.ptr(bv), L.ptr(Wg_planes), int(wg_scale),
+                                        L.ptr(value), L.ptr(G), rows, n_g, L.stream_ptr()), "mvg_pyramid_f32h")
+    return value, G
 
 
 def pyramid_f32s(feat, Wv_planes, bv, Wg_planes, n_g, value=None, G=None):

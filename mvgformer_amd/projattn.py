@@ -38,6 +38,8 @@ def _is_power_of_2(n):
 
 # fp32 value / G products of the inline schedule: one pair per (device, stream), shared by every layer (project_pyramid)
 _SHARED_F32 = {}
+# fp32 pyramid products on two-part fp16 operands (three MFMAs per product instead of six; same accuracy against fp64); 0 = the six-product bf16 form
+F32_H2 = os.environ.get("MVG_F32_H2", "1") != "0"
 
 class WeightCache:
     """Contiguous copies of module parameters in the compute dtype, rebuilt when a parameter
@@ -60,14 +62,18 @@ class WeightCache:
                                "dtype and weights) before capturing" % key)
         with torch.no_grad():
             t = build(*params) if build is not None else params[0]
+            extra = ()
+            if isinstance(t, tuple):      # (tensor, host-side scalars ...): e.g. an operand and its power-of-two scale
+                t, extra = t[0], tuple(t[1:])
             t = t.detach().to(dtype).contiguous()
         # An entry is built on whatever stream is current and then handed out to every stream (the decoder issues
         # query-independent work on a side stream): finish the build before anybody can see the entry.  Rare (first
         # use / parameters changed).
         if t.is_cuda:
             torch.cuda.current_stream(t.device).synchronize()
-        self._store[key] = (stamp, t)
-        return t
+        out = (t,) + extra if extra else t
+        self._store[key] = (stamp, out)
+        return out
 
 
 class ProjAttn(nn.Module):
@@ -220,8 +226,12 @@ class ProjAttn(nn.Module):
                                                torch.empty((n_img * S, 192), dtype=dt, device=feat.device))
                 self._vp, self._G = cur
             if self.f32_fused and Cc == 256 and feat.is_contiguous():
-                Wv_pl, Wg_pl = self.pyramid_planes_f32s()
-                ops.pyramid_f32s(feat, Wv_pl, bv, Wg_pl, 192, value=self._vp, G=self._G)        # projattn.py:169 + 180-181
+                if F32_H2:     # two-part fp16 operands, three products (csrc/f32s.hip: pyramid_f32h_kernel)
+                    (Wv_pl, sv), (Wg_pl, sg) = self.pyramid_planes_f32h()
+                    ops.pyramid_f32h(feat, Wv_pl, sv, bv, Wg_pl, sg, 192, value=self._vp, G=self._G)   # projattn.py:169 + 180-181
+                else:
+                    Wv_pl, Wg_pl = self.pyramid_planes_f32s()
+                    ops.pyramid_f32s(feat, Wv_pl, bv, Wg_pl, 192, value=self._vp, G=self._G)
             else:
                 ops.linear(feat.view(n_img * S, Cc), Wv, bv, out=self._vp.view(n_img * S, Cc))       # projattn.py:169
                 ops.linear(feat.view(n_img * S, Cc), Wq, None, out=self._G)
@@ -297,6 +307,13 @@ class ProjAttn(nn.Module):
         perm = lambda a, b: ops.split_swizzle_weight(torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)])
         return (self._wc.get("Wv_f32s", (self.rayconv.weight,), bf, ops.split_swizzle_weight),
                 self._wc.get("Woa_f32s", (self.sampling_offsets.weight, self.attention_weights.weight), bf, perm))
+
+    def pyramid_planes_f32h(self):
+        """operands of mvg_pyramid_f32h: ((value planes, scale), (G planes, scale)) -- two fp16 parts of each weight times a power of two"""
+        f16 = torch.float16
+        perm = lambda a, b: ops.split_swizzle_weight_h2(torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)])
+        return (self._wc.get("Wv_f32h", (self.rayconv.weight,), f16, ops.split_swizzle_weight_h2),
+                self._wc.get("Woa_f32h", (self.sampling_offsets.weight, self.attention_weights.weight), f16, perm))
 
     def query_term_weights_f32s(self):
         """operands of xw = (tgt + query_pos) @ [Woff; Wattn]^T + b as the fp32 chain B of the PREVIOUS layer takes them: (split

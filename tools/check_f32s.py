@@ -58,6 +58,22 @@ if full:
         timeit(lambda: ops.pyramid_f32s(feat, Wv_p, bv, Wg_p, 192, value, G)),
         timeit(lambda: (ops.linear(feat.view(rows, 256), Wv, bv), ops.linear(feat.view(rows, 256), Wg.contiguous(), None)))))
 
+# ---------------- pyramid, two-part fp16 operands (three products)
+(Wv_h, sv), (Wg_h, sg) = ops.split_swizzle_weight_h2(Wv), ops.split_swizzle_weight_h2(Wg)
+for name, ft in (("randn", feat), ("rows over 12 decades", feat * torch.exp(torch.randn(1, rows, 1, device=dev) * 5)),
+                 ("entries over 6 decades + zero rows", feat * torch.exp(torch.randn(1, rows, 256, device=dev) * 3) * (torch.rand(1, rows, 1, device=dev) > 0.1))):
+    vh, Gh = ops.pyramid_f32h(ft, Wv_h, sv, bv, Wg_h, sg, 192)
+    v6, G6 = ops.pyramid_f32s(ft, Wv_p, bv, Wg_p, 192)
+    torch.cuda.synchronize()
+    f = ft[0, :n]
+    print("pyramid f32h [%s]: value err %.2e  G err %.2e   (six-product form on the same input: %.2e / %.2e)" % (
+        name, rel(vh[0, :n], lin64(f, Wv, bv), scale_of(f, Wv, bv)), rel(Gh[:n], lin64(f, Wg), scale_of(f, Wg)),
+        rel(v6[0, :n], lin64(f, Wv, bv), scale_of(f, Wv, bv)), rel(G6[:n], lin64(f, Wg), scale_of(f, Wg))))
+    f = ft[0, -n:]
+    print("   tail: value err %.2e  G err %.2e" % (rel(vh[0, -n:], lin64(f, Wv, bv), scale_of(f, Wv, bv)), rel(Gh[-n:], lin64(f, Wg), scale_of(f, Wg))))
+if full:
+    print("pyramid_f32h %.1f us" % timeit(lambda: ops.pyramid_f32h(feat, Wv_h, sv, bv, Wg_h, sg, 192, value, G)))
+
 # ---------------- chain A
 R = 76800 if full else 1000
 samp = torch.randn(R, 256, device=dev)
