@@ -335,7 +335,8 @@ __device__ __forceinline__ void store_swapped_h2(float* __restrict__ out, long l
     }
 }
 
-__global__ __launch_bounds__(NT) void pyramid_f32h_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv, int swv,
+template <bool PAIR>
+__global__ __launch_bounds__(NT, PAIR ? 2 : 1) void pyramid_f32h_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv, int swv,
                                                           const float* __restrict__ bv, const bf16_t* __restrict__ Wg, int swg,
                                                           float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,9 +350,12 @@ __global__ __launch_bounds__(NT) void pyramid_f32h_kernel(const float* __restric
   const bf16_t* wpg2 = frag_ptr(Wg, 0, w < 4 ? w : 4 + ((w - 4) >> 1), 16, lane);
   const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
   const bool has_g = 32 * w < ng;
+  // PAIR: two workgroups per CU (2 x 68 KB of planes, <= 128 registers): no rows held across a tile's stages, fragment ring 2 deep --
+  // one workgroup's loads, splits, stores and barrier waits run under the other's matrix work
+  constexpr int RG = PAIR ? 2 : 4;
   f32x4 x[8];
   long tile = blockIdx.x;
-  if (tile < ntiles) {
+  if (!PAIR && tile < ntiles) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = i * NT + tid;
@@ -361,6 +365,13 @@ __global__ __launch_bounds__(NT) void pyramid_f32h_kernel(const float* __restric
   for (; tile < ntiles; tile += gridDim.x) {
     const long r0 = tile * RM;
     asm volatile("" : "+v"(wpv), "+v"(wpg), "+v"(wpg2));
+    if (PAIR) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * NT + tid;
+        x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
+      }
+    }
     __syncthreads();                               // the previous tile's stages have read the planes and the scale table
     // chunk i of this thread is 4 columns of row 8 i + w: a wavefront holds one whole row per chunk -> its maximum by a butterfly
 #pragma unroll
@@ -385,8 +396,8 @@ __global__ __launch_bounds__(NT) void pyramid_f32h_kernel(const float* __restric
     __syncthreads();
     const long nxt = tile + gridDim.x;
     f32x16 acc[2];
-    stage_swapped_h2<16, 4>(act, wpv, 65536, acc, rot, lane);
-    if (nxt < ntiles) {
+    stage_swapped_h2<16, RG>(act, wpv, 65536, acc, rot, lane);
+    if (!PAIR && nxt < ntiles) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = i * NT + tid;
@@ -396,16 +407,16 @@ __global__ __launch_bounds__(NT) void pyramid_f32h_kernel(const float* __restric
     store_swapped_h2(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, rs, swv, lane);
     if (ng == 192) {                               // balanced G stage, as in pyramid_f32s_kernel
       if (w < 4) {
-        stage_swapped_h2<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+        stage_swapped_h2<16, RG>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
         store_swapped_h2(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, rs, swg, lane);
       } else {
         const int cbg = 4 + ((w - 4) >> 1), mtg = (w - 4) & 1;
         f32x16 a1[1];
-        stage_swapped_h2<16, 4, 1>(act, wpg2, 65536, a1, (cbg * 3 + 7) & 15, lane, 32 * mtg);
+        stage_swapped_h2<16, RG, 1>(act, wpg2, 65536, a1, (cbg * 3 + 7) & 15, lane, 32 * mtg);
         store_swapped_h2<1>(G, ng, r0, rows, 32 * cbg + (lane & 31), a1, 0.f, rs, swg, lane, 32 * mtg);
       }
     } else if (has_g) {
-      stage_swapped_h2<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
+      stage_swapped_h2<16, RG>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
       store_swapped_h2(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, rs, swg, lane);
     }
   }
@@ -1235,6 +1246,7 @@ int cu_count() {
 int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two workgroups per CU (default: cfg-2 184 -> 140 us in the forward), 64 = one
                           // persistent 64-row workgroup per CU, 31 = the 32-row kernel with a 2-deep fragment ring
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
+int g_f32h_pair = 1;      // tuning knob "f32h_pair": mvg_pyramid_f32h as two workgroups per CU (no row prefetch, fragment ring 2)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
 
 extern "C" int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv_scale, const float* bv, const void* Wg_planes,
@@ -1246,12 +1258,19 @@ extern "C" int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv
        reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
     return MVG_E_BADARG;
   const size_t lds = 2 * HPLANE + RM * sizeof(int);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&pyramid_f32h_kernel, lds, configured)) return rc;
+  static bool configured[MVG_MAX_DEVICES] = {}, configured2[MVG_MAX_DEVICES] = {};
   const long ntiles = (rows + RM - 1) / RM;
-  const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
-  hipLaunchKernelGGL(pyramid_f32h_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale, bv,
-                     (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
+  if (g_f32h_pair) {
+    if (int rc = configure_lds(&pyramid_f32h_kernel<true>, lds, configured2)) return rc;
+    const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : 2 * cu_count());
+    hipLaunchKernelGGL(pyramid_f32h_kernel<true>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale,
+                       bv, (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
+  } else {
+    if (int rc = configure_lds(&pyramid_f32h_kernel<false>, lds, configured)) return rc;
+    const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
+    hipLaunchKernelGGL(pyramid_f32h_kernel<false>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale,
+                       bv, (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
+  }
   MVG_LAUNCH_CHECK();
   return 0;
 }

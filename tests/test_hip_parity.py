@@ -1769,6 +1769,46 @@ def test_dense_dlt_function_matches_the_torch_form(frac_valid):
         assert err < 1e-6, nm      # the torch form (fp32 rows) is at 1e-4 for the confidences
 
 
+def test_pyramid_products_on_two_part_fp16_operands():
+    """mvg_pyramid_f32h (three fp16 MFMAs per product, per-row power-of-two scales) against fp64: the error bar of the six-product
+    bf16 form (3.5e-7 of sum|a||w| + |b| on well-scaled rows, 1.5e-6 with entries spread over six decades -- the fp32 accumulation's
+    share in both forms), rows spread over 12 decades, zero rows, a ragged last tile; a row's result does not depend on its position
+    or on the launch shape (permutation / the two workgroup mappings: bit-identical); Inf / NaN stay in their rows."""
+    from mvgformer_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(21)
+    rows = 64 * 37 + 13
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    Wv, bv, Wg = rnd(256, 256) / 16, rnd(256), rnd(192, 256) / 16
+    (Wv_h, sv), (Wg_h, sg) = ops.split_swizzle_weight_h2(Wv), ops.split_swizzle_weight_h2(Wg)
+    lin64 = lambda x, W, b=None: x.double() @ W.double().t() + (0 if b is None else b.double())
+    scale = lambda x, W, b=None: x.double().abs() @ W.double().abs().t() + (0 if b is None else b.double().abs()) + 1e-300
+    base = rnd(1, rows, 256)
+    cases = {"randn": (base, 3.5e-7), "rows over 12 decades": (base * torch.exp(rnd(1, rows, 1) * 5), 3.5e-7),
+             "entries over 6 decades, zero rows": (base * torch.exp(rnd(1, rows, 256) * 3) * (torch.rand(1, rows, 1, generator=gen).to(DEV) > 0.1), 1.5e-6)}
+    for name, (feat, bar) in cases.items():
+        feat = feat.contiguous()
+        value, G = ops.pyramid_f32h(feat, Wv_h, sv, bv, Wg_h, sg, 192)
+        ev = float(((value[0].double() - lin64(feat[0], Wv, bv)).abs() / scale(feat[0], Wv, bv)).max())
+        eg = float(((G.double() - lin64(feat[0], Wg)).abs() / scale(feat[0], Wg)).max())
+        print("pyramid f32h [%s]: value %.2e G %.2e" % (name, ev, eg))
+        assert ev < bar and eg < bar, name
+        perm = torch.randperm(rows, generator=gen).to(DEV)
+        v2, G2 = ops.pyramid_f32h(feat[:, perm].contiguous(), Wv_h, sv, bv, Wg_h, sg, 192)
+        assert torch.equal(v2[0], value[0][perm]) and torch.equal(G2, G[perm])
+        try:
+            assert lib.mvg_set_tuning(b"f32h_pair", 0) == 0
+            v3, G3 = ops.pyramid_f32h(feat, Wv_h, sv, bv, Wg_h, sg, 192)
+        finally:
+            assert lib.mvg_set_tuning(b"f32h_pair", 1) == 0
+        assert torch.equal(v3, value) and torch.equal(G3, G)
+    feat = base.clone()
+    feat[0, 5, 7], feat[0, 70, 0] = float("inf"), float("nan")
+    value, G = ops.pyramid_f32h(feat, Wv_h, sv, bv, Wg_h, sg, 192)
+    bad = ~torch.isfinite(value[0]).all(1)
+    assert bad.nonzero().flatten().tolist() == [5, 70] and bool(torch.isfinite(G[[4, 6, 69, 71]]).all())
+
+
 def test_fp32_chain_b_tile_sizes_agree_bit_for_bit():
     """mvg_chain_update_ffn_class_f32s picks 32-row tiles for launches that would leave CUs idle with 64-row tiles (cfg-4, a rank's
     query shard).  Both variants sum every row in the same order: identical outputs, so a sharded run (small launch) and the
