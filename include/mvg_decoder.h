@@ -306,6 +306,14 @@ int mvg_msda_gsamp_chain(const void* vh, const void* G, const float* xw, const f
  * a multiple of 256 with zero rows (mvgformer_amd.ops.split_swizzle_weight).  A non-finite or > 3.39e38 input value makes its
  * output row NaN (as in mvg_linear's split form). */
 
+/* mvg_chain_attn_pose_f32s on two-part fp16 operands (three fp16 MFMAs per product; lib/models/dq_decoder.py:585-588,659-690):
+ * Wp / W0 / W1 from ops.split_swizzle_weight_h2 with their power-of-two scales; activation rows are scaled by the kernel between the
+ * stages (row maximum over the 8 wavefronts through LDS).  attn is stored as the exact fp32 result of its stage. */
+int mvg_chain_attn_pose_f32h(const float* samp, const uint8_t* inside, const void* Wp, int wp_scale, const float* bp, const void* W0,
+                             int w0_scale, const float* b0, const void* W1, int w1_scale, const float* b1, const float* W2,
+                             const float* b2, float* attn, float* o, const int32_t* order, const float* o_masked, int rows,
+                             void* stream);
+
 /* mvg_pyramid_f32s on two-part fp16 operands: every product as three fp16 MFMAs (l*h + h*l + h*h, fp32 accumulate) instead of six bf16
  * ones.  W?_planes: the weight times 2^w?_scale as two fp16 planes (h, l), each in mvg_swizzle order, N padded to 256
  * (ops.split_swizzle_weight_h2); activation rows are scaled by the kernel (a power of two per row from the row's maximum).  Same

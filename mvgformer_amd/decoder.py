@@ -26,6 +26,9 @@ from . import ops
 from .projattn import ProjAttn, WeightCache
 
 
+# fp32 chain A on two-part fp16 operands (csrc/f32s.hip: chain_a_f32h_small_kernel); 0 = the six-product bf16 form
+F32_CHAIN_H2 = os.environ.get("MVG_F32_CHAIN_H2", "1") != "0"
+
 class MLP(nn.Module):
     """multi_view_pose_transformer.py:81-102"""
 
@@ -345,6 +348,21 @@ class DQDecoderLayer(MvPDecoderLayer):
                            lambda *_: ops.chain_masked_row_output_f32s(*wts))
         return wts, o_masked
 
+    def _chain_a_weights_f32h(self):
+        """operands of ops.chain_attn_pose_f32h (two-part fp16 planes + their scales) and the masked-row constant of that kernel"""
+        f32, f16 = torch.float32, torch.float16
+        pose_layers = self.pose_embed.MLP.layers
+        sp = ops.split_swizzle_weight_h2
+        Wp, swp = self._w("Wp_f32h", (self.proj_attn.output_proj.weight,), f16, sp)
+        W0, sw0 = self._w("Wpe0_f32h", (pose_layers[0].weight,), f16, sp)
+        W1, sw1 = self._w("Wpe1_f32h", (pose_layers[1].weight,), f16, sp)
+        wts = (Wp, swp, self._w("bp", (self.proj_attn.output_proj.bias,), f32), W0, sw0, self._w("bpe0", (pose_layers[0].bias,), f32),
+               W1, sw1, self._w("bpe1", (pose_layers[1].bias,), f32),
+               self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
+        pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias)) + (self.proj_attn.output_proj.bias,)
+        o_masked = self._w("o_masked_f32h", pose_params, f32, lambda *_: ops.chain_masked_row_output_f32h(*wts))
+        return wts, o_masked
+
     def _chain_b_weights_f32s(self):
         f32, bf = torch.float32, torch.bfloat16
         sp = ops.split_swizzle_weight
@@ -402,7 +420,7 @@ class DQDecoderLayer(MvPDecoderLayer):
                         self.proj_attn.pyramid_planes_f32h()
             fa32, fb32 = self._fuses_chains_f32(dt)
             if fa32:
-                self._chain_a_weights_f32s()
+                self._chain_a_weights_f32h() if F32_CHAIN_H2 else self._chain_a_weights_f32s()
             if fb32:
                 self._chain_b_weights_f32s()
         fuse_a, fuse_b = self._fuses_chains(dt)
@@ -590,8 +608,12 @@ class DQDecoderLayer(MvPDecoderLayer):
             order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels) if (self.proj_attn.sort_pairs and Lq <= 65536) else None
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1), order=order,
                                                 xw=xw_in)
-            wts, o_masked = self._chain_a_weights_f32s()
-            attn, o = ops.chain_attn_pose_f32s(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+            if F32_CHAIN_H2:
+                wts, o_masked = self._chain_a_weights_f32h()
+                attn, o = ops.chain_attn_pose_f32h(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+            else:
+                wts, o_masked = self._chain_a_weights_f32s()
+                attn, o = ops.chain_attn_pose_f32s(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
             # fp32 (reference arithmetic): the per-view output projection and pose MLP run over the pairs in processing order and
             # skip the tiles whose pairs are all outside their image (their rows are zero / a cached constant either way).

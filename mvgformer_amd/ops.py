@@ -632,6 +632,46 @@ def chain_attn_pose_f32s(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=Non
     return attn, o
 
 
+def chain_attn_pose_f32h(samp, inside, Wp, swp, bp, W0, sw0, b0, W1, sw1, b1, W2, b2, order=None, o_masked=None):
+    """fp32 chain A on two-part fp16 operands (include/mvg_decoder.h: mvg_chain_attn_pose_f32h): samp (rows, 256) f32 -> (attn f32
+    (rows, 256), o f32 (rows, 3)); (Wp, swp) / (W0, sw0) / (W1, sw1) from split_swizzle_weight_h2."""
+    rows = samp.shape[0]
+    if samp.dtype != torch.float32 or samp.shape[1] != 256 or not samp.is_contiguous():
+        raise RuntimeError("mvg_chain_attn_pose_f32h: contiguous fp32 (rows, 256) samples required")
+    for t in (Wp, W0, W1):
+        if t.dtype != torch.float16 or t.numel() != 2 * 256 * 256 or not t.is_contiguous():
+            raise RuntimeError("mvg_chain_attn_pose_f32h: weight planes from split_swizzle_weight_h2 required")
+    if inside.dtype != torch.uint8 or inside.numel() != rows or not inside.is_contiguous():
+        raise RuntimeError("mvg_chain_attn_pose_f32h: inside must be a contiguous uint8 tensor with one entry per row")
+    if W2.dtype != torch.float32 or tuple(W2.shape) != (3, 256) or not W2.is_contiguous():
+        raise RuntimeError("mvg_chain_attn_pose_f32h: the last pose layer's (3, 256) fp32 weight required")
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == rows and order.is_contiguous()
+    attn = torch.empty((rows, 256), dtype=torch.float32, device=samp.device)
+    o = torch.empty((rows, 3), dtype=torch.float32, device=samp.device)
+    with _timed("chain_attn_pose_f32s"):
+      L.check(L.load().mvg_chain_attn_pose_f32h(L.ptr(samp), L.ptr(inside), L.ptr(Wp), int(swp), L.ptr(bp), L.ptr(W0), int(sw0), L.ptr(b0),
+                                                L.ptr(W1), int(sw1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
+                                                None if order is None else L.ptr(order),
+                                                None if o_masked is None else L.ptr(o_masked), rows, L.stream_ptr()),
+              "mvg_chain_attn_pose_f32h")
+    return attn, o
+
+
+def chain_masked_row_output_f32h(Wp, swp, bp, W0, sw0, b0, W1, sw1, b1, W2, b2):
+    """o (3,) f32 of a row with inside == 0 as the two-part fp16 chain A computes it (the chain run on one masked row)."""
+    dev = Wp.device
+    samp = torch.zeros((1, 256), dtype=torch.float32, device=dev)
+    inside = torch.zeros((1,), dtype=torch.uint8, device=dev)
+    global PROFILE
+    saved, PROFILE = PROFILE, None
+    try:
+        _, o = chain_attn_pose_f32h(samp, inside, Wp, swp, bp, W0, sw0, b0, W1, sw1, b1, W2, b2)
+    finally:
+        PROFILE = saved
+    return o.reshape(3)
+
+
 def chain_masked_row_output_f32s(Wp, bp, W0, b0, W1, b1, W2, b2):
     """o (3,) f32 of a row with inside == 0 as the fp32 chain A computes it (the chain run on one masked row)."""
     dev = Wp.device

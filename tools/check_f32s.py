@@ -98,6 +98,22 @@ if full:
         timeit(lambda: ops.chain_attn_pose_f32s(samp, inside, *wts, order=order, o_masked=o_masked)),
         timeit(lambda: ops.chain_attn_pose_f32s(samp, inside, *wts))))
 
+# ---------------- chain A, two-part fp16 operands
+sp2 = ops.split_swizzle_weight_h2
+(Wp_h, swp), (W0_h, sw0), (W1_h, sw1) = sp2(Wp), sp2(W0), sp2(W1)
+wts_h = (Wp_h, swp, bp, W0_h, sw0, b0, W1_h, sw1, b1, W2.contiguous(), b2)
+o_masked_h = ops.chain_masked_row_output_f32h(*wts_h)
+for od, om in ((None, None), (order, o_masked_h)):
+    attn_h, o_h = ops.chain_attn_pose_f32h(samp, inside, *wts_h, order=od, o_masked=om)
+    torch.cuda.synchronize()
+    print("chain A f32h (order %s): attn err %.2e (abs %.2e)  o abs err %.2e  masked o equal %s" % (
+        od is not None, rel(attn_h, a64, scale_of(samp, Wp, bp)), float((attn_h.double() - a64).abs().max()),
+        float((o_h.double() - o64).abs().max()), bool((o_h[inside == 0] == o_masked_h).all())))
+if full:
+    print("chain_a_f32h %.1f us (ordered, skipping) / %.1f us (no order)" % (
+        timeit(lambda: ops.chain_attn_pose_f32h(samp, inside, *wts_h, order=order, o_masked=o_masked_h)),
+        timeit(lambda: ops.chain_attn_pose_f32h(samp, inside, *wts_h))))
+
 # ---------------- chain B
 B, NQ, J, V = (1, 1024, 15, 5) if full else (1, 37, 15, 3)
 rows = B * NQ * J
