@@ -306,6 +306,17 @@ int mvg_msda_gsamp_chain(const void* vh, const void* G, const float* xw, const f
  * a multiple of 256 with zero rows (mvgformer_amd.ops.split_swizzle_weight).  A non-finite or > 3.39e38 input value makes its
  * output row NaN (as in mvg_linear's split form). */
 
+/* mvg_chain_update_ffn_class_f32s on two-part fp16 operands (three fp16 MFMAs per product; lib/models/dq_decoder.py:770-778,
+ * lib/models/mvp_decoder.py:94-98, dq_decoder.py:889-908): 32-row tiles, two workgroups per CU; Wu / W1 / W2 / W_next from
+ * ops.split_swizzle_weight_h2 with their power-of-two scales, every other argument as in the six-product entry.  The FFN's hidden
+ * activations carry a scale per (row, 256-column chunk); the residual t1 stays in fp32 registers. */
+int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const float* tgt, const void* Wu, int wu_scale, const float* bu,
+                                    const float* g2, const float* be2, const void* W1, int w1_scale, const float* b1, const void* W2,
+                                    int w2_scale, const float* b2, const float* g3, const float* be3, const float* Wc, const float* bc,
+                                    float threshold, const uint8_t* forced_valid, float* tgt_out, float* prob, uint8_t* valid,
+                                    int* any_valid, const float* query_pos, const void* W_next, int wn_scale, const float* b_next,
+                                    float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream);
+
 /* mvg_chain_attn_pose_f32s on two-part fp16 operands (three fp16 MFMAs per product; lib/models/dq_decoder.py:585-588,659-690):
  * Wp / W0 / W1 from ops.split_swizzle_weight_h2 with their power-of-two scales; activation rows are scaled by the kernel between the
  * stages (row maximum over the 8 wavefronts through LDS).  attn is stored as the exact fp32 result of its stage. */

@@ -1377,6 +1377,251 @@ __global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
   STAMP(41);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// chain B on two-part fp16 operands ("f32h"; round 4): 32-row tiles (2 persons), 71 KB of LDS -- two workgroups per CU, which the
+// six-product form's 32-row tile (101 KB) could not have.  Same steps as chain_b_f32s_kernel; every plane write is preceded by the
+// row-maximum exchange of chain_a_f32h_small_kernel (partials in an LDS table in front of a barrier that is there anyway).  The FFN's
+// hidden activations get a scale per (row, 256-column chunk): each chunk's second GEMM starts from a zero accumulator and its result is
+// un-scaled and added to the fp32 sum in chunk order.  t1 (the residual of the FFN) stays in registers: planes hold 22 bits.
+__device__ __forceinline__ float absmax16(const f32x4 (&v)[4]) {
+  float m = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[g][0]), fabsf(v[g][1])), fmaxf(fabsf(v[g][2]), fabsf(v[g][3]))));
+  return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+__device__ __forceinline__ int gather_scale(const float* __restrict__ pm, int row) {
+  const f32x4 p0 = *reinterpret_cast<const f32x4*>(pm + row * 8), p1 = *reinterpret_cast<const f32x4*>(pm + row * 8 + 4);
+  return row_scale(fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3]))));
+}
+// this lane's 16 values of row `row` (columns col0 + 8 g .. + 3) -> the two planes, scaled by 2^sr
+__device__ __forceinline__ void write_row_h2(char* __restrict__ planes, int plane_bytes, int row, int col0, const f32x4 (&v)[4], int sr) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 xs;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(v[g][t], sr);
+    uint2 ph, pl;
+    split4_h2(xs, ph, pl);
+    *reinterpret_cast<uint2*>(planes + row * PLP + (col0 + 8 * g) * 2) = ph;
+    *reinterpret_cast<uint2*>(planes + plane_bytes + row * PLP + (col0 + 8 * g) * 2) = pl;
+  }
+}
+
+__global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
+    const float* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu, int su,
+    const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
+    const bf16_t* __restrict__ W1, int s1, const float* __restrict__ b1, const bf16_t* __restrict__ W2, int s2,
+    const float* __restrict__ b2, const float* __restrict__ g3, const float* __restrict__ be3,
+    const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
+    float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
+    const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, int sn, const float* __restrict__ bn,
+    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
+  constexpr int RMT = 32, APL = RMT * PLP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;                                   // 2 planes x 32 rows x 256 columns: mean, then t1, then tgt' + query_pos
+  char* hb = smem + 2 * APL;                          // 2 planes x 32 rows x 256 columns: FFN hidden chunk
+  float* part = reinterpret_cast<float*>(hb + 2 * APL);
+  float* part2 = part + RMT * 8;
+  float* pm = part2 + RMT * 8;                        // partial row maxima [row][wavefront]
+  float* pr = pm + RMT * 8;                           // per-row class probabilities (RMT x 2)
+  int* rs = reinterpret_cast<int*>(pr + RMT * 2);     // s_row of act's rows
+  int* rsh = rs + RMT;                                // s_row of the hidden chunk's rows
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
+  const int qpt = RMT / J, rpt = qpt * J;
+  const int q0 = blockIdx.x * qpt, r0 = q0 * J;
+  const int nrow = min(rpt, rows - r0);
+  const int rot = (w * 3) & 15;
+  const int colb = 32 * w, col0 = colb + 4 * h;       // the wavefront's column block; this lane's first column
+
+  f32x4 tg[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) tg[g] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(rl, nrow - 1)) * 256 + col0 + 8 * g);
+
+  // ---- mean over views (dq_decoder.py:770) -> planes; chunk i of a thread = 4 columns of row 8 i + w (a wavefront holds a whole row)
+  {
+    constexpr int NCH = RMT * 64 / NT;
+    f32x4 sacc[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < V; v += 2) {
+      f32x4 xv[2][NCH];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          xv[u][i] = *reinterpret_cast<const f32x4*>(attn + ((long)min(v + u, V - 1) * rows + r0 + min(8 * i + w, nrow - 1)) * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        sacc[i] += xv[0][i];
+        if (v + 1 < V) sacc[i] += xv[1][i];
+      }
+    }
+    const float Vf = (float)V;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = 8 * i + w;
+      f32x4 m4 = {sacc[i][0] / Vf, sacc[i][1] / Vf, sacc[i][2] / Vf, sacc[i][3] / Vf};
+      if (row >= nrow) m4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      float m = fmaxf(fmaxf(fabsf(m4[0]), fabsf(m4[1])), fmaxf(fabsf(m4[2]), fabsf(m4[3])));
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+      const int sr = row_scale(m);
+      f32x4 xs;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(m4[t], sr);
+      uint2 ph, pl;
+      split4_h2(xs, ph, pl);
+      *reinterpret_cast<uint2*>(act + row * PLP + lane * 8) = ph;
+      *reinterpret_cast<uint2*>(act + APL + row * PLP + lane * 8) = pl;
+      if (lane == 0) rs[row] = sr;
+    }
+  }
+  __syncthreads();
+
+  // ---- t1 = LN2(tgt + feature_update_mlp(mean))   (dq_decoder.py:773-778)
+  f32x16 acc[1];
+  f32x4 bvr[4], t1[1][4];
+  stage_h2<1, 16, PLP, 2>(act, APL, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, rot, lane);
+  load_bias(bu + colb, bvr, lane);
+  {
+    const int un = -(rs[rl] + su);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) t1[0][g][t] = __builtin_ldexpf(acc[0][4 * g + t], un) + bvr[g][t];
+      if (rl < nrow) t1[0][g] += tg[g];
+    }
+  }
+  layernorm_rows<1>(t1, g2 + colb, be2 + colb, part, part2, lane, w);      // (its first barrier: every wavefront is done reading `act` and rs)
+  {
+    const float m = absmax16(t1[0]);
+    if (h == 0) pm[rl * 8 + w] = m;
+  }
+  __syncthreads();
+  {
+    const int sr = gather_scale(pm, rl);
+    write_row_h2(act, APL, rl, col0, t1[0], sr);
+    if (w == 0 && h == 0) rs[rl] = sr;
+  }
+  __syncthreads();
+
+  f32x4 y[1][4];
+  if (has_ffn) {
+    // ---- FFN (mvp_decoder.py:94-98): Y = sum over the 4 hidden chunks of relu(t1 W1^T + b1)[chunk] W2[:, chunk]^T
+    f32x4 ysum[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ysum[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wp2 = frag_ptr(W2, 0, w, 64, lane);
+    const int un1 = -(rs[rl] + s1);
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      f32x4 hid[4];
+      stage_h2<1, 16, PLP, 2>(act, APL, 0, frag_ptr(W1, c, w, 16, lane), 1024 * 256, acc, (w * 5) & 15, lane);
+      load_bias(b1 + c * 256 + colb, bvr, lane);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hid[g][t] = fmaxf(__builtin_ldexpf(acc[0][4 * g + t], un1) + bvr[g][t], 0.f);
+      {
+        const float m = absmax16(hid);
+        if (h == 0) pm[rl * 8 + w] = m;
+      }
+      __syncthreads();                                              // the previous chunk's second GEMM has read hb and rsh; maxima complete
+      {
+        const int sr = gather_scale(pm, rl);
+        write_row_h2(hb, APL, rl, col0, hid, sr);
+        if (w == 0 && h == 0) rsh[rl] = sr;
+      }
+      __syncthreads();
+      stage_h2<1, 16, PLP, 2>(hb, APL, 0, wp2 + (long)c * 16 * 1024, 256 * 1024, acc, rot, lane);
+      const int un2 = -(rsh[rl] + s2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ysum[g][t] += __builtin_ldexpf(acc[0][4 * g + t], un2);
+    }
+    load_bias(b2 + colb, bvr, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) y[0][g] = (ysum[g] + bvr[g]) + t1[0][g];
+    layernorm_rows<1>(y, g3 + colb, be3 + colb, part, part2, lane, w);
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) y[0][g] = t1[0][g];
+  }
+
+  // ---- tgt' -> global; class head (dq_decoder.py:889-893): per-row logits, completed across the wavefronts
+  {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (rl < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + rl) * 256 + col0 + 8 * g) = y[0][g];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + col0 + 8 * g);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + col0 + 8 * g);
+      a0 += (y[0][g][0] * w0[0] + y[0][g][1] * w0[1]) + (y[0][g][2] * w0[2] + y[0][g][3] * w0[3]);
+      a1 += (y[0][g][0] * w1[0] + y[0][g][1] * w1[1]) + (y[0][g][2] * w1[2] + y[0][g][3] * w1[3]);
+    }
+    a0 += __shfl_xor(a0, 32, 64);
+    a1 += __shfl_xor(a1, 32, 64);
+    __syncthreads();                                                // part / part2 of the last LayerNorm have been read
+    if (h == 0) {
+      part[rl * 8 + w] = a0;
+      part2[rl * 8 + w] = a1;
+    }
+    // the maxima of tgt' + query_pos for the next layer's query term ride on the same barrier
+    f32x4 z[4];
+    if (Wn) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        z[g] = y[0][g];
+        if (qpos) z[g] += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(rl, nrow - 1)) * 256 + col0 + 8 * g);
+      }
+      const float m = absmax16(z);
+      if (h == 0) pm[rl * 8 + w] = m;
+    }
+    __syncthreads();
+    if (tid < RMT) {
+      pr[2 * tid] = 1.f / (1.f + expf(-(row_total(part, tid) + bc[0])));
+      pr[2 * tid + 1] = 1.f / (1.f + expf(-(row_total(part2, tid) + bc[1])));
+    }
+    if (Wn) {        // every wavefront passed the barriers above: `act` and rs are free
+      const int sr = gather_scale(pm, rl);
+      write_row_h2(act, APL, rl, col0, z, sr);
+      if (w == 0 && h == 0) rs[rl] = sr;
+    }
+    __syncthreads();
+    if (tid < qpt && q0 + tid < nq_total) {
+      float p0 = 0.f, p1 = 0.f;
+      for (int j = 0; j < J; ++j) {
+        p0 += pr[2 * (tid * J + j)];
+        p1 += pr[2 * (tid * J + j) + 1];
+      }
+      p0 /= (float)J;
+      p1 /= (float)J;
+      const int qi = q0 + tid;
+      prob[2 * (long)qi] = p0;
+      prob[2 * (long)qi + 1] = p1;
+      const bool ok = forced ? (forced[qi] != 0) : (p1 > threshold);                   // dq_decoder.py:605
+      valid[qi] = ok ? 1 : 0;
+      if (ok) atomicOr(any_valid, 1);
+    }
+  }
+  if (Wn && colb < n_next) {
+    // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets / logits Linear (projattn.py:180-181)
+    stage_h2<1, 16, PLP, 2>(act, APL, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, (rot + 7) & 15, lane);
+    load_bias(bn + colb, bvr, lane);
+    const int un = -(rs[rl] + sn);
+    if (rl < nrow) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = __builtin_ldexpf(acc[0][4 * g + t], un) + bvr[g][t];
+        *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + rl) * n_next + col0 + 8 * g) = v;
+      }
+    }
+  }
+}
+
 template <typename K>
 int configure_lds(K kernel, size_t lds, bool (&configured)[MVG_MAX_DEVICES]) {
   int dev = 0;
@@ -1408,6 +1653,33 @@ int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two w
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
 int g_f32h_pair = 1;      // tuning knob "f32h_pair": mvg_pyramid_f32h as two workgroups per CU (no row prefetch, fragment ring 2)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
+
+extern "C" int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const float* tgt, const void* Wu, int wu_scale, const float* bu,
+                                              const float* g2, const float* be2, const void* W1, int w1_scale, const float* b1,
+                                              const void* W2, int w2_scale, const float* b2, const float* g3, const float* be3,
+                                              const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
+                                              float* tgt_out, float* prob, uint8_t* valid, int* any_valid, const float* query_pos,
+                                              const void* W_next, int wn_scale, const float* b_next, float* xw_next, int n_next, int B,
+                                              int NQ, int J, int has_ffn, void* stream) {
+  if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
+  if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
+  if (V <= 0 || J <= 0 || J > 32 || B < 0 || NQ < 0) return MVG_E_BADARG;
+  if (W_next && (!b_next || !xw_next || n_next <= 0 || n_next > 256 || n_next % 32 != 0)) return MVG_E_BADARG;
+  for (int sc : {wu_scale, w1_scale, w2_scale, wn_scale})
+    if (sc < -100 || sc > 100) return MVG_E_BADARG;
+  const int nq_total = B * NQ, rows = nq_total * J;
+  if (rows == 0) return 0;
+  const int qpt = 32 / J;
+  const size_t lds = 4 * 32 * PLP + (3 * 32 * 8 + 32 * 2) * sizeof(float) + 2 * 32 * sizeof(int);
+  static bool configured[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&chain_b_f32h_kernel, lds, configured)) return rc;
+  hipLaunchKernelGGL(chain_b_f32h_kernel, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, (hipStream_t)stream, attn, V, tgt,
+                     (const bf16_t*)Wu, wu_scale, bu, g2, be2, (const bf16_t*)W1, w1_scale, b1, (const bf16_t*)W2, w2_scale, b2, g3, be3, Wc,
+                     bc, threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, wn_scale, b_next,
+                     xw_next, n_next, rows, J, nq_total, has_ffn);
+  MVG_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int mvg_chain_attn_pose_f32h(const float* samp, const uint8_t* inside, const void* Wp, int wp_scale, const float* bp,
                                        const void* W0, int w0_scale, const float* b0, const void* W1, int w1_scale, const float* b1,

@@ -377,6 +377,22 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self._w("b3", (self.norm3.bias,), f32) if ffn else None,
                 self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
 
+    def _chain_b_weights_f32h(self):
+        """operands of ops.chain_update_ffn_class_f32h, in its argument order"""
+        f32, f16 = torch.float32, torch.float16
+        sp = ops.split_swizzle_weight_h2
+        ffn = self.open_forward_ffn
+        Wu, su = self._w("Wu_f32h", (self.feature_update_mlp.weight,), f16, sp)
+        W1, s1 = self._w("W1_f32h", (self.linear1.weight,), f16, sp) if ffn else (None, 0)
+        W2, s2 = self._w("W2_f32h", (self.linear2.weight,), f16, sp) if ffn else (None, 0)
+        return (Wu, su, self._w("bu", (self.feature_update_mlp.bias,), f32),
+                self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
+                W1, s1, self._w("b1", (self.linear1.bias,), f32) if ffn else None,
+                W2, s2, self._w("bb2", (self.linear2.bias,), f32) if ffn else None,
+                self._w("g3", (self.norm3.weight,), f32) if ffn else None,
+                self._w("b3", (self.norm3.bias,), f32) if ffn else None,
+                self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
+
     def _fuses_chains_f32(self, dt, Lq=None, levels=None):
         """(chain A, chain B) of the fp32 path run as the fused f32s kernels (csrc/f32s.hip)"""
         pose_layers = self.pose_embed.MLP.layers
@@ -422,7 +438,11 @@ class DQDecoderLayer(MvPDecoderLayer):
             if fa32:
                 self._chain_a_weights_f32h() if F32_CHAIN_H2 else self._chain_a_weights_f32s()
             if fb32:
-                self._chain_b_weights_f32s()
+                if F32_CHAIN_H2:
+                    self._chain_b_weights_f32h()
+                    self.proj_attn.query_term_weights_f32h()
+                else:
+                    self._chain_b_weights_f32s()
         fuse_a, fuse_b = self._fuses_chains(dt)
         if fuse_a:
             self._chain_a_weights(dt, fused_sampler=self.proj_attn.fuse_sampler_chain)
@@ -642,12 +662,21 @@ class DQDecoderLayer(MvPDecoderLayer):
             next_proj = None
             if (nxt is not None and nxt.compute_dtype == dt and nxt._fuses_chains_f32(dt, Lq, ctx.levels)[0]
                     and (query_pos is None or query_pos.shape == tgt.shape)):
-                Wn, bn, n_next = nxt.proj_attn.query_term_weights_f32s()
                 qp = None if query_pos is None else query_pos.float().reshape(B * Lq, C).contiguous()
-                next_proj = (qp, Wn, bn, n_next)
-            res = ops.chain_update_ffn_class_f32s(
-                attn, V, tgt32, *self._chain_b_weights_f32s(), threshold, B, NQ, J, forced, self.open_forward_ffn,
-                tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
+                if F32_CHAIN_H2:
+                    (Wn, sn), bn, n_next = nxt.proj_attn.query_term_weights_f32h()
+                    next_proj = (qp, Wn, sn, bn, n_next)
+                else:
+                    Wn, bn, n_next = nxt.proj_attn.query_term_weights_f32s()
+                    next_proj = (qp, Wn, bn, n_next)
+            if F32_CHAIN_H2:
+                res = ops.chain_update_ffn_class_f32h(
+                    attn, V, tgt32, *self._chain_b_weights_f32h(), threshold, B, NQ, J, forced, self.open_forward_ffn,
+                    tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
+            else:
+                res = ops.chain_update_ffn_class_f32s(
+                    attn, V, tgt32, *self._chain_b_weights_f32s(), threshold, B, NQ, J, forced, self.open_forward_ffn,
+                    tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
             tgt_update, prob, valid, any_valid = res[:4]
             if next_proj is not None:
                 nxt._xw_in = res[4]

@@ -726,6 +726,46 @@ def chain_update_ffn_class_f32s(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g
     return tgt_out, prob, valid, any_valid
 
 
+def chain_update_ffn_class_f32h(attn, V, tgt, Wu, su, bu, g2, be2, W1, s1, b1, W2, s2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
+                                forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None):
+    """fp32 chain B on two-part fp16 operands (include/mvg_decoder.h: mvg_chain_update_ffn_class_f32h); arguments and results as
+    chain_update_ffn_class_f32s, weights (planes, scale) from split_swizzle_weight_h2, next_query_proj = (qpos, Wn, sn, bn, n_next)."""
+    dev = attn.device
+    rows = B * NQ * J
+    if attn.dtype != torch.float32 or attn.numel() != V * rows * 256 or not attn.is_contiguous():
+        raise RuntimeError("mvg_chain_update_ffn_class_f32h: contiguous fp32 (V * rows, 256) attn required")
+    assert tgt.dtype == torch.float32 and tgt.numel() == rows * 256 and tgt.is_contiguous()
+    assert Wu.dtype == torch.float16 and Wu.numel() == 2 * 256 * 256
+    if has_ffn:
+        assert W1.dtype == torch.float16 and W1.numel() == 2 * 1024 * 256 and W2.dtype == torch.float16 and W2.numel() == 2 * 256 * 1024
+    if tgt_out is None:
+        tgt_out = torch.empty((rows, 256), dtype=torch.float32, device=dev)
+    else:
+        assert tgt_out.dtype == torch.float32 and tgt_out.numel() == rows * 256 and tgt_out.is_contiguous()
+        tgt_out = tgt_out.view(rows, 256)
+    prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
+    qpos = Wn = bn = xw_next = None
+    n_next = sn = 0
+    if next_query_proj is not None:
+        qpos, Wn, sn, bn, n_next = next_query_proj
+        assert Wn.dtype == torch.float16 and Wn.numel() == 2 * 256 * 256 and bn.numel() == 256 and bn.dtype == torch.float32
+        if qpos is not None:
+            assert qpos.dtype == torch.float32 and qpos.numel() == rows * 256 and qpos.is_contiguous()
+        xw_next = torch.empty((rows, n_next), dtype=torch.float32, device=dev)
+    if any_valid is None:
+        any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with _timed("chain_update_ffn_class_f32s"):
+      L.check(L.load().mvg_chain_update_ffn_class_f32h(
+          L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), int(su), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), int(s1 or 0), L.ptr(b1), L.ptr(W2),
+          int(s2 or 0), L.ptr(b2), L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out),
+          L.ptr(prob), L.ptr(valid), L.ptr(any_valid), L.ptr(qpos), L.ptr(Wn), int(sn), L.ptr(bn), L.ptr(xw_next), n_next, B, NQ, J,
+          1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class_f32h")
+    if next_query_proj is not None:
+        return tgt_out, prob, valid, any_valid, xw_next
+    return tgt_out, prob, valid, any_valid
+
+
 def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
     """fused output_proj (* in-image mask) + 3-layer pose MLP; Wp/W0/W1 in swizzle_weight order.
     order (rows) i32: row processing order (bin_pairs: masked rows last); o_masked (3) f32 from

@@ -315,6 +315,12 @@ class ProjAttn(nn.Module):
         return (self._wc.get("Wv_f32h", (self.rayconv.weight,), f16, ops.split_swizzle_weight_h2),
                 self._wc.get("Woa_f32h", (self.sampling_offsets.weight, self.attention_weights.weight), f16, perm))
 
+    def query_term_weights_f32h(self):
+        """operands of the next layer's query term as the two-part fp16 chain B of the PREVIOUS layer takes them: ((planes, scale) of the
+        (192 -> 256, 256) weight in gsamp_column_order, bias (256,) f32 zero-padded, n = 192)"""
+        Wpl = self.pyramid_planes_f32h()[1]
+        return Wpl, self.query_term_weights_f32s()[1], 192
+
     def query_term_weights_f32s(self):
         """operands of xw = (tgt + query_pos) @ [Woff; Wattn]^T + b as the fp32 chain B of the PREVIOUS layer takes them: (split
         planes of the (192 -> 256, 256) weight in gsamp_column_order, bias (256,) f32 zero-padded, n = 192)"""

@@ -138,5 +138,15 @@ xw = lin64(y + qpos.double(), Wn, bn)
 print("chain B: tgt' abs err %.2e  prob err %.2e  xw abs err %.2e  valid equal %s" % (
     float((res[0].double() - y).abs().max()), float((res[1].double() - pr).abs().max()), float((res[4].double() - xw).abs().max()),
     bool((res[2].bool() == (pr[..., 1] > 0.5)).all())))
+# ---------------- chain B, two-part fp16 operands
+(Wu_h, su), (Wf1_h, s1), (Wf2_h, s2), (Wn_h, sn) = sp2(Wu), sp2(Wf1), sp2(Wf2), sp2(Wn)
+args_h = (Wu_h, su, bu, g2, be2, Wf1_h, s1, bf1, Wf2_h, s2, bf2, g3, be3, Wc.contiguous(), bc)
+res_h = ops.chain_update_ffn_class_f32h(attn, V, tgt, *args_h, 0.5, B, NQ, J, next_query_proj=(qpos, Wn_h, sn, bn_pad, 192))
+torch.cuda.synchronize()
+print("chain B f32h: tgt' abs err %.2e  prob err %.2e  xw abs err %.2e  valid equal %s" % (
+    float((res_h[0].double() - y).abs().max()), float((res_h[1].double() - pr).abs().max()), float((res_h[4].double() - xw).abs().max()),
+    bool((res_h[2].bool() == (pr[..., 1] > 0.5)).all())))
+if full:
+    print("chain_b_f32h %.1f us" % timeit(lambda: ops.chain_update_ffn_class_f32h(attn, V, tgt, *args_h, 0.5, B, NQ, J, next_query_proj=(qpos, Wn_h, sn, bn_pad, 192))))
 if full:
     print("chain_b_f32s %.1f us" % timeit(lambda: ops.chain_update_ffn_class_f32s(attn, V, tgt, *args, 0.5, B, NQ, J, next_query_proj=nxt)))
