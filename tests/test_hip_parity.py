@@ -1809,6 +1809,61 @@ def test_pyramid_products_on_two_part_fp16_operands():
     assert bad.nonzero().flatten().tolist() == [5, 70] and bool(torch.isfinite(G[[4, 6, 69, 71]]).all())
 
 
+def test_fp32_chains_on_two_part_fp16_operands():
+    """mvg_chain_attn_pose_f32h / mvg_chain_update_ffn_class_f32h (three fp16 MFMAs per product, per-row scales exchanged between the
+    wavefronts) against fp64, with the bars tools/check_f32s.py applies to the six-product kernels; masked rows of mixed tiles equal the
+    cached constant bit for bit; a row's result does not depend on its tile (rows permuted / a second launch with other neighbours)."""
+    from mvgformer_amd import ops
+    gen = torch.Generator().manual_seed(33)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    mk = lambda n, k: (rnd(n, k) / k ** 0.5, rnd(n) * 0.1)
+    sp2 = ops.split_swizzle_weight_h2
+    lin64 = lambda x, W, b=None: x.double() @ W.double().t() + (0 if b is None else b.double())
+    # ---- chain A
+    R = 32 * 61 + 7
+    samp = rnd(R, 256) * torch.exp(rnd(R, 1))                 # rows of different magnitudes
+    inside = (torch.rand(R, generator=gen) < 0.67).to(torch.uint8).to(DEV)
+    (Wp, bp), (W0, b0), (W1, b1), (W2, b2) = mk(256, 256), mk(256, 256), mk(256, 256), mk(3, 256)
+    (Wp_h, swp), (W0_h, sw0), (W1_h, sw1) = sp2(Wp), sp2(W0), sp2(W1)
+    wts = (Wp_h, swp, bp, W0_h, sw0, b0, W1_h, sw1, b1, W2.contiguous(), b2)
+    o_masked = ops.chain_masked_row_output_f32h(*wts)
+    order = torch.argsort(1 - inside.int(), stable=True).to(torch.int32)
+    a64 = lin64(samp, Wp, bp) * inside.double()[:, None]
+    o64 = lin64(torch.relu(lin64(torch.relu(lin64(a64, W0, b0)), W1, b1)), W2, b2)
+    scale = samp.double().abs() @ Wp.double().abs().t() + bp.double().abs()
+    res = {}
+    for key, (od, om) in {"plain": (None, None), "ordered": (order, o_masked)}.items():
+        attn, o = ops.chain_attn_pose_f32h(samp, inside, *wts, order=od, o_masked=om)
+        assert float(((attn.double() - a64).abs() / scale).max()) < 4e-7
+        assert float((o.double() - o64).abs().max()) < 1e-6 * (1.0 + float(o64.abs().max()))
+        assert bool((o[inside == 0] == o_masked).all()) and bool((attn[inside == 0] == 0).all())
+        res[key] = (attn, o)
+    assert torch.equal(res["plain"][0], res["ordered"][0]) and torch.equal(res["plain"][1], res["ordered"][1])   # tile membership does not matter
+    # ---- chain B
+    B, NQ, J, V = 1, 41, 15, 3
+    rows = B * NQ * J
+    attn, tgt, qpos = rnd(V * rows, 256), rnd(rows, 256), rnd(rows, 256)
+    (Wu, bu), (Wf1, bf1), (Wf2, bf2), (Wc, bc), (Wn, bn) = mk(256, 256), mk(1024, 256), mk(256, 1024), mk(2, 256), mk(192, 256)
+    g2, be2, g3, be3 = (1 + 0.1 * rnd(256) for _ in range(4))
+    (Wu_h, su), (Wf1_h, s1), (Wf2_h, s2), (Wn_h, sn) = sp2(Wu), sp2(Wf1), sp2(Wf2), sp2(Wn)
+    args = (Wu_h, su, bu, g2, be2, Wf1_h, s1, bf1, Wf2_h, s2, bf2, g3, be3, Wc.contiguous(), bc)
+    nxt = (qpos, Wn_h, sn, torch.cat([bn, bn.new_zeros(64)]), 192)
+    out = [t.clone() for t in ops.chain_update_ffn_class_f32h(attn, V, tgt, *args, 0.5, B, NQ, J, next_query_proj=nxt)]
+    ln = lambda x, g, b: torch.nn.functional.layer_norm(x, (256,), g.double(), b.double(), 1e-5)
+    t1 = ln(tgt.double() + lin64(attn.double().view(V, rows, 256).mean(0), Wu, bu), g2, be2)
+    y = ln(t1 + lin64(torch.relu(lin64(t1, Wf1, bf1)), Wf2, bf2), g3, be3)
+    pr = torch.sigmoid(lin64(y, Wc, bc)).view(B, NQ, J, 2).mean(2)
+    assert float((out[0].double() - y).abs().max()) < 2e-5 and float((out[1].double() - pr).abs().max()) < 1e-6
+    assert float((out[4].double() - lin64(y + qpos.double(), Wn, bn)).abs().max()) < 3e-5
+    assert bool((out[2].bool() == (pr[..., 1] > 0.5)).all())
+    # the persons in another order: every person's rows are unchanged (a tile is 2 persons)
+    perm = torch.randperm(NQ, generator=gen).to(DEV)
+    rperm = (perm[:, None] * J + torch.arange(J, device=DEV)[None]).reshape(-1)
+    out2 = ops.chain_update_ffn_class_f32h(attn.view(V, rows, 256)[:, rperm].reshape(V * rows, 256).contiguous(), V, tgt[rperm].contiguous(), *args, 0.5, B, NQ, J,
+                                           next_query_proj=(qpos[rperm].contiguous(),) + nxt[1:])
+    assert torch.equal(out2[0], out[0][rperm]) and torch.equal(out2[4], out[4][rperm]) and torch.equal(out2[1][0], out[1][0][perm])
+
+
 def test_fp32_chain_b_tile_sizes_agree_bit_for_bit():
     """mvg_chain_update_ffn_class_f32s picks 32-row tiles for launches that would leave CUs idle with 64-row tiles (cfg-4, a rank's
     query shard).  Both variants sum every row in the same order: identical outputs, so a sharded run (small launch) and the
