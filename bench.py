@@ -724,7 +724,9 @@ def main():
                    "initial_poses": {"grid": "'sample_space' grid over the whole space (SURVEY 8(d))",
                                      "all": "grid over 30 % of the space: > 99 % of the (view, query) pairs inside their image"}[args.inside],
                    "samples_in_flight": args.inflight, "samples_per_forward": args.batch,
-                   **({"fp32_gemm": {"split": "operands split into 3 bf16 parts, 6 bf16 MFMA products, fp32 accumulate",
+                   **({"fp32_gemm": {"split": "fused kernels (pyramid products, chains A / B): operands scaled per row / tensor by a power of two and "
+                                              "split into 2 fp16 parts, 3 fp16 MFMA products, fp32 accumulate; the first layer's query term: 3 "
+                                              "bf16 parts, 6 bf16 MFMA products (MVG_F32_H2=0 MVG_F32_CHAIN_H2=0: that form everywhere)",
                                      "exact": "v_mfma_f32_32x32x2_f32 (fmaf chain)"}[args.f32_gemm]}
                       if args.dtype == "fp32" else {}),
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
