@@ -921,21 +921,23 @@ __global__ __launch_bounds__(NT, 4) void chain_a_f32s_small_kernel(const float* 
 // (the barrier the six-product kernel has there too), every lane then reads the 8 partials of its row -- no extra barrier.  attn
 // (stored for chain B) and the inputs of the 3-output layer are taken from the fp32 registers, not from the 22-bit planes: attn is
 // exactly the fp32 result of its stage, the last layer's partial sums go through an LDS table summed in wavefront order.
-__global__ __launch_bounds__(NT, 4) void chain_a_f32h_small_kernel(const float* __restrict__ samp, const uint8_t* __restrict__ inside,
+template <int MT>
+__global__ __launch_bounds__(NT, MT == 1 ? 4 : 2) void chain_a_f32h_small_kernel(const float* __restrict__ samp, const uint8_t* __restrict__ inside,
                                                                    const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
                                                                    const bf16_t* __restrict__ W0, const float* __restrict__ b0,
                                                                    const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                                    const float* __restrict__ W2, const float* __restrict__ b2,
                                                                    int swp, int sw0, int sw1, float* __restrict__ attn, float* __restrict__ o,
                                                                    const int* __restrict__ order, const float* __restrict__ o_masked, int R) {
-  constexpr int RMS = 32, SPLANE = RMS * PLP;
+  constexpr int RMS = 32 * MT, SPLANE = RMS * PLP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                                   // 2 fp16 planes
   int* rid = reinterpret_cast<int*>(smem + 2 * SPLANE);
   int* keepf = rid + RMS;
   int* rs = keepf + RMS;                                              // s_row of the planes' rows
-  float* pm = reinterpret_cast<float*>(rs + RMS);                     // [row][wavefront]: partial row maxima; later [row][wavefront][4]: partial outputs
-  float* w2l = pm + RMS * 8 * 4;
+  float* pm = reinterpret_cast<float*>(rs + RMS);                     // [row][wavefront]: partial row maxima
+  float* w2l = pm + RMS * 8;
+  float* po = reinterpret_cast<float*>(act);                          // [row][wavefront][4]: partial outputs, over the planes once they are dead
   float* bias_l = w2l + 768;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
   const int r0 = blockIdx.x * RMS;
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(NT, 4) void chain_a_f32h_small_kernel(const float* 
   const bool any_inside = __syncthreads_or(mine) != 0;
   if (!any_inside && o_masked) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * MT; ++i) {
       const int c = i * NT + tid, g = rid[c >> 6];
       if (g >= 0) *reinterpret_cast<f32x4*>(attn + (long)g * 256 + (c & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -969,14 +971,14 @@ __global__ __launch_bounds__(NT, 4) void chain_a_f32h_small_kernel(const float* 
   }
   {
     // chunk i of this thread = 4 columns of row 8 i + w: one wavefront holds a whole row -> its maximum by a butterfly
-    f32x4 x[4];
+    f32x4 x[4 * MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * MT; ++i) {
       const int c = i * NT + tid;
       x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid[c >> 6], 0) * 256 + (c & 63) * 4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * MT; ++i) {
       const int row = 8 * i + w;
       if (rid[row] < 0) x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       float m = fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fmaxf(fabsf(x[i][2]), fabsf(x[i][3])));
@@ -993,77 +995,94 @@ __global__ __launch_bounds__(NT, 4) void chain_a_f32h_small_kernel(const float* 
       if (lane == 0) rs[row] = sr;
     }
   }
-  const bool keep = keepf[rl] != 0;
-  const int grow = rid[rl];
+  bool keep[MT];
+  int grow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    keep[mt] = keepf[32 * mt + rl] != 0;
+    grow[mt] = rid[32 * mt + rl];
+  }
   __syncthreads();
-  f32x16 acc[1];
-  f32x4 bvr[4], y[4];
+  f32x16 acc[MT];
+  f32x4 bvr[4], y[MT][4];
   const bf16_t* wps[3] = {frag_ptr(Wp, 0, w, 16, lane), frag_ptr(W0, 0, w, 16, lane), frag_ptr(W1, 0, w, 16, lane)};
   const int sws[3] = {swp, sw0, sw1};
 #pragma unroll
   for (int st = 0; st < 3; ++st) {
-    stage_h2<1, 16, PLP, 2>(act, SPLANE, 0, wps[st], 65536, acc, (rot + 5 * st) & 15, lane);
+    stage_h2<MT, 16, PLP, 2>(act, SPLANE, 0, wps[st], 65536, acc, (rot + 5 * st) & 15, lane);
     load_bias(bias_l + 256 * st + 32 * w, bvr, lane);
-    const int un = -(rs[rl] + sws[st]);
-    float m = 0.f;
+    float m[MT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int mt = 0; mt < MT; ++mt) {
+      const int un = -(rs[32 * mt + rl] + sws[st]);
+      m[mt] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float v = __builtin_ldexpf(acc[0][4 * g + t], un) + bvr[g][t];
-        y[g][t] = st == 0 ? (keep ? v : 0.f) : fmaxf(v, 0.f);
-        m = fmaxf(m, fabsf(y[g][t]));
-      }
-    if (st == 0) {
-      // attn rows -> global, exactly the fp32 values (16 bytes per lane and column group)
-      if (grow >= 0) {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(attn + (long)grow * 256 + 32 * w + 8 * g + 4 * h) = y[g];
+        for (int t = 0; t < 4; ++t) {
+          const float v = __builtin_ldexpf(acc[mt][4 * g + t], un) + bvr[g][t];
+          y[mt][g][t] = st == 0 ? (keep[mt] ? v : 0.f) : fmaxf(v, 0.f);
+          m[mt] = fmaxf(m[mt], fabsf(y[mt][g][t]));
+        }
+      if (st == 0 && grow[mt] >= 0) {
+        // attn rows -> global, exactly the fp32 values (16 bytes per lane and column group)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(attn + (long)grow[mt] * 256 + 32 * w + 8 * g + 4 * h) = y[mt][g];
       }
     }
     if (st < 2) {
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (h == 0) pm[rl * 8 + w] = m;
-      __syncthreads();                                   // every wavefront has read the planes and rs; the partial maxima are complete
-      const f32x4 p0 = *reinterpret_cast<const f32x4*>(pm + rl * 8), p1 = *reinterpret_cast<const f32x4*>(pm + rl * 8 + 4);
-      const float mr = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
-      const int sr = row_scale(mr);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 xs;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(y[g][t], sr);
-        uint2 ph, pl;
-        split4_h2(xs, ph, pl);
-        *reinterpret_cast<uint2*>(act + rl * PLP + (32 * w + 8 * g + 4 * h) * 2) = ph;
-        *reinterpret_cast<uint2*>(act + SPLANE + rl * PLP + (32 * w + 8 * g + 4 * h) * 2) = pl;
+      for (int mt = 0; mt < MT; ++mt) {
+        m[mt] = fmaxf(m[mt], __shfl_xor(m[mt], 32, 64));
+        if (h == 0) pm[(32 * mt + rl) * 8 + w] = m[mt];
       }
-      if (w == 0 && h == 0) rs[rl] = sr;
+      __syncthreads();                                   // every wavefront has read the planes and rs; the partial maxima are complete
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = 32 * mt + rl;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pm + row * 8), p1 = *reinterpret_cast<const f32x4*>(pm + row * 8 + 4);
+        const float mr = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+        const int sr = row_scale(mr);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 xs;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(y[mt][g][t], sr);
+          uint2 ph, pl;
+          split4_h2(xs, ph, pl);
+          *reinterpret_cast<uint2*>(act + row * PLP + (32 * w + 8 * g + 4 * h) * 2) = ph;
+          *reinterpret_cast<uint2*>(act + SPLANE + row * PLP + (32 * w + 8 * g + 4 * h) * 2) = pl;
+        }
+        if (w == 0 && h == 0) rs[row] = sr;
+      }
       __syncthreads();
     }
   }
-  // last layer (3 outputs, dq_decoder.py:97-111's third Linear): this lane's 16 columns of row rl, the two halves of the wavefront
+  // last layer (3 outputs, dq_decoder.py:97-111's third Linear): this lane's 16 columns of its rows, the two halves of the wavefront
   // combined, the 8 wavefronts' partial sums through LDS in wavefront order
   {
-    float a3[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float s0 = 0.f;
+    for (int mt = 0; mt < MT; ++mt) {
+      float a3[3];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 wk = *reinterpret_cast<const f32x4*>(w2l + k * 256 + 32 * w + 8 * g + 4 * h);
-        s0 += (y[g][0] * wk[0] + y[g][1] * wk[1]) + (y[g][2] * wk[2] + y[g][3] * wk[3]);
+      for (int k3 = 0; k3 < 3; ++k3) {
+        float s0 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 wk = *reinterpret_cast<const f32x4*>(w2l + k3 * 256 + 32 * w + 8 * g + 4 * h);
+          s0 += (y[mt][g][0] * wk[0] + y[mt][g][1] * wk[1]) + (y[mt][g][2] * wk[2] + y[mt][g][3] * wk[3]);
+        }
+        a3[k3] = s0 + __shfl_xor(s0, 32, 64);
       }
-      a3[k] = s0 + __shfl_xor(s0, 32, 64);
+      if (mt == 0) __syncthreads();                      // every wavefront is through the last stage's k loop: the planes are free
+      if (h == 0) *reinterpret_cast<f32x4*>(po + ((32 * mt + rl) * 8 + w) * 4) = f32x4{a3[0], a3[1], a3[2], 0.f};
     }
-    // (pm's maxima of the second stage were read in front of that stage's last barrier)
-    if (h == 0) *reinterpret_cast<f32x4*>(pm + (rl * 8 + w) * 4) = f32x4{a3[0], a3[1], a3[2], 0.f};
     __syncthreads();
     if (tid < RMS && rid[tid] >= 0) {
       float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int ww = 0; ww < 8; ++ww) {
-        const f32x4 pp = *reinterpret_cast<const f32x4*>(pm + (tid * 8 + ww) * 4);
+        const f32x4 pp = *reinterpret_cast<const f32x4*>(po + (tid * 8 + ww) * 4);
         t0 += pp[0];
         t1 += pp[1];
         t2 += pp[2];
@@ -1651,6 +1670,7 @@ int cu_count() {
 int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two workgroups per CU (default: cfg-2 184 -> 140 us in the forward), 64 = one
                           // persistent 64-row workgroup per CU, 31 = the 32-row kernel with a 2-deep fragment ring
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
+int g_f32h_a_rows = 0;    // tuning knob "f32h_a_rows": rows per tile of mvg_chain_attn_pose_f32h (0 = by the row count | 32 | 64); both sum a row identically
 int g_f32h_pair = 1;      // tuning knob "f32h_pair": mvg_pyramid_f32h as two workgroups per CU (no row prefetch, fragment ring 2)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
 
@@ -1692,11 +1712,19 @@ extern "C" int mvg_chain_attn_pose_f32h(const float* samp, const uint8_t* inside
   if ((reinterpret_cast<uintptr_t>(samp) | reinterpret_cast<uintptr_t>(attn) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(W0) |
        reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2)) % 16 != 0)
     return MVG_E_BADARG;
-  const size_t lds = 2 * 32 * PLP + 3 * 32 * sizeof(int) + 32 * 8 * 4 * sizeof(float) + 2 * 768 * sizeof(float);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&chain_a_f32h_small_kernel, lds, configured)) return rc;
-  hipLaunchKernelGGL(chain_a_f32h_small_kernel, dim3((rows + 31) / 32), dim3(NT), lds, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp, bp,
-                     (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, wp_scale, w0_scale, w1_scale, attn, o, order, o_masked, rows);
+  static bool configured[MVG_MAX_DEVICES] = {}, configured2[MVG_MAX_DEVICES] = {};
+  // both tile sizes sum a row identically: 64-row tiles (half the fragment loads per row) once they fill the CUs
+  if (g_f32h_a_rows == 64 || (g_f32h_a_rows == 0 && (rows + 63) / 64 >= cu_count())) {
+    const size_t lds = 2 * 64 * PLP + 3 * 64 * sizeof(int) + 64 * 8 * sizeof(float) + 2 * 768 * sizeof(float);
+    if (int rc = configure_lds(&chain_a_f32h_small_kernel<2>, lds, configured2)) return rc;
+    hipLaunchKernelGGL(chain_a_f32h_small_kernel<2>, dim3((rows + 63) / 64), dim3(NT), lds, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp,
+                       bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, wp_scale, w0_scale, w1_scale, attn, o, order, o_masked, rows);
+  } else {
+    const size_t lds = 2 * 32 * PLP + 3 * 32 * sizeof(int) + 32 * 8 * sizeof(float) + 2 * 768 * sizeof(float);
+    if (int rc = configure_lds(&chain_a_f32h_small_kernel<1>, lds, configured)) return rc;
+    hipLaunchKernelGGL(chain_a_f32h_small_kernel<1>, dim3((rows + 31) / 32), dim3(NT), lds, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp,
+                       bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, wp_scale, w0_scale, w1_scale, attn, o, order, o_masked, rows);
+  }
   MVG_LAUNCH_CHECK();
   return 0;
 }

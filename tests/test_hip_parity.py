@@ -1839,6 +1839,14 @@ def test_fp32_chains_on_two_part_fp16_operands():
         assert bool((o[inside == 0] == o_masked).all()) and bool((attn[inside == 0] == 0).all())
         res[key] = (attn, o)
     assert torch.equal(res["plain"][0], res["ordered"][0]) and torch.equal(res["plain"][1], res["ordered"][1])   # tile membership does not matter
+    from mvgformer_amd import _lib
+    for r in (32, 64):                                            # nor does the tile size (the launcher picks it by the row count)
+        try:
+            assert _lib.load().mvg_set_tuning(b"f32h_a_rows", r) == 0
+            attn, o = ops.chain_attn_pose_f32h(samp, inside, *wts, order=order, o_masked=o_masked)
+        finally:
+            assert _lib.load().mvg_set_tuning(b"f32h_a_rows", 0) == 0
+        assert torch.equal(attn, res["ordered"][0]) and torch.equal(o, res["ordered"][1])
     # ---- chain B
     B, NQ, J, V = 1, 41, 15, 3
     rows = B * NQ * J
