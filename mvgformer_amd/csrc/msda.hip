@@ -186,6 +186,99 @@ __global__ __launch_bounds__(256) void msda_fwd_hp_kernel(
   }
 }
 
+// D = 32 (the decoder's head width): msda_fwd_hp_kernel with the per-sample arithmetic shared out.  There all 8 lanes of a (query, head)
+// unit compute every sample's coordinates, zero padding and weights; here lane `sub` prepares sample s0 + sub of a batch of 8 (one
+// location / weight load per lane instead of eight identical ones) and the lanes fetch each other's results with ds_swizzle (crossbar
+// only), as msda_gfused_f32_hp_kernel's second pass does.  Same operations in the same order per sample: identical outputs.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_hp8_kernel(
+    const T* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ starts,
+    const float* __restrict__ loc, const float* __restrict__ wgt, T* __restrict__ out,
+    int N, int S, int M, int L, int Lq, int P, int n_qblocks) {
+  constexpr int D = 32, QPB = 32;
+  const long row_stride = (long)M * D;
+  const long n_blocks = (long)N * n_qblocks * M;
+  const int sub = threadIdx.x & 7, qs = threadIdx.x >> 3;
+  const int LP = L * P;
+#define MVG_SW8(K, X) __builtin_amdgcn_ds_swizzle((X), 24 | ((K) << 5))      /* value of lane K of every group of 8 lanes */
+  for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int m = (int)(blk % M);
+    const long t = blk / M;
+    const int q = (int)(t % n_qblocks) * QPB + qs;
+    const int n = (int)(t / n_qblocks);
+    if (q >= Lq) continue;                               // whole 8-lane groups
+    const long qm = ((long)n * Lq + q) * M + m;
+    const float* locp = loc + qm * LP * 2;
+    const float* wp = wgt + qm * LP;
+    const T* vbase = value + (long)n * S * row_stride + (long)m * D + sub * 4;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < LP; s0 += 8) {
+      int my_w[4], my_s, my_t, my_b, my_x;
+      {
+        const int sidx = min(s0 + sub, LP - 1);
+        const int l = sidx / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const float2 lxy = *reinterpret_cast<const float2*>(locp + sidx * 2);
+        const float aw = wp[sidx];
+        float h_im = lxy.y * (float)H - 0.5f;   // cuh:295
+        float w_im = lxy.x * (float)W - 0.5f;   // cuh:296
+        const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W) && (s0 + sub < LP);
+        h_im = index_safe(h_im, (float)H);
+        w_im = index_safe(w_im, (float)W);
+        const float hl_f = floorf(h_im), wl_f = floorf(w_im);
+        const int h_low = (int)hl_f, w_low = (int)wl_f;
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hl_f, lw = w_im - wl_f;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        my_s = __float_as_int(inside ? aw : 0.f);
+        const bool hl_ok = h_low >= 0, hh_ok = h_high <= H - 1, wl_ok = w_low >= 0, wh_ok = w_high <= W - 1;
+        my_w[0] = __float_as_int((hl_ok && wl_ok) ? hh * hw : 0.f);
+        my_w[1] = __float_as_int((hl_ok && wh_ok) ? hh * lw : 0.f);
+        my_w[2] = __float_as_int((hh_ok && wl_ok) ? lh * hw : 0.f);
+        my_w[3] = __float_as_int((hh_ok && wh_ok) ? lh * lw : 0.f);
+        const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_high, 0), H - 1);
+        const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_high, 0), W - 1);
+        const int st = (int)starts[l];
+        my_t = (st + hl_c * W + wl_c) * (int)row_stride;
+        my_b = (st + hh_c * W + wl_c) * (int)row_stride;
+        my_x = (wh_c - wl_c) * (int)row_stride;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float cw[4][4], sc[4];
+        f32x4 raw[4][4];
+#define MVG_FW8(S_, K)                                                                   \
+        {                                                                                \
+          const int et = MVG_SW8(K, my_t), eb = MVG_SW8(K, my_b), ex = MVG_SW8(K, my_x); \
+          cw[S_][0] = __int_as_float(MVG_SW8(K, my_w[0]));                               \
+          cw[S_][1] = __int_as_float(MVG_SW8(K, my_w[1]));                               \
+          cw[S_][2] = __int_as_float(MVG_SW8(K, my_w[2]));                               \
+          cw[S_][3] = __int_as_float(MVG_SW8(K, my_w[3]));                               \
+          sc[S_] = __int_as_float(MVG_SW8(K, my_s));                                     \
+          raw[S_][0] = Vec4<T>::load(vbase + et);                                        \
+          raw[S_][1] = Vec4<T>::load(vbase + (et + ex));                                 \
+          raw[S_][2] = Vec4<T>::load(vbase + eb);                                        \
+          raw[S_][3] = Vec4<T>::load(vbase + (eb + ex));                                 \
+        }
+        if (half == 0) {
+          MVG_FW8(0, 0) MVG_FW8(1, 1) MVG_FW8(2, 2) MVG_FW8(3, 3)
+        } else {
+          MVG_FW8(0, 4) MVG_FW8(1, 5) MVG_FW8(2, 6) MVG_FW8(3, 7)
+        }
+#undef MVG_FW8
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 val = cw[k][0] * raw[k][0] + cw[k][1] * raw[k][1] + cw[k][2] * raw[k][2] + cw[k][3] * raw[k][3];
+          acc4 += val * sc[k];
+        }
+      }
+    }
+    Vec4<T>::store(out + qm * D + sub * 4, acc4);
+  }
+#undef MVG_SW8
+}
+
 // fp64 drop-in (the `double` case of AT_DISPATCH_FLOATING_TYPES, deform_cuda.cu:75: gradcheck-style calls): one thread
 // per (n, q, m, channel), everything in double.  No fast path -- nothing on the decoder's inference path is fp64.
 __global__ __launch_bounds__(256) void msda_fwd_f64_kernel(
@@ -286,7 +379,7 @@ __global__ __launch_bounds__(256) void msda_bwd_f64_kernel(
   }
 }
 
-static int g_fwd_map = 1;          // tuning knob "fwd_map": mvg_msda_forward, 0 = a wavefront takes the M heads of a query, 1 = one head per workgroup
+static int g_fwd_map = 1;          // tuning knob "fwd_map": mvg_msda_forward, 0 = a wavefront takes the M heads of a query, 1 = one head per workgroup (D = 32: per-sample arithmetic shared out over the unit's 8 lanes), 2 = one head per workgroup, every lane computes every sample
 template <typename T>
 static int launch_msda_fwd(const T* value, const int64_t* shapes, const int64_t* starts, const float* loc,
                            const float* wgt, T* out, int N, int S, int M, int D, int L, int Lq, int P,
@@ -298,12 +391,16 @@ static int launch_msda_fwd(const T* value, const int64_t* shapes, const int64_t*
   const int block = 256;
   long grid = (total + block - 1) / block;
   if (grid > (1L << 22)) grid = 1L << 22;
-  if (vec && g_fwd_map == 1 && 256 % (D / 4) == 0) {
+  if (vec && g_fwd_map >= 1 && 256 % (D / 4) == 0) {
     const int qpb = 256 / (D / 4), n_qblocks = (Lq + qpb - 1) / qpb;
     long blocks = (long)N * n_qblocks * M;
     if (blocks > (1L << 22)) blocks = (1L << 22) / M * M;        // grid-stride, a whole number of heads per stride
-    hipLaunchKernelGGL((msda_fwd_hp_kernel<T>), dim3((unsigned)blocks), dim3(block), 0, st, value, shapes, starts, loc, wgt, out, N, S,
-                       M, D, L, Lq, P, n_qblocks);
+    if (D == 32 && g_fwd_map == 1 && (long)S * M * D < (1L << 31))
+      hipLaunchKernelGGL((msda_fwd_hp8_kernel<T>), dim3((unsigned)blocks), dim3(block), 0, st, value, shapes, starts, loc, wgt, out, N, S,
+                         M, L, Lq, P, n_qblocks);
+    else
+      hipLaunchKernelGGL((msda_fwd_hp_kernel<T>), dim3((unsigned)blocks), dim3(block), 0, st, value, shapes, starts, loc, wgt, out, N, S,
+                         M, D, L, Lq, P, n_qblocks);
   } else if (vec)
     hipLaunchKernelGGL((msda_fwd_kernel<T, 4>), dim3((unsigned)grid), dim3(block), 0, st, value, shapes, starts, loc,
                        wgt, out, N, S, M, D, L, Lq, P);
@@ -1422,7 +1519,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
-  if (!strcmp(key, "fwd_map") && (value == 0 || value == 1)) { g_fwd_map = value; return 0; }
+  if (!strcmp(key, "fwd_map") && (value >= 0 && value <= 2)) { g_fwd_map = value; return 0; }
   if (!strcmp(key, "gfused_chunk") && value >= 0 && value <= 4096) { g_gfused_chunk = value; return 0; }
   if (!strcmp(key, "gfused_map") && (value == 0 || value == 1)) { g_gfused_map = value; return 0; }
   if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }

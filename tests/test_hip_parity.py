@@ -1631,7 +1631,8 @@ def test_every_kernel_variant_behind_a_tuning_knob(key, value, exact):
                                              (1, 5, 2, 64, 1, 5, torch.float32), (2, 50, 3, 24, 2, 4, torch.float32)])
 def test_forward_operator_mappings_agree_bit_for_bit(N, Lq, M, D, L, P, dt):
     """mvg_msda_forward (Deformable.deform_forward's drop-in): fwd_map = 1 (default: one head per workgroup, loads in batches of 4
-    samples; needs 256 % (D / 4) == 0, other D fall back) against fwd_map = 0 (a wavefront takes a query's heads): identical outputs,
+    samples, for D = 32 every lane of a unit prepares one sample of a batch of 8; needs 256 % (D / 4) == 0, other D fall back), 2 (the
+    same without sharing the per-sample arithmetic) and 0 (a wavefront takes a query's heads): identical outputs,
     with locations that leave the maps, L * P not a multiple of the batch and query counts that do not fill the last workgroup."""
     from mvgformer_amd import _lib
     from mvgformer_amd import deformable as DF
@@ -1645,12 +1646,12 @@ def test_forward_operator_mappings_agree_bit_for_bit(N, Lq, M, D, L, P, dt):
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=gen), -1).view(N, Lq, M, L, P).to(DEV)
     out = {}
     try:
-        for mp in (1, 0):
+        for mp in (1, 2, 0):
             assert lib.mvg_set_tuning(b"fwd_map", mp) == 0
             out[mp] = DF.deform_forward(value, shapes.to(DEV), starts.to(DEV), loc, attn, 64).clone()
     finally:
         assert lib.mvg_set_tuning(b"fwd_map", 1) == 0
-    assert torch.equal(out[0], out[1])
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
 
 
 @pytest.mark.parametrize("cfg,kw", [("cfg2", dict(NQ=160, layers=2)), ("cfg4", dict(layers=2)), ("cfg2", dict(NQ=3, layers=1))],

@@ -28,7 +28,7 @@ wh = shapes.flip(-1).float().view(1, 1, 1, L, 1, 2)
 loc = (ref + ray / wh + 0.002 * torch.randn(N, Lq, M, L, P, 2, device="cuda")).contiguous()
 attn = torch.softmax(torch.randn(N, Lq, M, L * P, device="cuda"), -1).view(N, Lq, M, L, P).contiguous()
 res = {}
-for mp in (0, 1):
+for mp in (0, 2, 1):
     assert lib.mvg_set_tuning(b"fwd_map", mp) == 0
     for _ in range(3):
         out = DF.deform_forward(value, shapes, starts, loc, attn, 64)
@@ -41,4 +41,4 @@ for mp in (0, 1):
     torch.cuda.synchronize()
     res[mp] = out.clone()
     print("fwd_map=%d  %s  %.1f us per call (N=%d images, %d queries, %d heads x %d levels x %d points)" % (mp, str(dt)[6:], e0.elapsed_time(e1) / 20 * 1e3, N, Lq, M, L, P))
-print("identical:", torch.equal(res[0], res[1]))
+print("identical:", torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]))
