@@ -1426,7 +1426,10 @@ __device__ __forceinline__ void write_row_h2(char* __restrict__ planes, int plan
   }
 }
 
-__global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
+// MT = 1: 32-row tiles, two workgroups per CU (128 registers, fragment ring 2).  MT = 2: 64-row tiles, one workgroup per CU (135 KB, 256
+// registers, ring 4) -- half the fragment loads per row, six MFMAs per wavefront and k-step.  Same chunks, same order per row: bit-identical.
+template <int MT>
+__global__ __launch_bounds__(NT, MT == 1 ? 4 : 2) void chain_b_f32h_kernel(
     const float* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu, int su,
     const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
     const bf16_t* __restrict__ W1, int s1, const float* __restrict__ b1, const bf16_t* __restrict__ W2, int s2,
@@ -1435,7 +1438,7 @@ __global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
     float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
     const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, int sn, const float* __restrict__ bn,
     float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
-  constexpr int RMT = 32, APL = RMT * PLP;
+  constexpr int RMT = 32 * MT, APL = RMT * PLP, RB = MT == 1 ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                   // 2 planes x 32 rows x 256 columns: mean, then t1, then tgt' + query_pos
   char* hb = smem + 2 * APL;                          // 2 planes x 32 rows x 256 columns: FFN hidden chunk
@@ -1452,9 +1455,12 @@ __global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
   const int rot = (w * 3) & 15;
   const int colb = 32 * w, col0 = colb + 4 * h;       // the wavefront's column block; this lane's first column
 
-  f32x4 tg[4];
+  f32x4 tg[MT][4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) tg[g] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(rl, nrow - 1)) * 256 + col0 + 8 * g);
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      tg[mt][g] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(32 * mt + rl, nrow - 1)) * 256 + col0 + 8 * g);
 
   // ---- mean over views (dq_decoder.py:770) -> planes; chunk i of a thread = 4 columns of row 8 i + w (a wavefront holds a whole row)
   {
@@ -1498,104 +1504,128 @@ __global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
   __syncthreads();
 
   // ---- t1 = LN2(tgt + feature_update_mlp(mean))   (dq_decoder.py:773-778)
-  f32x16 acc[1];
-  f32x4 bvr[4], t1[1][4];
-  stage_h2<1, 16, PLP, 2>(act, APL, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, rot, lane);
+  f32x16 acc[MT];
+  f32x4 bvr[4], t1[MT][4];
+  stage_h2<MT, 16, PLP, RB>(act, APL, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, rot, lane);
   load_bias(bu + colb, bvr, lane);
-  {
-    const int un = -(rs[rl] + su);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int un = -(rs[32 * mt + rl] + su);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) t1[0][g][t] = __builtin_ldexpf(acc[0][4 * g + t], un) + bvr[g][t];
-      if (rl < nrow) t1[0][g] += tg[g];
+      for (int t = 0; t < 4; ++t) t1[mt][g][t] = __builtin_ldexpf(acc[mt][4 * g + t], un) + bvr[g][t];
+      if (32 * mt + rl < nrow) t1[mt][g] += tg[mt][g];
     }
   }
-  layernorm_rows<1>(t1, g2 + colb, be2 + colb, part, part2, lane, w);      // (its first barrier: every wavefront is done reading `act` and rs)
-  {
-    const float m = absmax16(t1[0]);
-    if (h == 0) pm[rl * 8 + w] = m;
+  layernorm_rows<MT>(t1, g2 + colb, be2 + colb, part, part2, lane, w);     // (its first barrier: every wavefront is done reading `act` and rs)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const float m = absmax16(t1[mt]);
+    if (h == 0) pm[(32 * mt + rl) * 8 + w] = m;
   }
   __syncthreads();
-  {
-    const int sr = gather_scale(pm, rl);
-    write_row_h2(act, APL, rl, col0, t1[0], sr);
-    if (w == 0 && h == 0) rs[rl] = sr;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = 32 * mt + rl, sr = gather_scale(pm, row);
+    write_row_h2(act, APL, row, col0, t1[mt], sr);
+    if (w == 0 && h == 0) rs[row] = sr;
   }
   __syncthreads();
 
-  f32x4 y[1][4];
+  f32x4 y[MT][4];
   if (has_ffn) {
     // ---- FFN (mvp_decoder.py:94-98): Y = sum over the 4 hidden chunks of relu(t1 W1^T + b1)[chunk] W2[:, chunk]^T
-    f32x4 ysum[4];
+    f32x4 ysum[MT][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) ysum[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ysum[mt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* wp2 = frag_ptr(W2, 0, w, 64, lane);
-    const int un1 = -(rs[rl] + s1);
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
-      f32x4 hid[4];
-      stage_h2<1, 16, PLP, 2>(act, APL, 0, frag_ptr(W1, c, w, 16, lane), 1024 * 256, acc, (w * 5) & 15, lane);
+      f32x4 hid[MT][4];
+      stage_h2<MT, 16, PLP, RB>(act, APL, 0, frag_ptr(W1, c, w, 16, lane), 1024 * 256, acc, (w * 5) & 15, lane);
       load_bias(b1 + c * 256 + colb, bvr, lane);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int un1 = -(rs[32 * mt + rl] + s1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) hid[g][t] = fmaxf(__builtin_ldexpf(acc[0][4 * g + t], un1) + bvr[g][t], 0.f);
-      {
-        const float m = absmax16(hid);
-        if (h == 0) pm[rl * 8 + w] = m;
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) hid[mt][g][t] = fmaxf(__builtin_ldexpf(acc[mt][4 * g + t], un1) + bvr[g][t], 0.f);
+        const float m = absmax16(hid[mt]);
+        if (h == 0) pm[(32 * mt + rl) * 8 + w] = m;
       }
       __syncthreads();                                              // the previous chunk's second GEMM has read hb and rsh; maxima complete
-      {
-        const int sr = gather_scale(pm, rl);
-        write_row_h2(hb, APL, rl, col0, hid, sr);
-        if (w == 0 && h == 0) rsh[rl] = sr;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = 32 * mt + rl, sr = gather_scale(pm, row);
+        write_row_h2(hb, APL, row, col0, hid[mt], sr);
+        if (w == 0 && h == 0) rsh[row] = sr;
       }
       __syncthreads();
-      stage_h2<1, 16, PLP, 2>(hb, APL, 0, wp2 + (long)c * 16 * 1024, 256 * 1024, acc, rot, lane);
-      const int un2 = -(rsh[rl] + s2);
+      stage_h2<MT, 16, PLP, RB>(hb, APL, 0, wp2 + (long)c * 16 * 1024, 256 * 1024, acc, rot, lane);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int un2 = -(rsh[32 * mt + rl] + s2);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ysum[g][t] += __builtin_ldexpf(acc[0][4 * g + t], un2);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ysum[mt][g][t] += __builtin_ldexpf(acc[mt][4 * g + t], un2);
+      }
     }
     load_bias(b2 + colb, bvr, lane);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) y[0][g] = (ysum[g] + bvr[g]) + t1[0][g];
-    layernorm_rows<1>(y, g3 + colb, be3 + colb, part, part2, lane, w);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) y[mt][g] = (ysum[mt][g] + bvr[g]) + t1[mt][g];
+    layernorm_rows<MT>(y, g3 + colb, be3 + colb, part, part2, lane, w);
   } else {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) y[0][g] = t1[0][g];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) y[mt][g] = t1[mt][g];
   }
 
   // ---- tgt' -> global; class head (dq_decoder.py:889-893): per-row logits, completed across the wavefronts
   {
-    float a0 = 0.f, a1 = 0.f;
+    float c0[MT], c1[MT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (rl < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + rl) * 256 + col0 + 8 * g) = y[0][g];
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + col0 + 8 * g);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + col0 + 8 * g);
-      a0 += (y[0][g][0] * w0[0] + y[0][g][1] * w0[1]) + (y[0][g][2] * w0[2] + y[0][g][3] * w0[3]);
-      a1 += (y[0][g][0] * w1[0] + y[0][g][1] * w1[1]) + (y[0][g][2] * w1[2] + y[0][g][3] * w1[3]);
-    }
-    a0 += __shfl_xor(a0, 32, 64);
-    a1 += __shfl_xor(a1, 32, 64);
-    __syncthreads();                                                // part / part2 of the last LayerNorm have been read
-    if (h == 0) {
-      part[rl * 8 + w] = a0;
-      part2[rl * 8 + w] = a1;
-    }
-    // the maxima of tgt' + query_pos for the next layer's query term ride on the same barrier
-    f32x4 z[4];
-    if (Wn) {
+    for (int mt = 0; mt < MT; ++mt) {
+      float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        z[g] = y[0][g];
-        if (qpos) z[g] += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(rl, nrow - 1)) * 256 + col0 + 8 * g);
+        if (32 * mt + rl < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + 32 * mt + rl) * 256 + col0 + 8 * g) = y[mt][g];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + col0 + 8 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + col0 + 8 * g);
+        a0 += (y[mt][g][0] * w0[0] + y[mt][g][1] * w0[1]) + (y[mt][g][2] * w0[2] + y[mt][g][3] * w0[3]);
+        a1 += (y[mt][g][0] * w1[0] + y[mt][g][1] * w1[1]) + (y[mt][g][2] * w1[2] + y[mt][g][3] * w1[3]);
       }
-      const float m = absmax16(z);
-      if (h == 0) pm[rl * 8 + w] = m;
+      c0[mt] = a0 + __shfl_xor(a0, 32, 64);
+      c1[mt] = a1 + __shfl_xor(a1, 32, 64);
+    }
+    __syncthreads();                                                // part / part2 of the last LayerNorm have been read
+    if (h == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        part[(32 * mt + rl) * 8 + w] = c0[mt];
+        part2[(32 * mt + rl) * 8 + w] = c1[mt];
+      }
+    }
+    // the maxima of tgt' + query_pos for the next layer's query term ride on the same barrier
+    f32x4 z[MT][4];
+    if (Wn) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          z[mt][g] = y[mt][g];
+          if (qpos) z[mt][g] += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(32 * mt + rl, nrow - 1)) * 256 + col0 + 8 * g);
+        }
+        const float m = absmax16(z[mt]);
+        if (h == 0) pm[(32 * mt + rl) * 8 + w] = m;
+      }
     }
     __syncthreads();
     if (tid < RMT) {
@@ -1603,9 +1633,12 @@ __global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
       pr[2 * tid + 1] = 1.f / (1.f + expf(-(row_total(part2, tid) + bc[1])));
     }
     if (Wn) {        // every wavefront passed the barriers above: `act` and rs are free
-      const int sr = gather_scale(pm, rl);
-      write_row_h2(act, APL, rl, col0, z, sr);
-      if (w == 0 && h == 0) rs[rl] = sr;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = 32 * mt + rl, sr = gather_scale(pm, row);
+        write_row_h2(act, APL, row, col0, z[mt], sr);
+        if (w == 0 && h == 0) rs[row] = sr;
+      }
     }
     __syncthreads();
     if (tid < qpt && q0 + tid < nq_total) {
@@ -1626,16 +1659,19 @@ __global__ __launch_bounds__(NT, 4) void chain_b_f32h_kernel(
   }
   if (Wn && colb < n_next) {
     // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets / logits Linear (projattn.py:180-181)
-    stage_h2<1, 16, PLP, 2>(act, APL, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, (rot + 7) & 15, lane);
+    stage_h2<MT, 16, PLP, RB>(act, APL, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, (rot + 7) & 15, lane);
     load_bias(bn + colb, bvr, lane);
-    const int un = -(rs[rl] + sn);
-    if (rl < nrow) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int un = -(rs[32 * mt + rl] + sn);
+      if (32 * mt + rl < nrow) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = __builtin_ldexpf(acc[0][4 * g + t], un) + bvr[g][t];
-        *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + rl) * n_next + col0 + 8 * g) = v;
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = __builtin_ldexpf(acc[mt][4 * g + t], un) + bvr[g][t];
+          *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + 32 * mt + rl) * n_next + col0 + 8 * g) = v;
+        }
       }
     }
   }
@@ -1670,6 +1706,7 @@ int cu_count() {
 int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two workgroups per CU (default: cfg-2 184 -> 140 us in the forward), 64 = one
                           // persistent 64-row workgroup per CU, 31 = the 32-row kernel with a 2-deep fragment ring
 int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
+int g_f32h_b_rows = 0;    // tuning knob "f32h_b_rows": rows per tile of mvg_chain_update_ffn_class_f32h (0 = by the row count | 32 | 64)
 int g_f32h_a_rows = 0;    // tuning knob "f32h_a_rows": rows per tile of mvg_chain_attn_pose_f32h (0 = by the row count | 32 | 64); both sum a row identically
 int g_f32h_pair = 1;      // tuning knob "f32h_pair": mvg_pyramid_f32h as two workgroups per CU (no row prefetch, fragment ring 2)
 int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
@@ -1689,14 +1726,24 @@ extern "C" int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const f
     if (sc < -100 || sc > 100) return MVG_E_BADARG;
   const int nq_total = B * NQ, rows = nq_total * J;
   if (rows == 0) return 0;
-  const int qpt = 32 / J;
-  const size_t lds = 4 * 32 * PLP + (3 * 32 * 8 + 32 * 2) * sizeof(float) + 2 * 32 * sizeof(int);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&chain_b_f32h_kernel, lds, configured)) return rc;
-  hipLaunchKernelGGL(chain_b_f32h_kernel, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, (hipStream_t)stream, attn, V, tgt,
-                     (const bf16_t*)Wu, wu_scale, bu, g2, be2, (const bf16_t*)W1, w1_scale, b1, (const bf16_t*)W2, w2_scale, b2, g3, be3, Wc,
-                     bc, threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, wn_scale, b_next,
-                     xw_next, n_next, rows, J, nq_total, has_ffn);
+  // both tile sizes sum a row identically: 64-row tiles (one workgroup per CU, fragment ring 4) unless they would leave a quarter of
+  // the CUs without a workgroup (then 32-row tiles, two workgroups per CU)
+  const int tiles64 = (nq_total + 64 / J - 1) / (64 / J);
+  const bool big = J <= 32 && (g_f32h_b_rows == 64 || (g_f32h_b_rows == 0 && tiles64 > (cu_count() * 3) / 4));
+  static bool configured[MVG_MAX_DEVICES] = {}, configured2[MVG_MAX_DEVICES] = {};
+#define MVG_CBH(MTV, CFG)                                                                                                              \
+  {                                                                                                                                    \
+    constexpr int R = 32 * MTV;                                                                                                        \
+    const int qpt = R / J;                                                                                                             \
+    const size_t lds = 4 * R * PLP + (3 * R * 8 + R * 2) * sizeof(float) + 2 * R * sizeof(int);                                        \
+    if (int rc = configure_lds(&chain_b_f32h_kernel<MTV>, lds, CFG)) return rc;                                                        \
+    hipLaunchKernelGGL(chain_b_f32h_kernel<MTV>, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, (hipStream_t)stream, attn, V, tgt,   \
+                       (const bf16_t*)Wu, wu_scale, bu, g2, be2, (const bf16_t*)W1, w1_scale, b1, (const bf16_t*)W2, w2_scale, b2, g3,  \
+                       be3, Wc, bc, threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next,        \
+                       wn_scale, b_next, xw_next, n_next, rows, J, nq_total, has_ffn);                                                 \
+  }
+  if (big) MVG_CBH(2, configured2) else MVG_CBH(1, configured)
+#undef MVG_CBH
   MVG_LAUNCH_CHECK();
   return 0;
 }

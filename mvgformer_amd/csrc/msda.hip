@@ -1478,6 +1478,7 @@ extern int g_f32s_b_rows;
 extern int g_f32s_a_rows;
 extern int g_f32h_pair;
 extern int g_f32h_a_rows;
+extern int g_f32h_b_rows;
 extern int g_f32s_pyr_ws;
 extern int g_tri_lanes;
 extern int g_linear_xcd;
@@ -1505,6 +1506,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "f32s_grid") && value >= 0 && value <= 4096) { g_f32s_grid = value; return 0; }
   if (!strcmp(key, "f32s_pyr_ws") && (value == 0 || value == 1)) { g_f32s_pyr_ws = value; return 0; }
   if (!strcmp(key, "f32s_a_rows") && (value == 31 || value == 32 || value == 64)) { g_f32s_a_rows = value; return 0; }
+  if (!strcmp(key, "f32h_b_rows") && (value == 0 || value == 32 || value == 64)) { g_f32h_b_rows = value; return 0; }
   if (!strcmp(key, "f32h_a_rows") && (value == 0 || value == 32 || value == 64)) { g_f32h_a_rows = value; return 0; }
   if (!strcmp(key, "f32h_pair") && (value == 0 || value == 1)) { g_f32h_pair = value; return 0; }
   if (!strcmp(key, "f32s_b_rows") && (value == 0 || value == 32 || value == 64)) { g_f32s_b_rows = value; return 0; }

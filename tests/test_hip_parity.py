@@ -1865,7 +1865,16 @@ def test_fp32_chains_on_two_part_fp16_operands():
     assert float((out[0].double() - y).abs().max()) < 2e-5 and float((out[1].double() - pr).abs().max()) < 1e-6
     assert float((out[4].double() - lin64(y + qpos.double(), Wn, bn)).abs().max()) < 3e-5
     assert bool((out[2].bool() == (pr[..., 1] > 0.5)).all())
-    # the persons in another order: every person's rows are unchanged (a tile is 2 persons)
+    # both tile sizes (the launcher picks by the row count): identical
+    from mvgformer_amd import _lib as _l
+    for r in (32, 64):
+        try:
+            assert _l.load().mvg_set_tuning(b"f32h_b_rows", r) == 0
+            outr = ops.chain_update_ffn_class_f32h(attn, V, tgt, *args, 0.5, B, NQ, J, next_query_proj=nxt)
+        finally:
+            assert _l.load().mvg_set_tuning(b"f32h_b_rows", 0) == 0
+        assert all(torch.equal(a, b) for a, b in zip(outr, out))
+    # the persons in another order: every person's rows are unchanged (a tile is 2 or 4 persons)
     perm = torch.randperm(NQ, generator=gen).to(DEV)
     rperm = (perm[:, None] * J + torch.arange(J, device=DEV)[None]).reshape(-1)
     out2 = ops.chain_update_ffn_class_f32h(attn.view(V, rows, 256)[:, rperm].reshape(V * rows, 256).contiguous(), V, tgt[rperm].contiguous(), *args, 0.5, B, NQ, J,
