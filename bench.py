@@ -37,6 +37,24 @@ def algorithmic_bytes_per_view_layer(S, C, Lq, M, L, P, elem):
     return S * C * elem + Lq * M * L * P * 2 * elem + Lq * M * L * P * elem + Lq * C * elem
 
 
+def dense_flops(S, C, Lq, M, L, P, F, V, B, layers, exec_rows_a=None):
+    """SURVEY.md section 8(d), dense (MFMA) regime, per forward.  nominal: the reference's decomposition -- value, offsets and
+    logits Linears on the gathered rows, output projection, pose MLP (all pairs), update Linear, FFN.  executed: what this
+    build's bf16 / fp32 kernels multiply -- the offsets / logits Linear applied to the pyramid (G, V*S rows instead of V*Lq*L) +
+    the query term (Lq rows), chain A on the rows of the tiles it does not skip (exec_rows_a per layer; None = all pairs)."""
+    per_view = 2 * S * C * C + 2 * Lq * L * C * (M * P * 2) + 2 * Lq * L * C * (M * P) + 2 * Lq * C * C + 2 * Lq * (2 * C * C + 3 * C)
+    nominal = layers * B * (V * per_view + 2 * Lq * C * C + 4 * Lq * C * F)
+    rows_a = [V * B * Lq] * layers if exec_rows_a is None else list(exec_rows_a)
+    value = 2 * V * B * S * C * C
+    g = 2 * V * B * S * C * (M * P * 3)
+    xw = 2 * B * Lq * C * (M * P * 3)
+    chain_a = [2 * r * (3 * C * C + 3 * C) for r in rows_a]
+    chain_b = 2 * B * Lq * (C * C + 2 * C * F + 2 * C)
+    executed = layers * (value + g + xw + chain_b) + sum(chain_a)
+    return {"nominal": nominal, "executed": executed, "value": value, "G": g, "query_term": xw,
+            "chain_a": sum(chain_a) / max(len(chain_a), 1), "chain_b": chain_b}
+
+
 SAMPLER_SOURCES = ("mvgformer_amd/csrc/msda.hip", "mvgformer_amd/csrc/gsamp_dev.h", "mvgformer_amd/csrc/common.h",
                    "mvgformer_amd/csrc/sampchain.hip", "mvgformer_amd/csrc/chain_dev.h")
 
@@ -97,7 +115,63 @@ SAMPLER_KERNELS = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_
 # the workloads measured next to the headline in the driver's one command: (name, config, dtype, inside, batch)
 SECONDARY = (("cfg2_fp32", "cfg2", "fp32", "grid", 1), ("cfg4_fp32", "cfg4", "fp32", "grid", 1),
              ("cfg2_bf16_inside_all", "cfg2", "bf16", "all", 1), ("cfg5_bf16", "cfg5", "bf16", "grid", 1),
-             ("cfg2_bf16_batch2", "cfg2", "bf16", "grid", 2), ("cfg2_bf16_batch4", "cfg2", "bf16", "grid", 4))
+             ("cfg2_bf16_batch2", "cfg2", "bf16", "grid", 2), ("cfg2_bf16_batch4", "cfg2", "bf16", "grid", 4),
+             ("cfg2_bf16_valid10", "cfg2", "bf16", "valid10", 1))
+FP32_FORM = "2xfp16x3"      # fp32 kernels: operands as two fp16 parts x a power-of-two scale, three fp16 MFMA products, fp32 accumulation
+
+
+def measure_train_step(dev, steps=5, warmup=2):
+    """cfg-2 fp32 training step (run/train_3d.py's decoder share): forward under autograd + backward to every
+    parameter of the 4-layer decoder, `steps` timed steps after `warmup`, then a finite-gradient check and the kernel launches
+    of one step (torch.profiler device activities)."""
+    import gc
+    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
+    from mvgformer_amd.synthetic import build_case
+    case = build_case("cfg2", seed=0)
+    dec = build_decoder_for_case(case, dev, torch.float32)
+    g = case_to_device(case, dev)
+    for p in dec.parameters():
+        p.requires_grad_(True)
+    dec.train()
+
+    def step():
+        for p in dec.parameters():
+            p.grad = None
+        out = dec(g.tgt, g.reference_points, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None,
+                  query_pos=g.query_pos, threshold=0.1)
+        loss = out[0].float().pow(2).mean() + 1e-6 * out[1].float().pow(2).mean() + sum(c.float().sum() for c in out[4]) * 1e-3
+        loss.backward()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    params = list(dec.parameters())
+    grads = [p.grad for p in params if p.grad is not None]
+    finite = int(torch.isfinite(torch.stack(torch._foreach_norm(grads))).sum())
+    launches = None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        launches = sum(1 for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA"))
+    except Exception as e:      # the count is a diagnostic
+        launches = "n/a (%s)" % type(e).__name__
+    rec = {"workload": "cfg2: training step of the 4-layer decoder, fp32, forward under autograd + backward to every parameter",
+           "dtype": "fp32", "fp32_form": FP32_FORM, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "value": round(steps / elapsed, 3), "unit": "steps/s", "hip_graph": False, "loss": round(float(loss), 5),
+           "parameters_with_finite_gradients": "%d / %d" % (finite, len(grads)), "parameters": len(params), "device_activities_per_step": launches,
+           "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    assert finite == len(grads) and finite > 0, "non-finite gradients"
+    del dec, g, case, grads, params, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
 
 
 def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3, profile_steps=2):
@@ -111,7 +185,8 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3
     from mvgformer_amd.synthetic import build_case
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     elem = 2 if dtype_name == "bf16" else 4
-    case = build_case(config, B=batch, seed=0, ref_extent=0.3 if inside == "all" else 1.0)
+    case = build_case(config, B=batch, seed=0, ref_extent=0.3 if inside == "all" else 1.0,
+                      valid_fraction=0.1 if inside == "valid10" else None)
     dec = build_decoder_for_case(case, dev, dtype)
     g = case_to_device(case, dev)
     ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, batch, dev)
@@ -130,12 +205,18 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3
         for _ in range(warmup):
             graph.replay()
         torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        evs[0].record()
+        for i in range(steps):
             graph.replay()
+            evs[i + 1].record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        median = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
         assert torch.isfinite(out[1]).all(), "non-finite poses"
+        valid_share = float((out[4][-1][..., 1] > 0.1).float().mean())
         saved, ops.PROFILE = ops.PROFILE, {}
         overlap, dec.overlap_pyramid = dec.overlap_pyramid, False
         for _ in range(profile_steps):
@@ -147,10 +228,14 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3
     bytes_launch = batch * case.V * algorithmic_bytes_per_view_layer(S, 256, case.NQ * 15, 8, len(case.shapes), 8, elem)
     key = next((k for k in SAMPLER_KERNELS if k in prof), None)
     rec = {"workload": "%s: %d views, %d queries x 15 joints, %d layers, maps %s x 256ch, batch %d, initial poses %s"
-                       % (config, case.V, case.NQ, case.layers, case.shapes, batch, inside),
+                       % (config, case.V, case.NQ, case.layers, case.shapes, batch,
+                          "grid, ~10 % of the queries pass the 0.1 threshold" if inside == "valid10" else inside),
            "dtype": dtype_name, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "ms_per_step_median": round(median, 4),
            "ms_per_sample": round(elapsed / steps / batch * 1e3, 4), "value": round(batch * steps / elapsed, 3),
-           "unit": "samples/s", "hip_graph": True}
+           "unit": "samples/s", "hip_graph": True, "valid_query_share_last_layer": round(valid_share, 4)}
+    if dtype_name == "fp32":
+        rec["fp32_form"] = FP32_FORM
     if key is not None:
         us = prof[key][1] * 1e3
         rec.update({"sampler_kernel": SAMPLER_KERNELS[key], "sampler_us": round(us, 2),
@@ -502,13 +587,21 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # every step also gets its own HIP-event pair on the launch stream (median of the device-synchronised
+        # iterations); the wall clock around all K steps stays the contract's timed region and gives `value`
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.inflight == 1 else None
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        if evs:
+            evs[0].record()
+        for i in range(args.steps):
             step()
+            if evs:
+                evs[i + 1].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)) if evs else None
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -517,6 +610,7 @@ def main():
         # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
         prof = {}
         live_frac = None
+        exec_rows_a = None
         if sharded:
             mdist.install_any_valid_sync(dec, None)
         if args.profile_steps > 0:                 # every rank runs it (the sharded forward contains collectives)
@@ -535,6 +629,7 @@ def main():
             # fraction of (image, query) pairs inside their image, per sampling launch (the others are skipped): one more eager
             # forward, outside the timed pass, for the L1-path figure of the roofline object
             live_fracs = []
+            exec_rows_a = []        # per sampling launch: rows of the 128-row chain-A tiles that hold an in-image pair (per image)
             originals = {}
 
             def counting(name):
@@ -544,6 +639,8 @@ def main():
                     mask = kw.get("pair_mask", a[6] if (name == "msda_gsamp_chain" and len(a) > 6) else None)
                     if mask is not None:
                         live_fracs.append(mask.float().mean())
+                        per_img = mask.view(args.batch * V, -1).sum(1, dtype=torch.int64)
+                        exec_rows_a.append(((per_img + 127) // 128 * 128).clamp(max=mask.numel() // (args.batch * V)).sum())
                     return orig(*a, **kw)
                 setattr(ops, name, wrapped)
             for name in ("msda_gsamp", "msda_gfused_f32", "msda_gsamp_chain"):
@@ -556,6 +653,21 @@ def main():
                     setattr(ops, name, orig)
             dec.overlap_pyramid = overlap
             live_frac = float(torch.stack(live_fracs).mean()) if live_fracs else None
+            exec_rows_a = [int(x) for x in exec_rows_a] if len(exec_rows_a) == Ly else None
+            # the grouped pyramid products of the timed schedule (DQDecoder.launch_pyramid_projections), each launch alone
+            if rank == 0 and hasattr(dec, "_pyramid_groups") and ctx.feat is not None and ctx.feat.dtype == torch.bfloat16:
+                groups = dec._pyramid_groups(ctx)
+                if groups:
+                    ops.PROFILE = {}
+                    for _ in range(args.profile_steps):
+                        for grp in groups:
+                            jobs = []
+                            for layer in grp:
+                                jobs += layer.proj_attn.pyramid_jobs(ctx.feat)
+                            ops.pyramid_group_ws(ctx.feat, jobs)
+                    torch.cuda.synchronize()
+                    prof.update(ops.profile_summary())
+                    ops.PROFILE = None
 
     default_headline = (args.config == "cfg2" and args.dtype == "bf16" and args.queries is None and args.valid_fraction is None
                         and args.inside == "grid" and args.inflight == 1 and args.batch == 1 and args.producer == "nchw")
@@ -576,7 +688,12 @@ def main():
 
     refs = out[1]
     assert torch.isfinite(refs).all(), "non-finite poses"
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_mean = elapsed / args.steps * 1e3
+    if step_ms and world == 1:
+        n = len(step_ms)
+        ms_per_step = step_ms[n // 2] if n % 2 else 0.5 * (step_ms[n // 2 - 1] + step_ms[n // 2])
+    else:
+        ms_per_step = ms_mean          # N > 1: the contract's max-over-ranks wall clock
     value = (world if replicas else 1) * args.inflight * args.batch * args.steps / elapsed   # samples / s of the whole job
 
     # roofline of the dominant kernel: one sampling-kernel launch covers all V views of one layer
@@ -651,6 +768,36 @@ def main():
                                "frac": round(delivered / (ms * 1e-3) / 1e9 / l1_peak, 4),
                                "note": "binding roof of the gather kernel: what the L1s deliver to 16-byte-per-lane gathers (one wave "
                                        "instruction per 16 clk, tools/probes/l1_gather_probe); pairs outside their image are skipped"}
+    # the MFMA regime: dense flops of the forward against the dense bf16 peak (2.5 PF; the fp32 path's kernels
+    # run three fp16 MFMA products per fp32 product: priced at their fp32-equivalent flops against the same peak)
+    roof_mfma = None
+    if prof:
+        fl = dense_flops(S, 256, Lq_loc, 8, len(case.shapes), 8, 1024, V, args.batch, Ly, exec_rows_a)
+        per_kernel = {}
+
+        def add(name, key, gflop, launches_per_forward):
+            if key in prof and prof[key][1] > 0:
+                us = prof[key][1] * 1e3
+                per_kernel[name] = {"gflop": round(gflop / 1e9, 2), "us": round(us, 2), "tflops": round(gflop / us / 1e6, 1),
+                                    "frac": round(gflop / us / 1e6 / 2500.0, 4), "launches_per_forward": launches_per_forward}
+        add("chain_a", "chain_attn_pose", fl["chain_a"], Ly)
+        add("chain_b", "chain_update_ffn_class", fl["chain_b"] + fl["query_term"], Ly)
+        add("chain_a", "chain_attn_pose_f32s", fl["chain_a"], Ly)                     # fp32: the two-part fp16 kernels (same profile key)
+        add("chain_b", "chain_update_ffn_class_f32s", fl["chain_b"] + fl["query_term"], Ly)
+        add("pyramid_value_and_G", "pyramid_f32s", fl["value"] + fl["G"], Ly)
+        add("value_proj", "value_proj_ws", fl["value"], Ly)
+        add("feat_linear", "feat_linear_ws", fl["G"], Ly)
+        add("pyramid_group_first_layer", "pyramid_group_ws_2", fl["value"] + fl["G"], 1)
+        for nj in (4, 6, 8):
+            add("pyramid_group_%d_layers" % (nj // 2), "pyramid_group_ws_%d" % nj, (fl["value"] + fl["G"]) * (nj // 2), 1)
+        roof_mfma = {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "flops_nominal": fl["nominal"], "flops_executed": fl["executed"],
+                     "flops_per_step": fl["executed"], "achieved_tflops": round(fl["executed"] / (ms_per_step * 1e-3) / 1e12, 1),
+                     "frac": round(fl["executed"] / (ms_per_step * 1e-3) / 1e12 / 2500.0, 4),
+                     "nominal_tflops": round(fl["nominal"] / (ms_per_step * 1e-3) / 1e12, 1), "per_kernel": per_kernel,
+                     "note": "whole forward: executed dense flops / ms_per_step; per kernel: each launch timed alone (HIP events).  "
+                             "nominal = SURVEY 8(d)'s table (reference decomposition); executed = this build's GEMMs: the offsets / "
+                             "logits Linear on the pyramid (G) + the query term instead of on V*Lq*L gathered rows, chain A only on "
+                             "tiles with an in-image pair; chain_b includes the next layer's query term"}
     kern = {k: {"launches": n, "avg_us": round(ms * 1e3, 2)} for k, (n, ms) in sorted(prof.items())}
     # per-rank time split (kernel time per forward from the eager profile pass, each kernel alone): "fixed" = work that does
     # not shrink when the queries are sharded (pyramid packing + the query-independent pyramid GEMMs, replicated on every
@@ -658,10 +805,13 @@ def main():
     split = None
     if prof and args.profile_steps > 0:
         n_pyr = args.batch * V * S          # rows of the pyramid GEMMs: query-independent whatever the path (fp32: plain linears)
-        fixed_keys = ("pack_level", "pack_level_nhwc", "value_proj_ws", "feat_linear_ws", "pyramid_all_layers", "pyramid_f32s",
+        grouped = any(k.startswith("pyramid_group_ws_") for k in prof)    # the timed schedule's launches replace the per-product ones
+        fixed_keys = ("pack_level", "pack_level_nhwc", "pyramid_all_layers", "pyramid_f32s") + (
+            tuple(k for k in prof if k.startswith("pyramid_group_ws_")) if grouped else ("value_proj_ws", "feat_linear_ws")) + (
                       "linear_%dx256x256" % n_pyr, "linear_%dx192x256" % n_pyr)
+        skip = ("value_proj_ws", "feat_linear_ws") if grouped else ()
         fx = sum(n * ms for k, (n, ms) in prof.items() if k in fixed_keys) / args.profile_steps
-        var = sum(n * ms for k, (n, ms) in prof.items() if k not in fixed_keys) / args.profile_steps
+        var = sum(n * ms for k, (n, ms) in prof.items() if k not in fixed_keys and k not in skip) / args.profile_steps
         split = {"fixed_us": round(fx * 1e3, 1), "variable_us": round(var * 1e3, 1),
                  "note": "rank 0, kernels timed one at a time; fixed = replicated query-independent work"}
 
@@ -676,6 +826,14 @@ def main():
                 secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
+        try:
+            t_sec = time.perf_counter()
+            secondary["train_step_cfg2_fp32"] = measure_train_step(dev)
+            secondary["train_step_cfg2_fp32"]["wall_s"] = round(time.perf_counter() - t_sec, 1)
+        except Exception as e:
+            secondary["train_step_cfg2_fp32"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
 
     cpu = None
     if cpu_case is not None:
@@ -706,7 +864,11 @@ def main():
         "metric": "decoder samples/sec (5-view, 1024 queries, 4 layers)" if (args.config in ("cfg2", "cfg3") and args.queries is None)
         else "decoder samples/sec (%s)" % args.config,
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "ms_per_step": round(ms_per_step, 4), "ms_per_step_mean": round(ms_mean, 4),
+        "ms_per_step_note": "ms_per_step = median of the K per-step HIP-event intervals on the launch stream (1 GPU; SURVEY 8(d)); "
+                            "ms_per_step_mean = wall clock of the timed region / K, what `value` is computed from",
+        "ms_per_step_min_max": None if not step_ms else [round(step_ms[0], 4), round(step_ms[-1], 4)],
+        "higher_is_better": True,
         "scaling": "strong" if sharded else ("weak" if replicas else None),
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: %d views, %d queries x %d joints, %d decoder layers, maps %s x 256ch, "
@@ -730,7 +892,7 @@ def main():
                                      "exact": "v_mfma_f32_32x32x2_f32 (fmaf chain)"}[args.f32_gemm]}
                       if args.dtype == "fp32" else {}),
                    "hip_graph": graph is not None, "device": arch, "cus": cus},
-        "roofline": roof, "cpu_baseline": cpu, "rank_time_split": split, "kernels": kern,
+        "roofline": roof, "roofline_mfma": roof_mfma, "cpu_baseline": cpu, "rank_time_split": split, "kernels": kern,
         "secondary": secondary or None, "rccl": rccl,
     }
     print(json.dumps(line))

@@ -234,6 +234,15 @@ int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, con
 int mvg_value_proj_planes_ws(const void* feat, const void* Wf, const float* bias, void* vh, int n_img, int S,
                              void* stream);
 int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
+/* Several of the two products above over the SAME packed pyramid in ONE launch (round 5): job j is a value projection into head
+ * planes (planes[j] != 0: N[j] = 256, bias[j] required, out[j] = vh) or a G product (planes[j] == 0: N[j] = 192, bias ignored,
+ * out[j] = G row-major).  The host arrays hold njobs (1..8) entries.  An XCD's workgroups are divided among the jobs and sweep
+ * its row tiles together, so the pyramid is fetched through the fabric once per launch instead of once per product; every
+ * output is bit-identical to the single-product entry points (same kernel body).  slots_per_xcd: persistent workgroups per
+ * XCD (0 = the default: all 64 resident ones; fewer leave CU room for kernels that run next to the launch).
+ * projattn.py:169,180-181 for all layers. */
+int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njobs, const void* const* Wf, const float* const* bias,
+                         void* const* out, const int* N, const int* planes, int slots_per_xcd, void* stream);
 int mvg_msda_gsamp(const void* vh, const void* G, const float* xw, const float* ref_lvl,
                    const int64_t* shapes_host, const int64_t* starts_host, void* samp,
                    const uint8_t* pair_mask, const int32_t* order,

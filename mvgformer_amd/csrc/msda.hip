@@ -1487,6 +1487,7 @@ extern int g_chain_a_waves;
 extern int g_chain_split;
 extern int g_chain_ring;
 extern int g_wreg_grid;
+extern int g_wreg_gweight;
 extern int g_auto_small_b;
 extern int g_auto_small_a;
 extern int g_bin_multi;
@@ -1513,6 +1514,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128 || value == 256)) { g_chain_rm = value; return 0; }
   if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
+  if (!strcmp(key, "wreg_gweight") && value >= 100 && value <= 400) { g_wreg_gweight = value; return 0; }
   if (!strcmp(key, "bin_multi") && (value == 0 || value == 1)) { g_bin_multi = value; return 0; }
   if (!strcmp(key, "sampchain_map") && value >= 1 && value <= 4096) { g_sampchain_map = value; return 0; }
   if (!strcmp(key, "sampchain_mode") && value >= 0 && value <= 2) { g_sampchain_mode = value; return 0; }

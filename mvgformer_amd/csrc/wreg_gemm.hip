@@ -41,10 +41,10 @@ struct WregParams {
 // N = 64 * NCPT columns.  Every thread issues the SAME number of stores for every tile (chunks of rows past the end
 // of the matrix are redirected to re-write the last valid row's chunk with identical bytes), so the compiler can
 // give the loads of a later tile an exact vmcnt instead of vmcnt(0).
+// The persistent loop of one workgroup: row tiles first_tile, first_tile + tile_stride, ... of job `p`.
 template <int NCPT>
-__global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
+__device__ __forceinline__ void wreg_body(const WregParams& p, char* smem, const int first_tile, const int tile_stride) {
   constexpr bool PLANES = NCPT == 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                   // RM x 256 bf16 A tile
   char* stage0 = smem + RM * ACT_PITCH;               // 2 x (RM x 256 bf16) output tiles (double-buffered)
   float* bias_s = reinterpret_cast<float*>(smem + 3 * RM * ACT_PITCH);   // 256 f32
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   // loads(t+2), and because every iteration issues a fixed number of each, the wait at the top of t+1 is an exact
   // vmcnt(stores + loads), not vmcnt(0) -- a full iteration of latency hiding for every load.
   static_assert(NCH == 4, "prefetch registers are written out for 4 chunks per thread");
-  const int G = gridDim.x;
-  uint4 xa0 = load_chunk(blockIdx.x, 0), xa1 = load_chunk(blockIdx.x, 1), xa2 = load_chunk(blockIdx.x, 2),
-        xa3 = load_chunk(blockIdx.x, 3);
-  uint4 xb0 = load_chunk(blockIdx.x + G, 0), xb1 = load_chunk(blockIdx.x + G, 1), xb2 = load_chunk(blockIdx.x + G, 2),
-        xb3 = load_chunk(blockIdx.x + G, 3);
+  const int G = tile_stride;
+  uint4 xa0 = load_chunk(first_tile, 0), xa1 = load_chunk(first_tile, 1), xa2 = load_chunk(first_tile, 2),
+        xa3 = load_chunk(first_tile, 3);
+  uint4 xb0 = load_chunk(first_tile + G, 0), xb1 = load_chunk(first_tile + G, 1), xb2 = load_chunk(first_tile + G, 2),
+        xb3 = load_chunk(first_tile + G, 3);
   int it = 0, prev_tile = -1;
 
 #define WREG_ITERATION(X0, X1, X2, X3)                                                                           \
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   }
 
 #pragma unroll 1
-  for (int tile = blockIdx.x; tile < ntiles; tile += 2 * G) {
+  for (int tile = first_tile; tile < ntiles; tile += 2 * G) {
     WREG_ITERATION(xa0, xa1, xa2, xa3)
     tile += G;
     if (tile >= ntiles) break;
@@ -165,6 +165,49 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
   }
 #undef WREG_ITERATION
   if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);
+}
+
+template <int NCPT>
+__global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wreg_body<NCPT>(p, smem, blockIdx.x, gridDim.x);
+}
+
+// ---- several products of the SAME rows in one launch (round 5) -------------------------------------------------------------
+// All layers' value planes and G are products of the one packed pyramid with different weights.  Launched one after the other,
+// every product streams the 103-MB pyramid through the fabric again (8 x per forward at cfg-2).  Here the workgroups of an XCD
+// (block b runs on XCD b & 7 -- observed dispatch order, used for speed only) are divided among the jobs in proportion to their
+// column counts; every job sweeps the XCD's row tiles (tiles t = 8 u + xcd) in the same order and at the same pace, so a tile
+// fetched by the first job's workgroup is served to the others by the XCD's L2: the pyramid crosses the fabric once per launch.
+// A workgroup keeps ONE job's weight slice in registers for its whole life exactly like wreg_gemm_kernel -- same loop, same k
+// order, bit-identical outputs.
+constexpr int WREG_MAX_JOBS = 8;
+constexpr int WREG_MAX_SLOTS = 64;       // workgroups per XCD: 32 CUs x 2
+struct WregJob {
+  const bf16_t* Wf;
+  const float* bias;
+  void* out;
+  int N, rowmajor;
+};
+struct WregGroupParams {
+  const bf16_t* A;
+  int M, S_img, njobs, n_slots;
+  WregJob job[WREG_MAX_JOBS];
+  unsigned char slot_job[WREG_MAX_SLOTS];   // job of slot s = blockIdx >> 3
+  unsigned char slot_idx[WREG_MAX_SLOTS];   // index of the slot among its job's slots
+  unsigned char job_slots[WREG_MAX_JOBS];   // slots per XCD of job j
+};
+
+__global__ __launch_bounds__(256, 2) void wreg_group_kernel(WregGroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int j = gp.slot_job[slot];
+  WregParams p;
+  p.A = gp.A; p.M = gp.M; p.S_img = gp.S_img;
+  p.Wf = gp.job[j].Wf; p.bias = gp.job[j].bias; p.out = gp.job[j].out; p.N = gp.job[j].N; p.rowmajor = gp.job[j].rowmajor;
+  const int first = gp.slot_idx[slot] * 8 + xcd, stride = gp.job_slots[j] * 8;
+  if (!p.rowmajor) wreg_body<0>(p, smem, first, stride);
+  else wreg_body<3>(p, smem, first, stride);
 }
 
 int launch_wreg(const WregParams& p, hipStream_t st) {
@@ -202,4 +245,50 @@ extern "C" int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int
   p.A = (const bf16_t*)feat; p.Wf = (const bf16_t*)Wf; p.bias = nullptr; p.out = G;
   p.M = n_img * S; p.N = N; p.S_img = S; p.rowmajor = 1;
   return launch_wreg(p, (hipStream_t)stream);
+}
+
+int g_wreg_gweight = 300;   // tuning knob "wreg_gweight": share of an XCD's workgroups a 192-column job gets, x100 (a 256-column job: 400)
+
+extern "C" int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njobs, const void* const* Wf, const float* const* bias,
+                                    void* const* out, const int* N, const int* planes, int slots_per_xcd, void* stream) {
+  if (!feat || !Wf || !bias || !out || !N || !planes || n_img <= 0 || S <= 0 || njobs < 1 || njobs > WREG_MAX_JOBS) return MVG_E_BADARG;
+  WregGroupParams gp = {};
+  gp.A = (const bf16_t*)feat; gp.M = n_img * S; gp.S_img = S; gp.njobs = njobs;
+  int weight[WREG_MAX_JOBS], total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!Wf[j] || !out[j]) return MVG_E_BADARG;
+    if (planes[j] ? (N[j] != 256 || !bias[j]) : N[j] != 192) return MVG_E_BADARG;     // the two shapes the decoder has
+    gp.job[j].Wf = (const bf16_t*)Wf[j]; gp.job[j].bias = bias[j]; gp.job[j].out = out[j];
+    gp.job[j].N = N[j]; gp.job[j].rowmajor = planes[j] ? 0 : 1;
+    weight[j] = planes[j] ? 400 : g_wreg_gweight;
+    total += weight[j];
+  }
+  // slots per XCD in proportion to the jobs' work; never more than the 64 resident workgroups of an XCD
+  const int ntiles = (gp.M + RM - 1) / RM;
+  int budget = slots_per_xcd > 0 ? slots_per_xcd : g_wreg_grid / 8;
+  if (budget > WREG_MAX_SLOTS) budget = WREG_MAX_SLOTS;
+  if (budget > (ntiles + 7) / 8 * njobs) budget = (ntiles + 7) / 8 * njobs;
+  if (budget < njobs) budget = njobs;
+  int n_slots = 0;
+  for (int j = 0; j < njobs; ++j) {
+    int c = budget * weight[j] / total;
+    if (c < 1) c = 1;
+    gp.job_slots[j] = (unsigned char)c;
+    n_slots += c;
+  }
+  if (n_slots > WREG_MAX_SLOTS) return MVG_E_BADARG;
+  // interleave the jobs over the slots (slot s and s + 32 tend to share a CU)
+  int given[WREG_MAX_JOBS] = {0}, s = 0;
+  while (s < n_slots)
+    for (int j = 0; j < njobs && s < n_slots; ++j)
+      if (given[j] < gp.job_slots[j]) {
+        gp.slot_job[s] = (unsigned char)j;
+        gp.slot_idx[s] = (unsigned char)given[j]++;
+        ++s;
+      }
+  gp.n_slots = n_slots;
+  const size_t lds = 3 * RM * ACT_PITCH + 256 * sizeof(float);
+  hipLaunchKernelGGL(wreg_group_kernel, dim3(8 * n_slots), dim3(256), lds, (hipStream_t)stream, gp);
+  MVG_LAUNCH_CHECK();
+  return 0;
 }

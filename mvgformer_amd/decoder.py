@@ -789,6 +789,11 @@ class DQDecoder(MvPDecoder):
         # view groups (PyramidPipeline): MVG_VIEW_GROUP = views per group (0 = off, the default: measured SLOWER at cfg-5, 15.7 ->
         # 16.3-17.7 ms, with the sampler's FETCH_SIZE unchanged -- profiles/r04_experiments.txt; "auto" = 3 views once one layer's
         # value planes + G exceed the Infinity Cache), MVG_VIEW_GROUP_DEPTH = groups produced ahead of the sampler
+        # bf16: layers per grouped launch of the pyramid products behind layer 0's own (0 = one launch per product, rounds 1-4)
+        self.pyramid_group = int(os.environ.get("MVG_PYRAMID_GROUP", "3"))
+        # pack the pyramid on the side stream in front of its consumers: the first layer's query-side prologue (projection, pair
+        # binning, query term) then runs next to the pack instead of behind it
+        self.pack_on_side = os.environ.get("MVG_PACK_ON_SIDE", "1") != "0"
         self.view_group = os.environ.get("MVG_VIEW_GROUP", "0")
         self.view_group_depth = int(os.environ.get("MVG_VIEW_GROUP_DEPTH", "2"))
 
@@ -833,21 +838,69 @@ class DQDecoder(MvPDecoder):
         g = int(self.view_group)
         return g if 0 < g < ctx.V else 0
 
-    def launch_pyramid_projections(self, ctx, side=None):
+    def launch_pyramid_projections(self, ctx, side=None, forked=False):
         """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
         by an event its consumer waits on.  Returns the side stream (pass it to join_pyramid_projections before
-        the forward / the captured graph ends) or None when the projections run inline."""
+        the forward / the captured graph ends) or None when the projections run inline.  forked: `side` already waits for
+        whatever produced ctx.feat (pack_pyramid)."""
         if side is None:
             side = self.fork_side_stream(ctx.feat.device)
             if side is None:
                 return None
-        else:
+        elif not forked:
             side.wait_stream(torch.cuda.current_stream())       # the packed pyramid
         ctx.feat.record_stream(side)
         with torch.cuda.stream(side):
-            for layer in self.layers:
-                layer.proj_attn.project_pyramid(ctx.feat, record_event=True)
+            groups = self._pyramid_groups(ctx)
+            if groups is None:
+                for layer in self.layers:
+                    layer.proj_attn.project_pyramid(ctx.feat, record_event=True)
+            else:
+                # bf16 fast path: layer 0's value planes + G in one launch (the first sampler waits for nothing else), then the
+                # remaining layers' products in launches of `pyramid_group` layers: every launch reads the pyramid through the
+                # fabric once (ops.pyramid_group_ws); 8 reads of 103 MB per forward at cfg-2 become 2.  These launches fill every
+                # CU (2 x 239 registers per SIMD lane) and so does the sampler: next to each other they run one after the other,
+                # whatever the issue order -- issuing a group behind the sampler in front of it, or with half the workgroups,
+                # measured slower (profiles/r05_experiments.txt), so everything is issued here, up front.
+                for group in groups:
+                    jobs = []
+                    for layer in group:
+                        jobs += layer.proj_attn.pyramid_jobs(ctx.feat)
+                    ops.pyramid_group_ws(ctx.feat, jobs)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    for layer in group:
+                        layer.proj_attn._vp_event = ev
         return side
+
+    def pack_pyramid(self, ctx, src_views, side):
+        """ctx.pack(src_views) -- on the side stream (forked from the current one) when every consumer of the packed pyramid runs
+        there (bf16: the pyramid products), so that the first layer's prologue does not queue behind the 46-us pack; follow it
+        with launch_pyramid_projections(ctx, side, forked=True)."""
+        if side is not None and self.pack_on_side and ctx.dtype == torch.bfloat16:
+            with torch.cuda.stream(side):
+                ctx.pack(src_views)
+        else:
+            ctx.pack(src_views)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+
+    def _pyramid_groups(self, ctx):
+        """layers whose pyramid products share one launch (bf16 fast path), or None for one launch pair per layer"""
+        if self.pyramid_group <= 0 or ctx.feat.dtype != torch.bfloat16 or ctx.feat.shape[2] != 256:
+            return None
+        if not all(l.proj_attn.uses_fast_path(torch.bfloat16) and l.proj_attn.rayconv.weight.shape == (256, 256) for l in self.layers):
+            return None
+        layers = list(self.layers)
+        groups = [layers[:1]]
+        rest = layers[1:]
+        per = min(self.pyramid_group, 4)            # 2 jobs per layer, at most 8 per launch
+        while rest:
+            # equal-sized launches: 5 remaining layers at 3 per launch run as 3 + 2
+            n = -(-len(rest) // -(-len(rest) // per))
+            groups.append(rest[:n])
+            rest = rest[n:]
+        return groups
 
     def join_pyramid_projections(self, side, keep_results=False):
         """The current stream waits for the side stream.  keep_results: projections not consumed yet stay valid for
@@ -877,26 +930,30 @@ class DQDecoder(MvPDecoder):
         side = pipeline = None
         hs_buf = flags = geo_buf = None
         try:
+            deferred_pack = None
             if ctx is None:
-                ctx = DecoderContext.build(src_views, src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
-                                           layer0.compute_dtype, tgt.shape[0])
+                ctx = DecoderContext.prepare(src_spatial_shapes, src_level_start_index, meta, layer0.img_size,
+                                             layer0.compute_dtype, tgt.shape[0], src_views[0].device)
+                deferred_pack = src_views
             elif src_views is not None:
                 # a prepared context is reused across frames (static cameras): the pyramid is re-packed from THIS
                 # call's src_views every time (a no-op for levels produced in place in ctx.pyramid_buffers())
-                ctx.pack(src_views)
+                deferred_pack = src_views
             elif ctx.feat is None:
                 raise RuntimeError("DQDecoder.forward: context without a packed pyramid and no src_views")
             ctx.order = None
             inter, inter_ref, inter_2d, inter_proj, classes = [], [], [], [], []
             ref_points_2d = None
             side = self.fork_side_stream(tgt.device, (tgt.shape[1], ctx.levels.L, ctx.levels.S))
+            if deferred_pack is not None:
+                self.pack_pyramid(ctx, deferred_pack, side)
             pipeline = None
             if side is not None:
                 group = self._view_group_size(ctx)
                 if group:
                     pipeline = PyramidPipeline(self.layers, ctx.feat, ctx.feat.shape[0], group * ctx.B, self.view_group_depth, side)
                 else:
-                    self.launch_pyramid_projections(ctx, side)
+                    self.launch_pyramid_projections(ctx, side, forked=True)
             # the fused chain writes every layer's hidden state straight into its slice of the stacked output
             hs_buf = None
             if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:

@@ -185,9 +185,11 @@ class GraphedShardedDecoder:
             # every layer's pyramid-side GEMMs (replicated on all ranks: they bound the strong scaling) are issued on
             # the side stream in this segment, next to layer 0's query-side kernels; the later segments find them done
             side = self.dec.fork_side_stream(self.tgt.device) if hasattr(self.dec, "fork_side_stream") else None
-            self.ctx.pack(self.src)
             if side is not None:
-                self.dec.launch_pyramid_projections(self.ctx, side)
+                self.dec.pack_pyramid(self.ctx, self.src, side)
+                self.dec.launch_pyramid_projections(self.ctx, side, forked=True)
+            else:
+                self.ctx.pack(self.src)
             st0 = layers[0].forward_features(self.tgt, self.qpos, ref, self.ctx, self.thr)
             if side is not None:
                 self.dec.join_pyramid_projections(side, keep_results=True)
@@ -256,9 +258,11 @@ class SpeculativeShardedDecoder:
                 layer._next_layer = (layers[l + 1],) if (fuse and l + 1 < len(layers)) else None
                 layer._xw_in = None
             side = dec.fork_side_stream(tgt.device) if hasattr(dec, "fork_side_stream") else None
-            ctx.pack(src_views)
             if side is not None:
-                dec.launch_pyramid_projections(ctx, side)
+                dec.pack_pyramid(ctx, src_views, side)
+                dec.launch_pyramid_projections(ctx, side, forked=True)
+            else:
+                ctx.pack(src_views)
             outs = []
             st = layers[0].forward_features(tgt, query_pos, ref, ctx, threshold)
             for l, layer in enumerate(layers):

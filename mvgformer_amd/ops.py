@@ -412,6 +412,28 @@ def feat_linear_ws(feat, w_frag, N=192, out=None):
     return G
 
 
+def pyramid_group_ws(feat, jobs, slots=0):
+    """Several weight-stationary products of the same packed bf16 pyramid in one launch (mvg_pyramid_group_ws): jobs = list of
+    (w_frag, bias or None, out, planes) -- planes: value projection into head planes (out = vh (n_img, 8, S, 32)), else
+    G = feat @ W^T row-major (out (n_img*S, 192)).  Outputs bit-identical to value_proj_planes_ws / feat_linear_ws.
+    slots: workgroups per XCD (0 = the library default, all 64 resident ones; fewer leave room for kernels running next to it)."""
+    n_img, S, K = feat.shape
+    n = len(jobs)
+    assert 1 <= n <= 8 and K == 256 and feat.dtype == torch.bfloat16 and feat.is_contiguous()
+    for w, b, out, planes in jobs:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == n_img * S * (256 if planes else 192)
+        assert w.dtype == torch.bfloat16 and w.numel() == 256 * 256 and (b is not None or not planes)
+    vpp = C.c_void_p * n
+    Wf = vpp(*[w.data_ptr() for w, _, _, _ in jobs])
+    bias = vpp(*[(b.data_ptr() if b is not None else None) for _, b, _, _ in jobs])
+    outs = vpp(*[o.data_ptr() for _, _, o, _ in jobs])
+    Ns = (C.c_int * n)(*[256 if p else 192 for _, _, _, p in jobs])
+    planes = (C.c_int * n)(*[1 if p else 0 for _, _, _, p in jobs])
+    with _timed("pyramid_group_ws_%d" % n):
+      L.check(L.load().mvg_pyramid_group_ws(L.ptr(feat), n_img, S, n, Wf, bias, outs, Ns, planes, int(slots), L.stream_ptr()),
+              "mvg_pyramid_group_ws")
+
+
 def gsamp_column_order(device=None):
     """Row permutation of [sampling_offsets.weight (128); attention_weights.weight (64)] that msda_gsamp expects
     for G and xw: 8 groups of (16 offset rows | 8 logit rows).  With the reference's memory reinterpretation

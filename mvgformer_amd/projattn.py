@@ -265,6 +265,18 @@ class ProjAttn(nn.Module):
         ops.value_proj_planes_ws(feat[i0:i1], Wv_f, bv, vp[i0:i1])
         ops.feat_linear_ws(feat[i0:i1], self.query_term_weights(dt)[0], 192, out=self._G[i0 * S:i1 * S])
 
+    def pyramid_jobs(self, feat):
+        """this layer's two products as jobs of ops.pyramid_group_ws (value planes, G), into the buffers project_pyramid uses"""
+        dt = feat.dtype
+        n_img, S, _ = feat.shape
+        bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
+        Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
+        vp = self._plane_buffer(n_img, S, feat.device)
+        shape = (n_img * S, 192)
+        if self._G is None or self._G.dtype != torch.bfloat16 or tuple(self._G.shape) != shape or self._G.device != feat.device:
+            self._G = torch.empty(shape, dtype=torch.bfloat16, device=feat.device)
+        return [(Wv_f, bv, vp, True), (self.query_term_weights(dt)[0], None, self._G, False)]
+
     def project_values(self, feat):
         """value = rayconv(input_flatten) (projattn.py:169) as bf16 head planes vh[img][head][s][32]."""
         dt = feat.dtype

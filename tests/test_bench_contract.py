@@ -40,7 +40,9 @@ def test_bench_line_has_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["unit"] == "samples/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step_mean"]) < 1e-2 * d["value"]     # value: wall clock of the timed region
+    lo, hi = d["ms_per_step_min_max"]
+    assert lo <= d["ms_per_step"] <= hi and d["ms_per_step"] <= 1.05 * d["ms_per_step_mean"]    # the median of the per-step intervals
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["hip_graph"] is True
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "msda_gsamp_kernel"
@@ -49,12 +51,29 @@ def test_bench_line_has_the_contract_fields():
     assert r["algorithmic_bytes_per_launch"] == 231014400
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_us"] / 1e3) < 1.0
     assert 0.02 < r["frac"] < 1.0
+    # the MFMA regime of SURVEY 8(d)(ii), next to the HBM one
+    m = d["roofline_mfma"]
+    assert m["bound"] == "mfma" and m["peak"] == 2500.0 and m["unit"] == "TFLOP/s"
+    assert m["flops_nominal"] == 390038814720                     # 97.5 GFLOP per layer x 4
+    assert 0.5 * m["flops_nominal"] < m["flops_executed"] <= m["flops_per_step"] <= 1.2 * m["flops_nominal"]
+    assert abs(m["frac"] - m["achieved_tflops"] / m["peak"]) < 1e-3 and 0.0 < m["frac"] <= 1.0
+    assert abs(m["achieved_tflops"] - m["flops_executed"] / d["ms_per_step"] / 1e9) < 0.5
+    assert {"chain_a", "chain_b", "value_proj", "feat_linear", "pyramid_group_first_layer"} <= set(m["per_kernel"])
+    for name, k in m["per_kernel"].items():
+        assert 0.0 < k["frac"] <= 1.0 and abs(k["tflops"] - k["gflop"] / k["us"] * 1e-3) < 0.02 * k["tflops"] + 0.5, (name, k)
     assert d["scaling"] is None and d["rccl"] is None           # one GPU: neither weak nor strong, no collectives
     # the other named workloads ride in the same line (driver-witnessed): fp32 at cfg-2 / cfg-4, nothing-skipped bf16, cfg-5, B > 1
     sec = d["secondary"]
-    assert set(sec) == {"cfg2_fp32", "cfg4_fp32", "cfg2_bf16_inside_all", "cfg5_bf16", "cfg2_bf16_batch2", "cfg2_bf16_batch4"}
+    assert set(sec) == {"cfg2_fp32", "cfg4_fp32", "cfg2_bf16_inside_all", "cfg5_bf16", "cfg2_bf16_batch2", "cfg2_bf16_batch4",
+                        "cfg2_bf16_valid10", "train_step_cfg2_fp32"}
+    train = sec.pop("train_step_cfg2_fp32")
+    assert "error" not in train, train
+    done, total = train["parameters_with_finite_gradients"].split(" / ")
+    assert train["steps"] >= 5 and train["fp32_form"] == "2xfp16x3" and 0 < int(done) <= int(total) and train["ms_per_step"] > 0
+    assert 0.02 < sec["cfg2_bf16_valid10"]["valid_query_share_last_layer"] < 0.5
     for name, rec in sec.items():
         assert "error" not in rec, (name, rec)
+        assert ("fp32_form" in rec) == name.endswith("fp32") and rec.get("fp32_form", "2xfp16x3") == "2xfp16x3"
         for k in ("ms_per_step", "ms_per_sample", "value", "dtype", "workload", "sampler_kernel", "sampler_us", "frac", "steps"):
             assert k in rec, (name, k)
         assert rec["steps"] >= 10 and rec["hip_graph"] is True and 0.02 < rec["frac"] < 1.0
@@ -100,7 +119,7 @@ def test_two_rank_query_sharded_bench_runs_end_to_end_on_one_gpu(speculative):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4
     assert "queries sharded x2" in d["config"]["parallelism"] and d["config"]["hip_graph"] is True
     assert ("speculative" in d["config"]["parallelism"]) == bool(speculative)
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]       # one sample per step, whole job
+    assert abs(d["value"] - 1e3 / d["ms_per_step_mean"]) < 1e-2 * d["value"]       # one sample per step, whole job
     assert "process group up (gloo)" in p.stderr
     # first-contact insurance: the collectives ran once before anything was timed, and the line says what they saw
     assert d["rccl"]["ok"] is True and d["rccl"]["ranks"] == 2 and d["rccl"]["ranks_seen"] == [0, 1] and d["rccl"]["backend"] == "gloo"

@@ -1272,6 +1272,38 @@ def test_pyramid_gemms_and_binning_full_size():
         assert int(flags[n, :int(n_in[n])].sum()) == int(n_in[n]) and int(flags[n, int(n_in[n]):].sum()) == 0
 
 
+@pytest.mark.parametrize("n_img,S,n_layers", [(5, 40320, 1), (5, 40320, 3), (3, 1237, 4), (1, 5, 2), (2, 40, 1)])
+def test_grouped_pyramid_products_equal_the_single_launches(n_img, S, n_layers):
+    """mvg_pyramid_group_ws: several layers' value planes + G from one launch over the packed pyramid (the workgroups of an XCD
+    divided among the products) -- every output BIT-identical to mvg_value_proj_planes_ws / mvg_feat_linear_ws, also for
+    pyramids with fewer row tiles than workgroups and a ragged last tile."""
+    from mvgformer_amd import _lib, ops
+    torch.manual_seed(5 + n_img)
+    feat = torch.randn(n_img, S, 256, device=DEV).to(torch.bfloat16)
+    jobs, want = [], []
+    for l in range(n_layers):
+        W = ops.swizzle_weight((torch.randn(256, 256, device=DEV) / 16).to(torch.bfloat16))
+        bias = torch.randn(256, device=DEV) * 0.1
+        Wg = (torch.randn(192, 256, device=DEV) / 16).to(torch.bfloat16)
+        Wgf = ops.swizzle_weight(torch.cat([Wg, Wg.new_zeros(64, 256)], 0))
+        vh = torch.full((n_img, 8, S, 32), 7.0, dtype=torch.bfloat16, device=DEV)
+        G = torch.full((n_img * S, 192), 7.0, dtype=torch.bfloat16, device=DEV)
+        jobs += [(W, bias, vh, True), (Wgf, None, G, False)]
+        want += [ops.value_proj_planes_ws(feat, W, bias, torch.empty_like(vh)), ops.feat_linear_ws(feat, Wgf, 192)]
+    ops.pyramid_group_ws(feat, jobs)
+    torch.cuda.synchronize()
+    for (_, _, out, _), ref in zip(jobs, want):
+        assert torch.equal(out.view(-1), ref.view(-1))
+    for gw in (300, 400):       # other divisions of the workgroups: same bits
+        _lib.check(_lib.load().mvg_set_tuning(b"wreg_gweight", gw), "wreg_gweight")
+        for _, _, out, _ in jobs:
+            out.fill_(3.0)
+        ops.pyramid_group_ws(feat, jobs)
+        for (_, _, out, _), ref in zip(jobs, want):
+            assert torch.equal(out.view(-1), ref.view(-1))
+    _lib.check(_lib.load().mvg_set_tuning(b"wreg_gweight", 300), "wreg_gweight")
+
+
 def _emulate_gsamp_one_image(vp, G, xw, ref_lvl, shapes, starts, n, B):
     """torch restatement of msda_gsamp_kernel's arithmetic for image n (all its queries, 8 heads): bilinear gather of
     the head's logits / offsets from the bf16 G (+ xw), the reference's memory reinterpretation, softmax, sampling
