@@ -55,8 +55,7 @@ def dense_flops(S, C, Lq, M, L, P, F, V, B, layers, exec_rows_a=None):
             "chain_a": sum(chain_a) / max(len(chain_a), 1), "chain_b": chain_b}
 
 
-SAMPLER_SOURCES = ("mvgformer_amd/csrc/msda.hip", "mvgformer_amd/csrc/gsamp_dev.h", "mvgformer_amd/csrc/common.h",
-                   "mvgformer_amd/csrc/sampchain.hip", "mvgformer_amd/csrc/chain_dev.h")
+SAMPLER_SOURCES = ("mvgformer_amd/csrc/msda.hip", "mvgformer_amd/csrc/gsamp_dev.h", "mvgformer_amd/csrc/common.h")
 
 
 def sampler_source_hash():
@@ -109,7 +108,7 @@ def measure_traffic_live(argv_tail, kernel_prefix):
                         "fetch_correction": 2.0}
 
 
-SAMPLER_KERNELS = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel",
+SAMPLER_KERNELS = {"msda_gsamp": "msda_gsamp_kernel",
                    "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
 
 # the workloads measured next to the headline in the driver's one command: (name, config, dtype, inside, batch)
@@ -636,14 +635,14 @@ def main():
                 orig = originals[name] = getattr(ops, name)
 
                 def wrapped(*a, **kw):
-                    mask = kw.get("pair_mask", a[6] if (name == "msda_gsamp_chain" and len(a) > 6) else None)
+                    mask = kw.get("pair_mask")
                     if mask is not None:
                         live_fracs.append(mask.float().mean())
                         per_img = mask.view(args.batch * V, -1).sum(1, dtype=torch.int64)
                         exec_rows_a.append(((per_img + 127) // 128 * 128).clamp(max=mask.numel() // (args.batch * V)).sum())
                     return orig(*a, **kw)
                 setattr(ops, name, wrapped)
-            for name in ("msda_gsamp", "msda_gfused_f32", "msda_gsamp_chain"):
+            for name in ("msda_gsamp", "msda_gfused_f32"):
                 counting(name)
             try:
                 forward()
@@ -705,10 +704,9 @@ def main():
     # measured by this run (two rocprofv3 child passes of the same command) or the committed figure of tools/prof.sh --
     # quoted only for the kernel sources (hash) and configuration it was measured on; the line says which.
     traffic, traffic_source = None, None
-    # the dominant kernel: the fused sampler + chain A (bf16 default), the plain G-sampling kernel (MVG_FUSE_SAMPLER=0) or
-    # the generic fused sampling kernel (fp32); its algorithmic bytes are SURVEY 8(d)'s sampling figure in all three cases
-    # (the chain-A half of the fused kernel adds no bytes to the numerator)
-    kernel_names = {"msda_gsamp_chain": "samp_chain_kernel", "msda_gsamp": "msda_gsamp_kernel",
+    # the dominant kernel: the G-sampling kernel (bf16), its fp32 twin or the generic fused sampling kernel; its algorithmic
+    # bytes are SURVEY 8(d)'s sampling figure in all three cases
+    kernel_names = {"msda_gsamp": "msda_gsamp_kernel",
                     "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
     samp_key = next((k for k in kernel_names if k in prof), "msda_fused")
     samp_name = kernel_names[samp_key]
@@ -750,7 +748,7 @@ def main():
                 # launches: the bf16 kernel zero-fills the others without sampling (the consumer multiplies their rows by 0,
                 # dq_decoder.py:585-586); `achieved` prices ALL pairs at SURVEY 8(d)'s bytes.  --inside all = nothing skipped
                 "in_image_pair_fraction": None if live_frac is None else round(live_frac, 4),
-                "pairs_skipped": bool(samp_key in ("msda_gsamp", "msda_gsamp_chain", "msda_gfused_f32")),
+                "pairs_skipped": bool(samp_key in ("msda_gsamp", "msda_gfused_f32")),
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
                 "fused_minimum_bytes_per_launch": args.batch * V * (S * 256 + Lq_loc * 256) * elem}

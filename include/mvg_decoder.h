@@ -66,7 +66,6 @@ const char* mvg_version(void);
  *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
  *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs;
  *   "bin_multi" = 1 | 0 : multi-workgroup binning for large Lq (needs the workspace of mvg_bin_pairs);
- *   "sampchain_map" = n : consecutive 64-row tiles per XCD chunk of the fused sampler + chain A kernel;
  *   "gsamp_pipe" = 0 | 1 | 2 : sampler gather loop (default / double-buffered / LDS window for the coarsest level);
  *   "f32_split" = 1 | 0 : fp32 GEMMs as six bf16 MFMA products on operands split into three bf16 parts (default) or as
  *       v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);  "linear_tiles" = 0 | 1 | 2, "linear_xcd" = 1 | 0 : tile shapes and
@@ -290,20 +289,6 @@ int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp,
                         const void* W0, const float* b0, const void* W1, const float* b1,
                         const float* W2, const float* b2, void* attn, float* o,
                         const int32_t* order, const float* o_masked, int rows, void* stream);
-
-/* Fused sampler + chain A of the bf16 path: mvg_msda_gsamp and mvg_chain_attn_pose as ONE kernel (csrc/sampchain.hip) --
- * a workgroup gathers the 64 x 256 sampled tile of 64 consecutive slots of the processing order (all 8 heads) into LDS and
- * runs output_proj x in-image mask -> attn and the pose MLP -> o on it; the (rows, 256) `samp` tensor never exists, and
- * one workgroup's MFMA stages run under the gather latency of the other workgroup on its CU.  Arguments as in the two
- * entry points it replaces (vh, G, xw, ref_lvl, levels | inside = the pair mask = the row mask | order | chain weights in
- * fragment order | attn (N_img*Lq, 256) bf16, o (N_img*Lq, 3) f32 | o_masked).  With o_masked == NULL no tile is
- * skipped (run on one masked row, this is how o_masked for this kernel is obtained).  Every row is bit-identical to
- * mvg_msda_gsamp followed by the 64-row / 8-wavefront / column-split variant of mvg_chain_attn_pose. */
-int mvg_msda_gsamp_chain(const void* vh, const void* G, const float* xw, const float* ref_lvl,
-                         const int64_t* shapes_host, const int64_t* starts_host, const uint8_t* inside,
-                         const int32_t* order, const void* Wp, const float* bp, const void* W0, const float* b0,
-                         const void* W1, const float* b1, const float* W2, const float* b2, void* attn, float* o,
-                         const float* o_masked, int N_img, int Lq, int L, int S, int B, void* stream);
 
 /* ---- fp32 path as fused kernels ("f32s": fp32 storage, fp32-accurate products on the bf16 matrix pipe; csrc/f32s.hip) --------
  * The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75 dispatches float / double only; the Linears of

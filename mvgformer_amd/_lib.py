@@ -57,7 +57,6 @@ SIGNATURES = {
     "mvg_feat_linear_ws": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_pyramid_group_ws": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "mvg_msda_gsamp": [_vp] * 9 + [_i] * 5 + [_vp],
-    "mvg_msda_gsamp_chain": [_vp] * 19 + [_i] * 5 + [_vp],
     "mvg_bin_pairs": [_vp] * 3 + [_i] + [_vp] + [_i] * 2 + [_vp, C.c_size_t, _vp],
     "mvg_bin_pairs_workspace": [_i, _i],
     "mvg_mean_views": [_vp, _i, _vp, _i, _i, _i, _vp],

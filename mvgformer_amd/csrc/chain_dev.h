@@ -1,5 +1,4 @@
-// Device building blocks of the fused Linear chains (csrc/chain.hip) -- shared with the fused sampler + chain A
-// kernel (csrc/sampchain.hip).  See chain.hip for the design notes.
+// Device building blocks of the fused Linear chains (csrc/chain.hip).  See chain.hip for the design notes.
 #pragma once
 #include "common.h"
 
@@ -214,8 +213,7 @@ __device__ __forceinline__ void write_act_pre(char* __restrict__ act, const f32x
 // Chain A on a tile that is already in LDS: act (RM x 256 bf16 sampled rows, ACT_PITCH), rid (global row of every
 // tile row, -1 past the end), w2s (last pose layer, 3 x 256 f32).  attn = inside * (act Wp^T + bp) -> global (needed
 // for the view mean), then the pose MLP -> o (dx, dy, confidence logit).  Called by all threads of the workgroup after a
-// barrier that made the tile visible; used by chain_a_kernel (tile loaded from samp) and by the fused sampler + chain A
-// kernel (tile produced in place by the gather phase, csrc/sampchain.hip).
+// barrier that made the tile visible (chain_a_kernel: tile loaded from samp).
 // PRE1: the first weight fragments of stage 1 were requested by the caller before it loaded the tile (chain_a_ring1), so that
 // their round trip runs under the tile's (s_memtime: stage 1 took 11 500 cycles against 6 300 - 7 800 for stages 2 and 3,
 // which have always had this prefetch).

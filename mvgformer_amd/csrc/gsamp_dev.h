@@ -1,5 +1,4 @@
-// Device building blocks of the G-sampling kernel (csrc/msda.hip: msda_gsamp_kernel) -- shared with the fused sampler +
-// chain A kernel (csrc/sampchain.hip).  See msda.hip for the design notes.
+// Device building blocks of the G-sampling kernel (csrc/msda.hip: msda_gsamp_kernel).  See msda.hip for the design notes.
 #pragma once
 #include "common.h"
 

@@ -1491,8 +1491,6 @@ extern int g_wreg_gweight;
 extern int g_auto_small_b;
 extern int g_auto_small_a;
 extern int g_bin_multi;
-extern int g_sampchain_map;
-extern int g_sampchain_mode;
 
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;
@@ -1516,8 +1514,6 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
   if (!strcmp(key, "wreg_gweight") && value >= 100 && value <= 400) { g_wreg_gweight = value; return 0; }
   if (!strcmp(key, "bin_multi") && (value == 0 || value == 1)) { g_bin_multi = value; return 0; }
-  if (!strcmp(key, "sampchain_map") && value >= 1 && value <= 4096) { g_sampchain_map = value; return 0; }
-  if (!strcmp(key, "sampchain_mode") && value >= 0 && value <= 2) { g_sampchain_mode = value; return 0; }
   if (!strcmp(key, "auto_small") && (value == 0 || value == 1)) { g_auto_small = value; return 0; }
   if (!strcmp(key, "auto_small_b") && (value == 0 || value == 1)) { g_auto_small_b = value; return 0; }
   if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }

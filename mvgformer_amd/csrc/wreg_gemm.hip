@@ -4,14 +4,12 @@
 //   G projection     : G  = feat @ [Woff; Wattn]^T, row-major (n_img*S, 192) (projattn.py:180-181 applied to the
 //                      pyramid itself: bilinear sampling commutes with the Linear, see msda_gsamp_kernel)
 //
-// Why weight-stationary: with K = 256 these GEMMs move ~1 KB per row and are bound by what a 256-CU chip pulls
-// through its L1s (~6 TB/s); a tiled GEMM re-fetches its 64-128 KB weight tile for every row tile, which at
-// 200 000 rows is as much traffic as the activations (measured: 107 us for the value projection = 510 MB, 200 MB
-// of it weights).  Here 512 persistent workgroups load the weight ONCE into registers -- each of the 4
-// wavefronts keeps its 64 output columns x 256 k = 32 KB as 128 VGPRs in MFMA-fragment order -- and stream
-// 32-row tiles through LDS: the k-loop is pure ds_read_b128 + v_mfma_f32_32x32x16_bf16; the loads of the tile
-// after next and the stores of the previous one are issued together at the start of an iteration and waited for one
-// MFMA + epilogue phase later; two workgroups per CU overlap each other.
+// Why weight-stationary: with K = 256 these GEMMs move ~1 KB per row and are bound by what the chip streams (HBM writes,
+// ~5.5 TB/s in the forward); a tiled GEMM re-fetches its 64-128 KB weight tile for every row tile, which at 200 000 rows is as
+// much traffic as the activations (measured: 107 us for the value projection = 510 MB, 200 MB of it weights).  Here 512
+// persistent workgroups load the weight ONCE into registers -- each of the 4 wavefronts keeps its 64 output columns x 256 k =
+// 32 KB as 128 VGPRs in MFMA-fragment order -- and stream 32-row tiles through LDS (wreg2_body below: LDS-DMA ring for the
+// rows, wavefront-private staging for the outputs, one barrier and one exact vmcnt wait per tile); two workgroups per CU.
 //
 // Head planes (consumed by msda_gsamp_kernel): a pixel's 32 channels of one head are 64 contiguous bytes, two
 // horizontally adjacent pixels one 128-byte line when the left one has an even column -- the bilinear corners of a
@@ -19,14 +17,40 @@
 // one line per corner pair and perm-free dot2 operands, but twice the bytes -- with the pairs processed in
 // image-space order the smaller footprint wins: sampler 153 -> 145 us, this GEMM 59 -> 40 us.)
 #include "common.h"
+#include <type_traits>
 
 int g_wreg_grid = 512;   // tuning knob (mvg_set_tuning "wreg_grid"): persistent workgroups
+
+// measurement builds (tools/probes/stamps_wreg.py): s_memtime per wavefront at the phase boundaries of one steady-state tile
+#ifdef WREG_STAMPS
+__device__ unsigned long long wreg_stamps[1024 * 4 * 16];
+#define W2STAMP_ALWAYS(i, val)                                                                                            \
+  do {                                                                                                                    \
+    if (lane == 0 && blockIdx.x < 1024) {                                                                                 \
+      asm volatile("" ::: "memory");                                                                                      \
+      wreg_stamps[(blockIdx.x * 4 + wn) * 16 + (i)] = (val);                                                              \
+      asm volatile("" ::: "memory");                                                                                      \
+    }                                                                                                                     \
+  } while (0)
+#define W2STAMP(i)                                                                                                        \
+  do {                                                                                                                    \
+    if (it == WREG_STAMPS && lane == 0 && blockIdx.x < 1024) {                                                            \
+      asm volatile("" ::: "memory");                                                                                      \
+      wreg_stamps[(blockIdx.x * 4 + wn) * 16 + (i)] = __builtin_amdgcn_s_memtime();                                       \
+      asm volatile("" ::: "memory");                                                                                      \
+    }                                                                                                                     \
+  } while (0)
+extern "C" int mvg_wreg_read_stamps(unsigned long long* host, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(wreg_stamps), sizeof(unsigned long long) * 64 * n_blocks);
+}
+#else
+#define W2STAMP(i)
+#define W2STAMP_ALWAYS(i, val)
+#endif
 
 namespace {
 
 constexpr int RM = 32;            // rows per tile (one 32x32 MFMA row block)
-constexpr int ACT_PITCH = 528;    // bytes per bf16 activation row in LDS (256 bf16 + 16 pad: conflict-free b128)
-constexpr int NCH = RM * 32 / 256;
 
 struct WregParams {
   const bf16_t* A;        // (M, 256) bf16 rows
@@ -37,22 +61,44 @@ struct WregParams {
   int rowmajor;           // 0 = head planes (N = 256), 1 = row-major bf16 (M, N)
 };
 
-// NCPT: 16-byte output chunks per thread and tile.  0 = head planes (N = 256: 4 chunks), 1..4 = row-major with
-// N = 64 * NCPT columns.  Every thread issues the SAME number of stores for every tile (chunks of rows past the end
-// of the matrix are redirected to re-write the last valid row's chunk with identical bytes), so the compiler can
-// give the loads of a later tile an exact vmcnt instead of vmcnt(0).
-// The persistent loop of one workgroup: row tiles first_tile, first_tile + tile_stride, ... of job `p`.
-template <int NCPT>
-__device__ __forceinline__ void wreg_body(const WregParams& p, char* smem, const int first_tile, const int tile_stride) {
-  constexpr bool PLANES = NCPT == 0;
-  char* act = smem;                                   // RM x 256 bf16 A tile
-  char* stage0 = smem + RM * ACT_PITCH;               // 2 x (RM x 256 bf16) output tiles (double-buffered)
-  float* bias_s = reinterpret_cast<float*>(smem + 3 * RM * ACT_PITCH);   // 256 f32
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, rl = lane & 31, h = lane >> 5;
+// ---- the persistent loop of one workgroup: row tiles first_tile, first_tile + tile_stride, ... of one product -------------------
+// Rounds 1-4 staged the rows through registers (global_load -> ds_write), both products' outputs through a shared 33-KB staging
+// buffer, with two workgroup barriers per tile; knock-out builds (tools/probes/ko_wreg.py, profiles/r05_experiments.txt) showed
+// its phases ADDING UP (3 layers' products: 220 us = ~70 base + ~80 MFMA + ~53 stores + ~15 loads, power-throttled box) and the
+// ISA showed why: vmcnt(0) at the loop head (every load and store of the previous iteration drained), an A fragment read,
+// waited for, two MFMAs, and so on.  This body keeps the geometry (4 wavefronts x 64 output columns in 128 registers, 32-row
+// tiles, 2 workgroups per CU), the k order and the accumulation -- outputs are bit-identical to the old body's -- and changes
+// how the bytes move:
+//   * A tiles arrive by LDS-DMA (global_load_lds_dwordx4, 4 x 1 KB per wavefront and tile, one M0 write per tile) into a ring of
+//     3 unpadded 16-KB slots, two tiles ahead; the 16-byte chunks of a row are XOR-permuted by (row & 15) on the SOURCE side (the
+//     DMA writes lane-linear), the MFMA operand reads apply the same permutation: conflict-free ds_read_b128 without a pad;
+//   * a wavefront stages ITS OWN 64 columns x 32 rows (4.5 KB, private: no barrier between its epilogue and its stores) and
+//     stores them during the next tile: head planes as 1-KB runs (16 rows x 64 B of one head), G rows as 8 x 128-B lines;
+//   * one workgroup barrier per tile (hand-over of the A ring); the wait in front of it is an exact count -- in-order vmcnt:
+//     behind the loads of tile t sit the 4 stores of tile t-2 and the 4 loads of tile t+1 -- so loads and stores stay in
+//     flight across the barrier (hipcc does not see the asm loads: it neither counts nor drains them);
+//   * the previous tile's stores, the DMA of the tile after next and the bias reads are issued between the MFMAs of the k loop
+//     (pinned with sched_barrier): a wavefront's tile takes ~3.2 k cycles instead of ~4.4 k with the phases one after the other.
+// What it buys (profiles/r05_experiments.txt): 8-10 % less kernel time alone (where 30 back-to-back launches throttle the
+// clock to 1.1-1.9 GHz: fewer instructions, less LDS traffic), 4 % per forward at 4 samples per forward, nothing at one sample
+// per forward -- there the launches run at 2.2 GHz and ~5.5 TB/s: HBM-write-bound either way.
+constexpr int W2_NA = 3;                       // A ring slots
+constexpr int W2_ABYTES = RM * 512;            // one slot: 32 rows x 256 bf16, unpadded
+constexpr int W2_STP = 144;                    // staging pitch: 64 bf16 + 16 B (conflict-free b64 writes / b128 reads)
+constexpr int W2_STW = RM * W2_STP;            // per wavefront
+constexpr int W2_LDS = W2_NA * W2_ABYTES + 4 * W2_STW + 256 * (int)sizeof(float);
+
+template <bool PLANES, bool SMALL_S>
+__device__ __forceinline__ void wreg2_body(const WregParams& p, char* smem, const int first_tile, const int tile_stride) {
+  const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31, h = lane >> 5;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* stage = smem + W2_NA * W2_ABYTES + wn * W2_STW;
+  float* bias_s = reinterpret_cast<float*>(smem + W2_NA * W2_ABYTES + 4 * W2_STW);
   const bool wave_has_cols = wn * 64 < p.N;
   bias_s[tid] = p.bias ? p.bias[tid] : 0.f;
+  W2STAMP_ALWAYS(8, __builtin_amdgcn_s_memtime());
+  W2STAMP_ALWAYS(13, __builtin_amdgcn_s_memrealtime());
 
-  // ---- the weight slice of this wavefront -> registers, once
   f32x4 wreg[16][2];
   {
     const bf16_t* wp = p.Wf + (long)wn * 16 * 1024 + lane * 8;
@@ -62,115 +108,175 @@ __device__ __forceinline__ void wreg_body(const WregParams& p, char* smem, const
       wreg[ks][1] = *reinterpret_cast<const f32x4*>(wp + ks * 1024 + 512);
     }
   }
+  __syncthreads();                               // bias_s; the weight loads are drained here, before the counted waits start
+  W2STAMP_ALWAYS(9, __builtin_amdgcn_s_memtime());
+  const int ntiles = (p.M + RM - 1) / RM;
+  const int G = tile_stride;
+  const unsigned abuf_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  constexpr int TS = RM;                        // tile stride in rows
-  const int ntiles = (p.M + TS - 1) / TS;
-  bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-  // A chunk c = i*256 + tid of a tile: row = c >> 5, 16-byte column v16 = c & 31 (NCH chunks per thread)
-  auto load_chunk = [&](int tile, int i) -> uint4 {
-    const int c = i * 256 + tid, row = c >> 5, v16 = c & 31;
-    const int rr = min(tile, ntiles - 1) * TS;
-    return *reinterpret_cast<const uint4*>(p.A + (long)min(rr + row, p.M - 1) * 256 + v16 * 8);
-  };
-  // global stores of a finished tile from its staging buffer
-  auto store_tile = [&](int tile, const char* stage) {
-    const int r0 = tile * TS;
-    const int last_row = p.M - 1 - r0;                 // rows past it do not exist (only in the final tile)
-    if (PLANES) {
+  // LDS-DMA of a tile into ring slot `slot`: piece q of wavefront wn fills tile positions (4 wn + q) * 64 .. + 63 = rows
+  // 2 (4 wn + q), + 1; lane -> (row, slot chunk lane & 31) <- source chunk (lane & 31) ^ (row & 15).  Tiles past the end re-read
+  // the last tile, rows past the end the last row (nobody uses them): every wavefront issues 4 loads per call, always.
+  // ONE statement per tile: M0 (the LDS base) is written once and the four pieces go through the instruction's offset field,
+  // which the hardware adds to the LDS address AND to the global address -- so lane pointer q is biased by -1024 q bytes.
+  // (One M0 write per piece measured ~260 cycles per piece: the write waits for the previous piece to have read M0.)
+  int srow[4], schunk[4];
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = i * 256 + tid, v16 = c & 31;
-        // the 64 bytes of (pixel, head) are written by 4 threads: thread q4 stores channels 8*q4 .. 8*q4+7
-        const int row = min(c >> 5, last_row);
-        const int grow = r0 + row;
-        const int img = grow / p.S_img, sp = grow - img * p.S_img;
-        const int head = v16 >> 2, q4 = v16 & 3;
-        *reinterpret_cast<f32x4*>(outp + (((long)img * 8 + head) * p.S_img + sp) * 32 + q4 * 8) =
-            *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + v16 * 16);
+  for (int q = 0; q < 4; ++q) {
+    srow[q] = 2 * (4 * wn + q) + (lane >> 5);
+    schunk[q] = ((lane & 31) ^ (srow[q] & 15)) * 8 - 512 * q;          // bf16 elements
+  }
+  const bf16_t* dsrc[4];
+  auto dma_addr = [&](int tile) {
+    const long r0 = (long)min(tile, ntiles - 1) * RM;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dsrc[q] = p.A + min(r0 + srow[q], (long)p.M - 1) * 256 + schunk[q];
+  };
+  auto dma_issue = [&](int slot) {
+    const unsigned dst = abuf_lds + slot * W2_ABYTES + wn * 4096;
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:3072"
+                 :: "v"(dsrc[0]), "v"(dsrc[1]), "v"(dsrc[2]), "v"(dsrc[3]), "s"(dst) : "memory");
+  };
+  // operand reads: chunk 2 ks + h of row rl sits at slot chunk (2 ks + h) ^ (rl & 15) = (((ks & 7) ^ (rl >> 1 & 7)) << 1 | (h ^ rl & 1))
+  // + 16 (ks >> 3): 8 lane-dependent addresses, ks >= 8 through the instruction's offset field
+  unsigned aoff[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) aoff[k] = rl * 512 + ((((k ^ ((rl >> 1) & 7)) << 1) | (h ^ (rl & 1))) << 4);
+
+  // stores of a finished tile from the wavefront's staging rows (4 x 16 B per lane), in three steps that the k loop of the next
+  // tile spreads over its MFMAs: staging rows -> registers, addresses, stores
+  bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+  f32x4 sv[4];
+  bf16_t* sdst[4];
+  auto st_read = [&](int tile, int i) {
+    const int last_row = p.M - 1 - tile * RM;           // rows past it do not exist (only in the final tile)
+    if (PLANES) sv[i] = *reinterpret_cast<const f32x4*>(stage + min(16 * (i & 1) + (lane >> 2), last_row) * W2_STP + (i >> 1) * 64 + (lane & 3) * 16);
+    else sv[i] = *reinterpret_cast<const f32x4*>(stage + min(8 * i + (lane >> 3), last_row) * W2_STP + (lane & 7) * 16);
+  };
+  auto st_addr = [&](int tile) {
+    const int r0 = tile * RM;
+    const int last_row = p.M - 1 - r0;
+    if (PLANES) {
+      // image / pixel of the tile's first row once per tile (wave-uniform); a 32-row tile crosses at most one image boundary
+      // when an image has >= 32 pixels (else: the division per lane)
+      const int img0 = r0 / p.S_img, sp0 = r0 - img0 * p.S_img;
+      if (!SMALL_S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = min(16 * (i & 1) + (lane >> 2), last_row);
+          const bool over = sp0 + row >= p.S_img;
+          const int sp = over ? sp0 + row - p.S_img : sp0 + row, img = over ? img0 + 1 : img0;
+          sdst[i] = outp + (((long)img * 8 + 2 * wn + (i >> 1)) * p.S_img + sp) * 32 + (lane & 3) * 8;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int grow = r0 + min(16 * (i & 1) + (lane >> 2), last_row);
+          const int img = grow / p.S_img, sp = grow - img * p.S_img;
+          sdst[i] = outp + (((long)img * 8 + 2 * wn + (i >> 1)) * p.S_img + sp) * 32 + (lane & 3) * 8;
+        }
       }
     } else {
-      constexpr int CPR = 8 * (NCPT > 0 ? NCPT : 1);    // 16-byte chunks per output row
 #pragma unroll
-      for (int i = 0; i < NCPT; ++i) {
-        const int c = i * 256 + tid;
-        const int row = min(c / CPR, last_row), ch = c % CPR;
-        *reinterpret_cast<f32x4*>(outp + (long)(r0 + row) * p.N + ch * 8) =
-            *reinterpret_cast<const f32x4*>(stage + row * ACT_PITCH + ch * 16);
-      }
+      for (int i = 0; i < 4; ++i) sdst[i] = outp + (long)(r0 + min(8 * i + (lane >> 3), last_row)) * p.N + wn * 64 + (lane & 7) * 8;
     }
   };
+  auto st_store = [&](int i) { *reinterpret_cast<f32x4*>(sdst[i]) = sv[i]; };
 
-  // Software pipeline, loads two tiles ahead.  Iteration t: [wait loads(t)] -> A tile to LDS -> barrier ->
-  // stores(t-1) from the other staging buffer -> loads(t+2) into the registers just freed -> MFMA(t) -> epilogue(t)
-  // -> barrier.  gfx9 has ONE in-order vmcnt for loads and stores: loads(t+1) are older than stores(t-1) and
-  // loads(t+2), and because every iteration issues a fixed number of each, the wait at the top of t+1 is an exact
-  // vmcnt(stores + loads), not vmcnt(0) -- a full iteration of latency hiding for every load.
-  static_assert(NCH == 4, "prefetch registers are written out for 4 chunks per thread");
-  const int G = tile_stride;
-  uint4 xa0 = load_chunk(first_tile, 0), xa1 = load_chunk(first_tile, 1), xa2 = load_chunk(first_tile, 2),
-        xa3 = load_chunk(first_tile, 3);
-  uint4 xb0 = load_chunk(first_tile + G, 0), xb1 = load_chunk(first_tile + G, 1), xb2 = load_chunk(first_tile + G, 2),
-        xb3 = load_chunk(first_tile + G, 3);
-  int it = 0, prev_tile = -1;
+  dma_addr(first_tile); dma_issue(0);
+  dma_addr(first_tile + G); dma_issue(1);
+  int it = 0, slot = 0, prev_tile = -1;
 
-#define WREG_ITERATION(X0, X1, X2, X3)                                                                           \
-  {                                                                                                              \
-    {                                                                                                            \
-      const int row = tid >> 5, v16 = tid & 31;                                                                  \
-      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = X0;                                          \
-      *reinterpret_cast<uint4*>(act + (row + 8) * ACT_PITCH + v16 * 16) = X1;                                    \
-      *reinterpret_cast<uint4*>(act + (row + 16) * ACT_PITCH + v16 * 16) = X2;                                   \
-      *reinterpret_cast<uint4*>(act + (row + 24) * ACT_PITCH + v16 * 16) = X3;                                   \
-    }                                                                                                            \
-    __syncthreads();                                                                                             \
-    char* stage = stage0 + (it & 1) * RM * ACT_PITCH;                                                            \
-    if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);                         \
-    X0 = load_chunk(tile + 2 * G, 0);                                                                            \
-    X1 = load_chunk(tile + 2 * G, 1);                                                                            \
-    X2 = load_chunk(tile + 2 * G, 2);                                                                            \
-    X3 = load_chunk(tile + 2 * G, 3);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
-    f32x16 acc[2];                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;                                            \
-    if (wave_has_cols) {                                                                                         \
-      _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) {                                                        \
-        const f32x4 a = *reinterpret_cast<const f32x4*>(act + rl * ACT_PITCH + ks * 32 + 16 * h);                \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks][j]),              \
-                                                           __builtin_bit_cast(bf16x8, a), acc[j], 0, 0, 0);      \
-      }                                                                                                          \
-    }                                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                            \
-        const int nn = wn * 64 + j * 32 + 8 * g + 4 * h;                                                         \
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + nn);                                           \
-        uint2 pk;                                                                                                \
-        pk.x = pack_bf16(acc[j][4 * g] + bv[0], acc[j][4 * g + 1] + bv[1]);     \
-        pk.y = pack_bf16(acc[j][4 * g + 2] + bv[2], acc[j][4 * g + 3] + bv[3]); \
-        *reinterpret_cast<uint2*>(stage + rl * ACT_PITCH + nn * 2) = pk;                                         \
-      }                                                                                                          \
-    prev_tile = tile;                                                                                            \
-    ++it;                                                                                                        \
-    __syncthreads(); /* act may be overwritten, this tile's staging buffer is complete */                        \
-  }
-
-#pragma unroll 1
-  for (int tile = first_tile; tile < ntiles; tile += 2 * G) {
-    WREG_ITERATION(xa0, xa1, xa2, xa3)
+  // One tile.  WITH_PREV: the previous tile's stores ride on this tile's k loop.  Order of the memory instructions of an
+  // iteration: stores(t-1) x 4, then loads(t+2) x 4 -- so behind loads(t) sit exactly stores(t-2) and loads(t+1).
+  auto tile_body = [&](auto with_prev, const int tile) {
+    constexpr bool WITH_PREV = decltype(with_prev)::value;
+    W2STAMP(0);
+    if (it >= 2 && wave_has_cols) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    W2STAMP(1);
+    __builtin_amdgcn_s_barrier();          // every wavefront's share of this tile has landed; slot (t-1) % 3 is no longer read
+    asm volatile("" ::: "memory");
+    W2STAMP(2);
+    int nslot = slot + 2; if (nslot >= W2_NA) nslot -= W2_NA;
+    if (!wave_has_cols) {                  // (the fourth wavefront of a 192-column job only moves its share of the tiles)
+      dma_addr(tile + 2 * G);
+      dma_issue(nslot);
+    } else {
+      const char* ab = smem + slot * W2_ABYTES;
+      f32x16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+      f32x4 a[4];
+      f32x4 bv[8];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const f32x4*>(ab + aoff[ks & 7] + (ks >> 3) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[ks][j]),
+                                                           __builtin_bit_cast(bf16x8, a[ks & 3]), acc[j], 0, 0, 0);
+        if (ks + 4 < 16) a[ks & 3] = *reinterpret_cast<const f32x4*>(ab + aoff[(ks + 4) & 7] + ((ks + 4) >> 3) * 256);
+        // fillers, issued in the shadow of this step's MFMAs
+        if (WITH_PREV) {
+          if (ks == 0) { st_read(prev_tile, 0); st_read(prev_tile, 1); }
+          if (ks == 1) { st_read(prev_tile, 2); st_read(prev_tile, 3); }
+          if (ks == 2) st_addr(prev_tile);
+          if (ks == 4) { st_store(0); st_store(1); }
+          if (ks == 5) { st_store(2); st_store(3); }
+        }
+        if (ks == 6) dma_addr(tile + 2 * G);
+        if (ks == 7) dma_issue(nslot);
+        if (ks >= 8 && ks < 12) {
+          bv[2 * (ks - 8)] = *reinterpret_cast<const f32x4*>(bias_s + wn * 64 + ((ks - 8) >> 1) * 32 + 8 * (2 * ((ks - 8) & 1)) + 4 * h);
+          bv[2 * (ks - 8) + 1] = *reinterpret_cast<const f32x4*>(bias_s + wn * 64 + ((ks - 8) >> 1) * 32 + 8 * (2 * ((ks - 8) & 1) + 1) + 4 * h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      W2STAMP(5);
+      // epilogue: bias (requested during the k loop), bf16, into the wavefront's staging rows
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nn = j * 32 + 8 * g + 4 * h;
+          const f32x4 b4 = bv[4 * j + g];
+          uint2 pk;
+          pk.x = pack_bf16(acc[j][4 * g] + b4[0], acc[j][4 * g + 1] + b4[1]);
+          pk.y = pack_bf16(acc[j][4 * g + 2] + b4[2], acc[j][4 * g + 3] + b4[3]);
+          *reinterpret_cast<uint2*>(stage + rl * W2_STP + nn * 2) = pk;
+        }
+      prev_tile = tile;
+      W2STAMP(6);
+    }
+    slot = slot + 1 == W2_NA ? 0 : slot + 1;
+    ++it;
+  };
+  int tile = first_tile;
+  if (tile < ntiles) {
+    tile_body(std::false_type{}, tile);
     tile += G;
-    if (tile >= ntiles) break;
-    WREG_ITERATION(xb0, xb1, xb2, xb3)
-    tile -= G;
   }
-#undef WREG_ITERATION
-  if (prev_tile >= 0) store_tile(prev_tile, stage0 + ((it & 1) ^ 1) * RM * ACT_PITCH);
-}
-
-template <int NCPT>
-__global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  wreg_body<NCPT>(p, smem, blockIdx.x, gridDim.x);
+#pragma unroll 1
+  for (; tile < ntiles; tile += G) tile_body(std::true_type{}, tile);
+  W2STAMP_ALWAYS(10, __builtin_amdgcn_s_memtime());
+  W2STAMP_ALWAYS(12, (unsigned long long)it);
+  if (wave_has_cols && prev_tile >= 0) {
+    st_addr(prev_tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { st_read(prev_tile, i); st_store(i); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's look-ahead loads must not outlive the workgroup's LDS
+  W2STAMP_ALWAYS(11, __builtin_amdgcn_s_memtime());
+  W2STAMP_ALWAYS(14, __builtin_amdgcn_s_memrealtime());
 }
 
 // ---- several products of the SAME rows in one launch (round 5) -------------------------------------------------------------
@@ -179,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void wreg_gemm_kernel(WregParams p) {
 // (block b runs on XCD b & 7 -- observed dispatch order, used for speed only) are divided among the jobs in proportion to their
 // column counts; every job sweeps the XCD's row tiles (tiles t = 8 u + xcd) in the same order and at the same pace, so a tile
 // fetched by the first job's workgroup is served to the others by the XCD's L2: the pyramid crosses the fabric once per launch.
-// A workgroup keeps ONE job's weight slice in registers for its whole life exactly like wreg_gemm_kernel -- same loop, same k
+// A workgroup keeps ONE job's weight slice in registers for its whole life exactly like wreg2_gemm_kernel -- same loop, same k
 // order, bit-identical outputs.
 constexpr int WREG_MAX_JOBS = 8;
 constexpr int WREG_MAX_SLOTS = 64;       // workgroups per XCD: 32 CUs x 2
@@ -198,7 +304,15 @@ struct WregGroupParams {
   unsigned char job_slots[WREG_MAX_JOBS];   // slots per XCD of job j
 };
 
-__global__ __launch_bounds__(256, 2) void wreg_group_kernel(WregGroupParams gp) {
+// SMALL_S: images of fewer than 32 pixels (a tile may cross several image boundaries: the head-plane stores divide per lane)
+template <bool PLANES, bool SMALL_S>
+__global__ __launch_bounds__(256, 2) void wreg2_gemm_kernel(WregParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wreg2_body<PLANES, SMALL_S>(p, smem, blockIdx.x, gridDim.x);
+}
+
+template <bool SMALL_S>
+__global__ __launch_bounds__(256, 2) void wreg2_group_kernel(WregGroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int j = gp.slot_job[slot];
@@ -206,24 +320,38 @@ __global__ __launch_bounds__(256, 2) void wreg_group_kernel(WregGroupParams gp) 
   p.A = gp.A; p.M = gp.M; p.S_img = gp.S_img;
   p.Wf = gp.job[j].Wf; p.bias = gp.job[j].bias; p.out = gp.job[j].out; p.N = gp.job[j].N; p.rowmajor = gp.job[j].rowmajor;
   const int first = gp.slot_idx[slot] * 8 + xcd, stride = gp.job_slots[j] * 8;
-  if (!p.rowmajor) wreg_body<0>(p, smem, first, stride);
-  else wreg_body<3>(p, smem, first, stride);
+  if (!p.rowmajor) wreg2_body<true, SMALL_S>(p, smem, first, stride);
+  else wreg2_body<false, false>(p, smem, first, stride);
+}
+
+// > 64 KB of dynamic LDS: the attribute is per DEVICE (see launch_chain_a)
+int wreg2_configure() {
+  static bool configured[MVG_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
+  if (!configured[dev]) {
+    const void* fns[] = {reinterpret_cast<const void*>(&wreg2_gemm_kernel<true, false>),
+                         reinterpret_cast<const void*>(&wreg2_gemm_kernel<true, true>),
+                         reinterpret_cast<const void*>(&wreg2_gemm_kernel<false, false>),
+                         reinterpret_cast<const void*>(&wreg2_group_kernel<false>),
+                         reinterpret_cast<const void*>(&wreg2_group_kernel<true>)};
+    hipError_t e = hipSuccess;
+    for (const void* f : fns)
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+    if (e != hipSuccess) return (int)e;
+    configured[dev] = true;
+  }
+  return 0;
 }
 
 int launch_wreg(const WregParams& p, hipStream_t st) {
-  const size_t lds = 3 * RM * ACT_PITCH + 256 * sizeof(float);
-  const int TS = RM;
-  const int ntiles = (p.M + TS - 1) / TS;
+  if (p.N % 64 != 0 || p.N > 256) return MVG_E_BADARG;
+  if (int e = wreg2_configure()) return e;
+  const int ntiles = (p.M + RM - 1) / RM;
   const int grid = ntiles < g_wreg_grid ? ntiles : g_wreg_grid;      // persistent: 2 workgroups per CU
-#define WREG_LAUNCH(NC) hipLaunchKernelGGL((wreg_gemm_kernel<NC>), dim3(grid), dim3(256), lds, st, p)
-  if (!p.rowmajor) WREG_LAUNCH(0);
-  else switch (p.N / 64) {
-    case 1: WREG_LAUNCH(1); break;
-    case 2: WREG_LAUNCH(2); break;
-    case 3: WREG_LAUNCH(3); break;
-    default: WREG_LAUNCH(4); break;
-  }
-#undef WREG_LAUNCH
+  if (p.rowmajor) hipLaunchKernelGGL((wreg2_gemm_kernel<false, false>), dim3(grid), dim3(256), W2_LDS, st, p);
+  else if (p.S_img >= RM) hipLaunchKernelGGL((wreg2_gemm_kernel<true, false>), dim3(grid), dim3(256), W2_LDS, st, p);
+  else hipLaunchKernelGGL((wreg2_gemm_kernel<true, true>), dim3(grid), dim3(256), W2_LDS, st, p);
   MVG_LAUNCH_CHECK();
   return 0;
 }
@@ -287,8 +415,9 @@ extern "C" int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njob
         ++s;
       }
   gp.n_slots = n_slots;
-  const size_t lds = 3 * RM * ACT_PITCH + 256 * sizeof(float);
-  hipLaunchKernelGGL(wreg_group_kernel, dim3(8 * n_slots), dim3(256), lds, (hipStream_t)stream, gp);
+  if (int e = wreg2_configure()) return e;
+  if (gp.S_img >= RM) hipLaunchKernelGGL(wreg2_group_kernel<false>, dim3(8 * n_slots), dim3(256), W2_LDS, (hipStream_t)stream, gp);
+  else hipLaunchKernelGGL(wreg2_group_kernel<true>, dim3(8 * n_slots), dim3(256), W2_LDS, (hipStream_t)stream, gp);
   MVG_LAUNCH_CHECK();
   return 0;
 }

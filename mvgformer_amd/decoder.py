@@ -284,7 +284,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         return self._wc.get(key, params, dtype, build)
 
     # cached operands of the fused chains (csrc/chain.hip), in the order the ops take them
-    def _chain_a_weights(self, dt, fused_sampler=False):
+    def _chain_a_weights(self, dt):
         f32 = torch.float32
         pose_layers = self.pose_embed.MLP.layers
         sw = lambda w: ops.swizzle_weight(w.to(dt))
@@ -296,10 +296,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
         # o of a masked row, computed by the kernel that is going to use it (the variants reduce the last pose layer in
         # different orders; a masked row inside a mixed tile and one in an all-masked tile must agree bit for bit)
-        if fused_sampler:
-            o_masked = self._w("o_masked_sc", pose_params, f32, lambda *_: ops.gsamp_chain_masked_row_output(*wts))
-        else:
-            o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
+        o_masked = self._w("o_masked", pose_params, f32, lambda *_: ops.chain_masked_row_output(*wts))
         return wts, o_masked
 
     def _pose_masked_rows(self, dt):
@@ -396,9 +393,12 @@ class DQDecoderLayer(MvPDecoderLayer):
     def _fuses_chains_f32(self, dt, Lq=None, levels=None):
         """(chain A, chain B) of the fp32 path run as the fused f32s kernels (csrc/f32s.hip)"""
         pose_layers = self.pose_embed.MLP.layers
-        ok = dt == torch.float32 and self.use_fused_chains_f32 and self.d_model == 256
+        from . import _lib
+        # the library's f32_split knob (bench.py --f32-gemm exact) selects the reference-arithmetic GEMMs: the fused kernels, whose
+        # products are split by construction, stand down with it
+        ok = (dt == torch.float32 and self.use_fused_chains_f32 and self.d_model == 256 and _lib.TUNING.get("f32_split", 1) != 0)
         fuse_a = (ok and len(pose_layers) == 3 and pose_layers[0].out_features == 256 and pose_layers[1].out_features == 256
-                  and pose_layers[0].in_features == 256 and self.proj_attn.f32_fused
+                  and pose_layers[0].in_features == 256 and self.proj_attn.f32_fused_active()
                   and (levels is None or self.proj_attn.f32_g_form(Lq, levels.L, levels.S)))
         fuse_b = (ok and self.num_joints <= 32 and (not self.open_forward_ffn or (self.linear1.out_features == 1024 and
                                                                                    self.linear1.in_features == 256)))
@@ -429,7 +429,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             if dt == torch.float32 and self.proj_attn.g_sampling_f32 is not False and \
                     self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192:
                 self.proj_attn._fast_query_weights(dt)      # the fp32 G-sampling branch of native_sample (Woa_perm / boa_perm)
-                if self.proj_attn.f32_fused and self.proj_attn.rayconv.weight.shape == (256, 256):
+                if self.proj_attn.f32_fused_active() and self.proj_attn.rayconv.weight.shape == (256, 256):
                     self.proj_attn.query_term_weights_f32s()
                     from . import projattn as _pa
                     if _pa.F32_H2:
@@ -438,14 +438,21 @@ class DQDecoderLayer(MvPDecoderLayer):
             if fa32:
                 self._chain_a_weights_f32h() if F32_CHAIN_H2 else self._chain_a_weights_f32s()
             if fb32:
+                # (the query-term operand indexes rows 0..191 of [offsets; logits]: only with the G form's geometry, like every
+                # other operand of that form)
+                g_geometry = (self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192
+                              and self.proj_attn.rayconv.weight.shape == (256, 256))
                 if F32_CHAIN_H2:
                     self._chain_b_weights_f32h()
-                    self.proj_attn.query_term_weights_f32h()
+                    if g_geometry:
+                        self.proj_attn.query_term_weights_f32h()
                 else:
                     self._chain_b_weights_f32s()
+                    if g_geometry:
+                        self.proj_attn.query_term_weights_f32s()
         fuse_a, fuse_b = self._fuses_chains(dt)
         if fuse_a:
-            self._chain_a_weights(dt, fused_sampler=self.proj_attn.fuse_sampler_chain)
+            self._chain_a_weights(dt)
         if fuse_b:
             self._chain_b_weights(dt)
         return self
@@ -506,10 +513,12 @@ class DQDecoderLayer(MvPDecoderLayer):
         # DecoderContext when the layer runs inside DQDecoder.forward -- as torch ops per layer they were ~40 launches each.
         ctx = self._ctx
         tc = getattr(ctx, "_train_cache", None) if ctx is not None else None
+        if tc is not None and tc["key"] != (ctx.cams.data_ptr(), ctx.cams._version):
+            tc = None           # the context was given new camera records: projection matrices and records are rebuilt
         if tc is None:
             cams = ctx.cams if ctx is not None else ops.pack_cameras(meta, self.img_size, dev)
             tc = dict(cams=cams, levels=ctx.levels if ctx is not None else ops.Levels(src_spatial_shapes, level_start_index),
-                      Pm=G.proj_matrices_from_records(cams, V, B))
+                      Pm=G.proj_matrices_from_records(cams, V, B), key=(cams.data_ptr(), cams._version))
             if ctx is not None:
                 ctx._train_cache = tc
         # all V views as ONE batch of V*B images (image n = v*B + b, the order of src_views): one projection, one ProjAttn
@@ -613,15 +622,10 @@ class DQDecoderLayer(MvPDecoderLayer):
                 order = ctx.order
             elif mode:
                 order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
-            if self.proj_attn.fuse_sampler_chain:       # one kernel: the sampled rows never leave the CU
-                wts, o_masked = self._chain_a_weights(dt, fused_sampler=True)
-                attn, o = self.proj_attn.native_sample_chain(x, ref_lvl, ctx.feat, ctx.levels, V, B, inside.view(-1), order,
-                                                             xw_in, wts, o_masked)
-            else:
-                samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
-                                                    order=order, xw=xw_in)
-                wts, o_masked = self._chain_a_weights(dt)
-                attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+            samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
+                                                order=order, xw=xw_in)
+            wts, o_masked = self._chain_a_weights(dt)
+            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         elif self._fuses_chains_f32(dt, Lq, ctx.levels)[0] and C == 256:
             # fp32, fused: G-sampling kernel + chain A on pre-split operands (csrc/f32s.hip); pairs in processing order, masked
             # pairs last (zero-filled by the sampler, all-masked tiles skipped by the chain)
@@ -794,6 +798,9 @@ class DQDecoder(MvPDecoder):
         # pack the pyramid on the side stream in front of its consumers: the first layer's query-side prologue (projection, pair
         # binning, query term) then runs next to the pack instead of behind it
         self.pack_on_side = os.environ.get("MVG_PACK_ON_SIDE", "1") != "0"
+        pool = {}
+        for layer in self.layers:       # the inline fp32 pyramid products share one (value, G) pair per stream -- of THIS decoder
+            layer.proj_attn._f32_pool = pool
         self.view_group = os.environ.get("MVG_VIEW_GROUP", "0")
         self.view_group_depth = int(os.environ.get("MVG_VIEW_GROUP_DEPTH", "2"))
 

@@ -472,46 +472,6 @@ def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None, out=None, im
     return samp
 
 
-def msda_gsamp_chain(vp, G, xw, r, levels, B, inside, order, Wp, bp, W0, b0, W1, b1, W2, b2, o_masked=None):
-    """fused sampler + chain A (include/mvg_decoder.h: mvg_msda_gsamp_chain): msda_gsamp's operands + chain_attn_pose's
-    weights -> (attn bf16 (n_img*Lq, 256), o f32 (n_img*Lq, 3)); the sampled rows stay in LDS."""
-    n_img = vp.shape[0]
-    Lq = r.shape[1]
-    rows = n_img * Lq
-    attn = torch.empty((rows, 256), dtype=torch.bfloat16, device=vp.device)
-    o = torch.empty((rows, 3), dtype=torch.float32, device=vp.device)
-    assert inside.dtype == torch.uint8 and inside.numel() == rows and inside.is_contiguous()
-    if order is not None:
-        assert order.dtype == torch.int32 and order.numel() == rows and order.is_contiguous()
-    with _timed("msda_gsamp_chain"):
-      L.check(L.load().mvg_msda_gsamp_chain(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
-                                            L.ptr(inside), None if order is None else L.ptr(order), L.ptr(Wp), L.ptr(bp),
-                                            L.ptr(W0), L.ptr(b0), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn),
-                                            L.ptr(o), None if o_masked is None else L.ptr(o_masked), n_img, Lq, levels.L,
-                                            levels.S, B, L.stream_ptr()), "mvg_msda_gsamp_chain")
-    return attn, o
-
-
-def gsamp_chain_masked_row_output(Wp, bp, W0, b0, W1, b1, W2, b2):
-    """o (3,) f32 of a row with inside == 0 as the FUSED kernel computes it (its last pose layer reduces in another order
-    than the 128-row chain A: the two must not be mixed): the fused kernel run on one masked pair (weights only ->
-    cacheable).  The sampler operands are never read for a masked pair; tiny dummies stand in."""
-    dev = Wp.device
-    lv = Levels([[1, 1]], [0])
-    vp = torch.zeros((1, 8, 1, 32), dtype=torch.bfloat16, device=dev)
-    G = torch.zeros((1, 192), dtype=torch.bfloat16, device=dev)
-    xw = torch.zeros((1, 192), dtype=torch.float32, device=dev)
-    r = torch.zeros((1, 1, 1, 2), dtype=torch.float32, device=dev)
-    inside = torch.zeros((1,), dtype=torch.uint8, device=dev)
-    global PROFILE
-    saved, PROFILE = PROFILE, None
-    try:
-        _, o = msda_gsamp_chain(vp, G, xw, r, lv, 1, inside, None, Wp, bp, W0, b0, W1, b1, W2, b2, o_masked=None)
-    finally:
-        PROFILE = saved
-    return o.reshape(3)
-
-
 def bin_pairs(r, inside, levels, out=None):
     """processing order of the (image, query) pairs for msda_gsamp: Morton-sorted by level-0 cell block, pairs with
     inside == 0 last.  r (n_img, Lq, L, 2) per-level reference points; inside (n_img, Lq) u8 or None."""

@@ -36,8 +36,6 @@ def _is_power_of_2(n):
     return (n & (n - 1) == 0) and n != 0
 
 
-# fp32 value / G products of the inline schedule: one pair per (device, stream), shared by every layer (project_pyramid)
-_SHARED_F32 = {}
 # fp32 pyramid products on two-part fp16 operands (three MFMAs per product instead of six; same accuracy against fp64); 0 = the six-product bf16 form
 F32_H2 = os.environ.get("MVG_F32_H2", "1") != "0"
 
@@ -107,12 +105,6 @@ class ProjAttn(nn.Module):
         self.use_fast_path = True
         # bf16 fast path: sample the pairs in image-space (Morton) order.  "layer"/True: binned per layer; "first":
         # DQDecoderLayer bins once per forward (first layer) and reuses the order; False: query order
-        # bf16 fast path: sampler and chain A as ONE kernel (csrc/sampchain.hip) instead of two launches.  Built, bit-exact
-        # against the two-kernel form, and measured SLOWER on MI355X (cfg-2: 197 us vs 138 + 38 us per layer; its gather
-        # phase alone takes 175 us: 16 instead of 20 waves per CU and a workgroup barrier in front of the chain phase cost
-        # more than the 20 us of chain A that do hide under the other workgroup's gathers) -- so it is off by default;
-        # MVG_FUSE_SAMPLER=1 selects it.
-        self.fuse_sampler_chain = os.environ.get("MVG_FUSE_SAMPLER", "0") == "1"
         # fp32 path: G-sampling (csrc/msda.hip: msda_gfused_f32_kernel) instead of gather -> Linear -> fused sampling.
         # True / False, or "auto": wherever the offsets / logits Linear has fewer rows on the pyramid (V*S) than on the
         # gathered reference points (V*Lq*L) -- cfg-2: 40 320 vs 46 080 rows per image, 6.80 -> 6.26 ms; cfg-4 (512 queries:
@@ -131,6 +123,9 @@ class ProjAttn(nn.Module):
         self._vp = None
         self._vp_event = None
         self._G = None
+        # inline fp32 pyramid products: one (value, G) pair per (device, stream) shared by the layers of ONE decoder (DQDecoder
+        # hands its layers a common dict); it dies with its owner
+        self._f32_pool = {}
 
     def _reset_parameters(self):
         constant_(self.sampling_offsets.weight.data, 0.)
@@ -181,11 +176,18 @@ class ProjAttn(nn.Module):
         self.query_term_weights(dtype)
         self._fast_query_weights(dtype)
 
+    def f32_fused_active(self):
+        """the fused fp32 kernels on split operands (csrc/f32s.hip) are in use: MVG_F32_FUSED and the library's f32_split knob
+        (bench.py --f32-gemm exact, mvg_set_tuning("f32_split", 0)) both select them; with either off the fp32 path is the
+        reference-arithmetic decomposition (fmaf-chain GEMMs, one launch each)"""
+        from . import _lib
+        return bool(self.f32_fused) and _lib.TUNING.get("f32_split", 1) != 0
+
     def f32_g_form(self, Lq, L, S):
         """fp32 path: G-sampling (the offsets / logits Linear applied to the pyramid) rather than gather-then-Linear -- by
         MVG_G_SAMPLING_F32, else whenever the gathered rows (Lq * L per image) outnumber the pyramid's (S)"""
         geometry = self.sampling_offsets.out_features + self.attention_weights.out_features == 192 and self.rayconv.weight.shape == (256, 256)
-        if self.g_sampling_f32 == "auto" and self.f32_fused and geometry:
+        if self.g_sampling_f32 == "auto" and self.f32_fused_active() and geometry:
             # with the one-pass pyramid kernel (mvg_pyramid_f32s) the G form moves fewer bytes at every shipped shape: the gather
             # form re-fetched 2.6 x its algorithmic bytes at cfg-4 (profiles/r03_bench_cfg4_fp32.json)
             return True
@@ -212,20 +214,20 @@ class ProjAttn(nn.Module):
             if record_event:
                 # side-stream schedule: every layer's products exist at the same time -> one pair of buffers per layer
                 if (self._vp is None or self._vp.dtype != dt or tuple(self._vp.shape) != (n_img, S, Cc) or self._vp.device != feat.device
-                        or any(self._vp is pair[0] for pair in _SHARED_F32.values())):
+                        or any(self._vp is pair[0] for pair in self._f32_pool.values())):
                     self._vp = torch.empty((n_img, S, Cc), dtype=dt, device=feat.device)
                     self._G = torch.empty((n_img * S, 192), dtype=dt, device=feat.device)
             else:
                 # inline (overlap off, or under autograd): a layer's products are dead once its sampler ran, the next layer's are
-                # written behind it on the same stream -> ONE pair for all layers of the decoders on this stream (0.36 GB at cfg-2
+                # written behind it on the same stream -> ONE pair for all layers of this decoder on this stream (0.36 GB at cfg-2
                 # instead of 0.36 GB per layer held for the model's lifetime)
                 slot = (feat.device, torch.cuda.current_stream(feat.device).cuda_stream)      # streams do not share (decoders in flight)
-                cur = _SHARED_F32.get(slot)
+                cur = self._f32_pool.get(slot)
                 if cur is None or tuple(cur[0].shape) != (n_img, S, Cc):
-                    cur = _SHARED_F32[slot] = (torch.empty((n_img, S, Cc), dtype=dt, device=feat.device),
+                    cur = self._f32_pool[slot] = (torch.empty((n_img, S, Cc), dtype=dt, device=feat.device),
                                                torch.empty((n_img * S, 192), dtype=dt, device=feat.device))
                 self._vp, self._G = cur
-            if self.f32_fused and Cc == 256 and feat.is_contiguous():
+            if self.f32_fused_active() and Cc == 256 and feat.is_contiguous():
                 if F32_H2:     # two-part fp16 operands, three products (csrc/f32s.hip: pyramid_f32h_kernel)
                     (Wv_pl, sv), (Wg_pl, sg) = self.pyramid_planes_f32h()
                     ops.pyramid_f32h(feat, Wv_pl, sv, bv, Wg_pl, sg, 192, value=self._vp, G=self._G)   # projattn.py:169 + 180-181
@@ -405,19 +407,6 @@ class ProjAttn(nn.Module):
         oa = ops.linear(ain, Woa, boa, out_dtype=torch.float32)              # projattn.py:180-181
         value = ops.linear(feat.view(n_img * S, Cc), Wv, bv, out_dtype=dt)   # projattn.py:169
         return ops.msda_fused(value.view(n_img, S, Cc), oa, r, levels)       # projattn.py:184-200
-
-    def native_sample_chain(self, x, r, feat, levels, V, B, inside, order, xw, chain_weights, o_masked):
-        """bf16 fast path of native_sample with chain A (output projection x in-image mask, pose MLP) fused into the
-        sampling kernel (csrc/sampchain.hip): returns (attn (V*B*Lq, 256) bf16, o (V*B*Lq, 3) f32)."""
-        dt = feat.dtype
-        assert self.uses_fast_path(dt)
-        if order is None and self.sort_pairs and r.shape[1] <= 65536:
-            order = ops.bin_pairs(r, inside, levels)
-        if xw is None:
-            Wq, bq = self._fast_query_weights(dt)
-            xw = ops.linear((x() if callable(x) else x).reshape(-1, feat.shape[2]), Wq, bq, out_dtype=torch.float32)
-        vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
-        return ops.msda_gsamp_chain(vp, G, xw, r, levels, B, inside, order, *chain_weights, o_masked=o_masked)
 
     # ------------------------------------------------------------------------------- forward
     def _step(self, n):

@@ -464,52 +464,6 @@ def test_train_mode_without_autograd_applies_dropout():
     assert torch.equal(tr0[0], ev[0])
 
 
-def test_fused_sampler_chain_kernel_equals_the_two_kernel_form():
-    """csrc/sampchain.hip (sampler + chain A in one kernel; MVG_FUSE_SAMPLER=1 -- measured slower than the two launches
-    on MI355X, so not the default) against the two launches it replaces: BIT-identical to msda_gsamp + the 64-row / 8-wavefront / column-split chain A (same device functions, same
-    per-row arithmetic) on a full-size cfg-2 layer stack and on the small cases with masked pairs, uneven batches and the
-    forced-(0,0) rule; within bf16 rounding of the default (128-row) two-kernel chain A."""
-    from mvgformer_amd import _lib
-    from mvgformer_amd.factory import build_decoder_for_case, case_to_device
-    from tests.golden.cases import LAYER_CASES
-    lib = _lib.load()
-    cases = [build_case("cfg2", seed=1, layers=2)]
-    for cname in ("mini5_half", "mini5_b2", "mini5_empty"):
-        sp = LAYER_CASES[cname]
-        cases.append(build_case(sp["config"], B=sp.get("B", 1), seed=sp["seed"], NQ=sp.get("NQ"), layers=sp["layers"],
-                                valid_fraction=sp.get("valid_fraction")))
-    for case in cases:
-        dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
-        g = case_to_device(case, DEV)
-        def run(fused):
-            for layer in dec.layers:
-                layer.proj_attn.fuse_sampler_chain = fused
-            return _run(dec, g)
-        fused = run(True)
-        fused2 = run(True)
-        two_default = run(False)
-        try:
-            for k, v in (("chain_rm", 64), ("chain_a_waves", 8), ("chain_split", 1)):
-                _lib.check(lib.mvg_set_tuning(k.encode(), v), k)
-            for layer in dec.layers:            # o_masked of the unfused path is cached per variant: rebuild it
-                layer._wc._store.pop("o_masked", None)
-            two_same = run(False)
-        finally:
-            for k, v in (("chain_rm", 128), ("chain_a_waves", 4), ("chain_split", 1)):
-                _lib.check(lib.mvg_set_tuning(k.encode(), v), k)
-            for layer in dec.layers:
-                layer._wc._store.pop("o_masked", None)
-        for a, b, c in zip(fused[:4], fused2[:4], two_same[:4]):
-            assert torch.equal(a, b), "run-to-run (%s)" % case.name
-            assert torch.equal(a, c), "fused vs two kernels, same chain variant (%s)" % case.name
-        assert all(torch.equal(a, c) for a, c in zip(fused[4], two_same[4]))
-        assert torch.equal(fused[1].abs().sum(-1) > 0, two_default[1].abs().sum(-1) > 0)
-        e_hs = float((fused[0][0] - two_default[0][0]).abs().max())
-        e_px = float((fused[2][0] - two_default[2][0]).abs().max())
-        print("%s: fused vs default two-kernel chain A, layer 0: |hs| %.2e  2D %.2e px" % (case.name, e_hs, e_px))
-        assert e_hs < 2e-2 and e_px < 2e-2
-
-
 def test_triangulation_launch_also_projects_for_the_next_layer():
     """mvg_triangulate_project: the next layer's (r, ref_lvl, inside) written by the triangulation launch are bit-identical to
     mvg_project run on the new reference points (zeros for queries that did not pass included), and the triangulated points

@@ -1617,11 +1617,9 @@ _KNOBS = [("gsamp_pipe", 1, True), ("gsamp_pipe", 2, True), ("linear_tiles", 0, 
           ("gsamp_map", 8, True), ("bin_multi", 0, True), ("auto_small", 0, True), ("wreg_grid", 256, True),
           ("wreg_grid", 64, True), ("auto_small_b", 0, False), ("auto_small_a", 0, True), ("chain_rm", 64, True), ("chain_rm", 256, False),
           ("chain_a_waves", 8, False), ("chain_waves", 4, False), ("chain_split", 0, False), ("chain_ring", 8, False),
-          ("chain_ring", 16, False), ("sampchain_map", 1, True), ("sampchain_map", 16, True)]
+          ("chain_ring", 16, False)]
 _KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, linear_xcd=1, tri_lanes=0, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, auto_small_b=1, auto_small_a=1, chain_rm=128,
-                      chain_a_waves=4, chain_waves=8, chain_split=1, chain_ring=4, sampchain_map=4)
-# knobs of the fused sampler + chain A kernel (csrc/sampchain.hip, MVG_FUSE_SAMPLER=1); the default is the two-kernel form
-_FUSED_KERNEL_KNOBS = ("sampchain_map",)
+                      chain_a_waves=4, chain_waves=8, chain_split=1, chain_ring=4)
 
 
 @pytest.mark.parametrize("key,value,exact", _KNOBS, ids=["%s=%d" % (k, v) for k, v, _ in _KNOBS])
@@ -1635,8 +1633,6 @@ def test_every_kernel_variant_behind_a_tuning_knob(key, value, exact):
     lib = _lib.load()
     case = build_case("cfg2", seed=11, NQ=160, layers=2)            # Lq = 2400 per image, 12 000 pairs
     dec = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
-    for layer in dec.layers:
-        layer.proj_attn.fuse_sampler_chain = key in _FUSED_KERNEL_KNOBS
     gc = case_to_device(case, DEV)
     run = lambda: [t.float().clone() for t in dec(gc.tgt, gc.reference_points, gc.src_views, gc.meta, gc.spatial_shapes,
                                                   gc.level_start_index, None, query_pos=gc.query_pos, threshold=0.1)[:4]]

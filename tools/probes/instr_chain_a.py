@@ -4,7 +4,7 @@ of each tile's first row (call it without a processing order).
 
     cd mvgformer_amd/csrc && python ../../tools/probes/instr_chain_a.py
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize -c chain_exp.hip -o /tmp/chain_e.o
-    hipcc --offload-arch=gfx950 -shared -o ../_exp_CA.so api.o msda.o geom.o gemm.o /tmp/chain_e.o wreg_gemm.o sampchain.o msda_bwd.o
+    hipcc --offload-arch=gfx950 -shared -o ../_exp_CA.so api.o msda.o geom.o gemm.o /tmp/chain_e.o wreg_gemm.o msda_bwd.o
     (GPU box)  cp mvgformer_amd/_exp_CA.so mvgformer_amd/libmvgformer_hip.so; python tools/probes/time_chain_a.py"""
 s = open("chain.hip").read()
 d = open("chain_dev.h").read()

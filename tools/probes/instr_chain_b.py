@@ -3,7 +3,7 @@ commit this file belongs to) whose kernel stores per-phase cycle counts into the
 
     cd mvgformer_amd/csrc && python ../../tools/probes/instr_chain_b.py chain.hip chain_exp.hip
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize -c chain_exp.hip -o /tmp/chain_e.o
-    hipcc --offload-arch=gfx950 -shared -o ../_exp_CB.so api.o msda.o geom.o gemm.o /tmp/chain_e.o wreg_gemm.o sampchain.o msda_bwd.o
+    hipcc --offload-arch=gfx950 -shared -o ../_exp_CB.so api.o msda.o geom.o gemm.o /tmp/chain_e.o wreg_gemm.o msda_bwd.o
     (GPU box)  cp mvgformer_amd/_exp_CB.so mvgformer_amd/libmvgformer_hip.so; python tools/probes/time_chain_b.py
 Results of round 3: profiles/r03_experiments.txt."""
 import sys
