@@ -780,9 +780,9 @@ def main():
                                     "frac": round(gflop / us / 1e6 / 2500.0, 4), "launches_per_forward": launches_per_forward}
         add("chain_a", "chain_attn_pose", fl["chain_a"], Ly)
         add("chain_b", "chain_update_ffn_class", fl["chain_b"] + fl["query_term"], Ly)
-        add("chain_a", "chain_attn_pose_f32s", fl["chain_a"], Ly)                     # fp32: the two-part fp16 kernels (same profile key)
-        add("chain_b", "chain_update_ffn_class_f32s", fl["chain_b"] + fl["query_term"], Ly)
-        add("pyramid_value_and_G", "pyramid_f32s", fl["value"] + fl["G"], Ly)
+        add("chain_a", "chain_attn_pose_f32h", fl["chain_a"], Ly)                     # fp32: the two-part fp16 kernels
+        add("chain_b", "chain_update_ffn_class_f32h", fl["chain_b"] + fl["query_term"], Ly)
+        add("pyramid_value_and_G", "pyramid_f32h", fl["value"] + fl["G"], Ly)
         add("value_proj", "value_proj_ws", fl["value"], Ly)
         add("feat_linear", "feat_linear_ws", fl["G"], Ly)
         add("pyramid_group_first_layer", "pyramid_group_ws_2", fl["value"] + fl["G"], 1)
@@ -804,7 +804,7 @@ def main():
     if prof and args.profile_steps > 0:
         n_pyr = args.batch * V * S          # rows of the pyramid GEMMs: query-independent whatever the path (fp32: plain linears)
         grouped = any(k.startswith("pyramid_group_ws_") for k in prof)    # the timed schedule's launches replace the per-product ones
-        fixed_keys = ("pack_level", "pack_level_nhwc", "pyramid_all_layers", "pyramid_f32s") + (
+        fixed_keys = ("pack_level", "pack_level_nhwc", "pyramid_all_layers", "pyramid_f32h") + (
             tuple(k for k in prof if k.startswith("pyramid_group_ws_")) if grouped else ("value_proj_ws", "feat_linear_ws")) + (
                       "linear_%dx256x256" % n_pyr, "linear_%dx192x256" % n_pyr)
         skip = ("value_proj_ws", "feat_linear_ws") if grouped else ()
@@ -886,7 +886,7 @@ def main():
                    "samples_in_flight": args.inflight, "samples_per_forward": args.batch,
                    **({"fp32_gemm": {"split": "fused kernels (pyramid products, chains A / B): operands scaled per row / tensor by a power of two and "
                                               "split into 2 fp16 parts, 3 fp16 MFMA products, fp32 accumulate; the first layer's query term: 3 "
-                                              "bf16 parts, 6 bf16 MFMA products (MVG_F32_H2=0 MVG_F32_CHAIN_H2=0: that form everywhere)",
+                                              "bf16 parts, 6 bf16 MFMA products",
                                      "exact": "v_mfma_f32_32x32x2_f32 (fmaf chain)"}[args.f32_gemm]}
                       if args.dtype == "fp32" else {}),
                    "hip_graph": graph is not None, "device": arch, "cus": cus},

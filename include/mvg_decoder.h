@@ -55,24 +55,21 @@ extern "C" {
  * usable device is present; MVG_E_NOGPU otherwise.  Host-only. */
 int mvg_device_info(char* arch_out, int arch_len, int* cu_count);
 const char* mvg_version(void);
-/* Kernel-variant knobs for A/B measurements (host-only, process-wide; env MVG_TUNE="k=v,..").  Keys:
- *   "fused_cpl_bf16" = 4 | 8 : channels per lane of the generic fused sampling kernel (bf16);
- *   "gsamp_threads" = 128 | 256 | 512 | 1024 : workgroup size of the G-sampling kernel; "gsamp_map" = 0 | n : its
- *       XCD block mapping (chunks of n slot blocks per XCD, 0 = one head per XCD);
- *   "auto_small" = 1 | 0 : launches with few queries per image (<= 8192 joint tokens, e.g. a rank's shard of a
- *       query-sharded run) use 128-thread sampling workgroups and single-block chunks (bit-identical results);
- *   "auto_small_b" = 1 | 0 : chain B with 32-row tiles (2 persons) while that leaves at most 128 of the 64-row tiles;
- *   "auto_small_a" = 1 | 0 : chain A with 64-row tiles while the launch has at most 320 tiles of 128 rows (bit-identical rows);
- *   "chain_rm" = 64 | 128 | 256, "chain_a_waves" / "chain_waves" = 4 | 8, "chain_split" = 0 | 1, "chain_ring" = 4 | 8 | 16 :
- *       geometry of the fused Linear chains;  "wreg_grid" = persistent workgroups of the weight-stationary GEMMs;
- *   "bin_multi" = 1 | 0 : multi-workgroup binning for large Lq (needs the workspace of mvg_bin_pairs);
- *   "gsamp_pipe" = 0 | 1 | 2 : sampler gather loop (default / double-buffered / LDS window for the coarsest level);
- *   "f32_split" = 1 | 0 : fp32 GEMMs as six bf16 MFMA products on operands split into three bf16 parts (default) or as
- *       v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);  "linear_tiles" = 0 | 1 | 2, "linear_xcd" = 1 | 0 : tile shapes and
- *       XCD-aware tile order of mvg_linear*;  "tri_lanes" = 0 | 1 : one-lane (default) or lane-parallel Jacobi in mvg_triangulate*.
- * The sampler / binning / GEMM-grid / triangulation knobs select bit-identical results; the chain-geometry knobs change the order
- * of an fp32 sum (differences at bf16 rounding), f32_split the rounding of the fp32 products (tests/test_hip_parity.py:
- * test_every_kernel_variant_behind_a_tuning_knob). */
+/* Kernel-variant knobs for A/B measurements.  PROCESS-GLOBAL and not thread-safe: a value set here applies to every later call
+ * of every entry point from every thread, whatever the stream or device; set knobs before the first launch (or from one thread
+ * while nothing is in flight), never as per-request state.  Host-only.  Env MVG_TUNE="key=value,..." sets them at load time.
+ *   "gsamp_threads" = 128 | 256 | 512 | 1024, "gsamp_map" = 0 | n : workgroup size and XCD block mapping of the G-sampling kernel
+ *       (chunks of n slot blocks per XCD, 0 = one head per XCD);  "gsamp_pipe" = 0 | 1 : its gather loop (1 = double-buffered);
+ *   "gfused_chunk" = 0 | n : the same mapping for the fp32 G-sampling kernel;  "fwd_map" = 0 | 1 | 2 : decomposition of mvg_msda_forward;
+ *   "auto_small" = 1 | 0 : launches with few rows (a rank's shard of a query-sharded run) use smaller workgroups / tiles in the
+ *       sampler, chain A (64-row tiles up to 320 tiles of 128 rows) and chain B (32-row tiles up to 128 tiles of 64 rows);
+ *   "chain_rm" = 64 | 128 | 256 : rows per tile of mvg_chain_attn_pose;  "f32h_rows" = 0 | 32 | 64 : rows per tile of the fp32 chains;
+ *   "wreg_grid" = n : persistent workgroups of mvg_pyramid_group_ws;  "bin_multi" = 1 | 0 : multi-workgroup binning for large Lq;
+ *   "linear_tiles" = 0 | 1 | 2 : tile shapes of mvg_linear*;
+ *   "f32_split" = 1 | 0 : fp32 GEMMs of mvg_linear* as six bf16 MFMA products on operands split into three bf16 parts (default) or
+ *       as v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain); with 0 the Python layer also stands the fused fp32 kernels down.
+ * Every knob but f32_split, auto_small (chain B's 32-row tiles sum the FFN in another order) and chain_rm = 256 selects
+ * bit-identical results (tests/test_hip_parity.py: test_every_kernel_variant_behind_a_tuning_knob). */
 int mvg_set_tuning(const char* key, int value);
 
 /* ---- Deformable.deform_forward / deform_backward (deform.h:32-72) -------------------
@@ -126,10 +123,6 @@ int mvg_msda_backward_det_f32(const float* value, const int64_t* shapes_host, co
 
 /* ---- stage entry points of the decoder layer ------------------------------------------ */
 
-/* (N_img,C,H,W) NCHW level -> rows [start, start+H*W) of the channels-last pyramid
- * feat (N_img,S,C).  src dtype f32; dst dtype `dtype`.  (replaces cat+permute, projattn.py:160) */
-int mvg_pack_level(const float* src_nchw, void* feat, int dtype, int N_img, int C, int H, int W,
-                   int S, int start, void* stream);
 
 /* all L levels in one launch: src_nchw_host = HOST array of L device pointers to the (N_img,C,H_l,W_l) maps */
 int mvg_pack_pyramid(const float* const* src_nchw_host, void* feat, int dtype, int N_img, int C, const int64_t* shapes_host,
@@ -167,20 +160,7 @@ int mvg_linear_ordered(const float* A, int lda, const float* W, const float* bia
                        const uint8_t* rowmask, int relu, int M, int N, int K, const int32_t* order,
                        const uint8_t* inside, const float* masked_row, void* stream);
 
-/* Split-K form of the fp32 mvg_linear for reductions far longer than the output is wide -- the weight gradient of a Linear under
- * autograd, dW (N_out, K_in) = dY^T X summed over 10^4 .. 10^5 rows (lib/models/dq_decoder.py:659-717,763-778 trained by
- * run/train_3d.py): partial[z] (M, N) = A[:, z K/splits : (z + 1) K/splits] @ W[:, same range]^T for z < splits; the caller sums
- * the partials (a fixed order: deterministic).  A (M, K) / W (N, K) fp32 with leading dimensions lda / ldw; K / splits a multiple
- * of 32; no bias / activation. */
-int mvg_linear_splitk_f32(const float* A, int lda, const float* W, int ldw, float* partial, int M, int N, int K, int splits,
-                          void* stream);
 
-/* The weight gradient itself, from the row-major tensors autograd holds: partial[z] (N, K) = sum over the rows of slice z of
- * dY[r][n] X[r][k]  (dY (rows, N), X (rows, K) fp32, leading dimensions ldy / ldx; the rows are cut into `splits` slices of whole
- * 32-row slabs, slices past the end write zeros).  Split-form products like mvg_linear; the operands are transposed on their way
- * into LDS, no dY^T / X^T copies.  N, K multiples of 4. */
-int mvg_linear_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, int rows, int N, int K, int splits,
-                         void* stream);
 
 /* The same with the bias gradient and the sum over the slices: dW (N, K) = dY^T X and, when db is not NULL, db (N) = the column sums
  * of dY (what autograd's Linear backward returns for weight and bias, lib/models/dq_decoder.py:659-717 under run/train_3d.py).
@@ -216,23 +196,6 @@ int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, con
                         const uint8_t* pair_mask, const int32_t* order,
                         int N_img, int Lq, int L, int S, int B, void* stream);
 
-/* ---- bf16 fast path of the ProjAttn front end (replaces mvg_gather_ref + 2 x mvg_linear + mvg_msda_fused) ----
- * Bilinear sampling commutes with a Linear: Linear(bilinear(feat,p) + x) = bilinear(feat@W^T, p) + (x@W^T + b).
- *   mvg_value_proj_planes_ws : rayconv Linear (projattn.py:169) of the packed bf16 pyramid, written as head planes
- *       vh[img][head 8][s][ch 32] (bf16, n_img*8*S*32 elements): the 32 channels of (pixel, head) are 64 contiguous bytes.
- *   mvg_feat_linear_ws      : G (n_img*S, N) bf16 row-major = feat @ W^T, no bias (N = 192: the [offsets; logits]
- *       rows in the order of mvgformer_amd.ops.gsamp_column_order: 8 groups of 16 offset + 8 logit outputs, so that
- *       with the reference's memory reinterpretation the 72 values a head needs are contiguous in a G row).
- *   mvg_msda_gsamp          : per (image, query, head): gathers its 24 logits + 48 offsets from G at the reference
- *       point, adds xw (B*Lq,192) f32 = (tgt+query_pos) @ W^T + b (same column order as G), softmax, locations, samples vh -> samp
- *       (N_img*Lq, 256) bf16.  M=8, D=32, P=8, L<=4.  pair_mask (N_img*Lq) u8 or NULL: rows with mask 0 are
- *       written as zeros without being sampled (the consumer multiplies exactly these rows by the in-image mask,
- *       dq_decoder.py:585-586).  order (N_img*Lq) i32 or NULL: slot i of the launch computes pair order[i].
- * Weights Wf: bf16, zero-padded to 256 rows, MFMA-fragment order [wn 4][ks 16][j 2][lane 64][8]
- * (mvgformer_amd.ops.swizzle_weight); the kernels keep them in registers (weight-stationary, csrc/wreg_gemm.hip). */
-int mvg_value_proj_planes_ws(const void* feat, const void* Wf, const float* bias, void* vh, int n_img, int S,
-                             void* stream);
-int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream);
 /* Several of the two products above over the SAME packed pyramid in ONE launch (round 5): job j is a value projection into head
  * planes (planes[j] != 0: N[j] = 256, bias[j] required, out[j] = vh) or a G product (planes[j] == 0: N[j] = 192, bias ignored,
  * out[j] = G row-major).  The host arrays hold njobs (1..8) entries.  An XCD's workgroups are divided among the jobs and sweep
@@ -290,20 +253,22 @@ int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp,
                         const float* W2, const float* b2, void* attn, float* o,
                         const int32_t* order, const float* o_masked, int rows, void* stream);
 
-/* ---- fp32 path as fused kernels ("f32s": fp32 storage, fp32-accurate products on the bf16 matrix pipe; csrc/f32s.hip) --------
+/* ---- fp32 path as fused kernels (fp32 storage, fp32-accurate products on the fp16 matrix pipe; csrc/f32s.hip) ----------------
  * The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75 dispatches float / double only; the Linears of
  * lib/models/dq_decoder.py:763-848,659-717 and lib/models/ops/modules/projattn.py:169,180-181,203 are fp32 nn.Linear).  These
- * entry points keep fp32 tensors at every boundary and form every product as six bf16 MFMAs on operands split into three bf16
- * parts (x = h + m + l exactly; the dropped cross terms are below 2^-25 |a w|: error against the fp64 product not above an fp32
- * fmaf chain's, tests/test_hip_parity.py).  Weight operands W*_planes: the three bf16 parts of the nn.Linear weight, each in the
- * MFMA-fragment order of mvg_chain_attn_pose (mvgformer_amd.ops.swizzle_weight), part p at element offset p * N * K, N padded to
- * a multiple of 256 with zero rows (mvgformer_amd.ops.split_swizzle_weight).  A non-finite or > 3.39e38 input value makes its
- * output row NaN (as in mvg_linear's split form). */
+ * entry points keep fp32 tensors at every boundary and form every product as three fp16 MFMAs (l*h + h*l + h*h, fp32 accumulate)
+ * on operands scaled by a power of two and split into two fp16 parts (x 2^s = h + l: 22 bits of each operand; error against the
+ * fp64 product not above an fp32 fmaf chain's, tests/test_hip_parity.py).  Weight operands W*_planes: the weight times 2^scale as
+ * two fp16 planes (h, l), each in the MFMA-fragment order of mvg_chain_attn_pose (mvgformer_amd.ops.swizzle_weight), plane p at
+ * element offset p * N * K, N padded to a multiple of 256 with zero rows (mvgformer_amd.ops.split_swizzle_weight_h2, which also
+ * returns the scale); activation rows are scaled by the kernels (a power of two per row from the row's maximum).  A non-finite
+ * input value makes its output row NaN.  The range-safe alternative is the unfused path on mvg_linear's three-part split form. */
 
-/* mvg_chain_update_ffn_class_f32s on two-part fp16 operands (three fp16 MFMAs per product; lib/models/dq_decoder.py:770-778,
- * lib/models/mvp_decoder.py:94-98, dq_decoder.py:889-908): 32-row tiles, two workgroups per CU; Wu / W1 / W2 / W_next from
- * ops.split_swizzle_weight_h2 with their power-of-two scales, every other argument as in the six-product entry.  The FFN's hidden
- * activations carry a scale per (row, 256-column chunk); the residual t1 stays in fp32 registers. */
+/* chain B in fp32 (lib/models/dq_decoder.py:770-778, lib/models/mvp_decoder.py:94-98, dq_decoder.py:889-908): attn (V, B*NQ*J, 256)
+ * f32; Wu (256,256), W1 (1024,256), W2 (256,1024), W_next (n_next padded to 256, 256) as planes with their scales; everything else
+ * as in mvg_chain_update_ffn_class (n_next: multiple of 32).  32- or 64-row tiles by the row count (both sum a row identically).
+ * The FFN's hidden activations carry a scale per (row, 256-column chunk); the residual t1 stays in fp32 registers.  Replaces
+ * mvg_mean_views + mvg_linear x 3 (+ the next layer's query-term GEMM) + mvg_add_layernorm x 2 + mvg_class_head of the unfused path. */
 int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const float* tgt, const void* Wu, int wu_scale, const float* bu,
                                     const float* g2, const float* be2, const void* W1, int w1_scale, const float* b1, const void* W2,
                                     int w2_scale, const float* b2, const float* g3, const float* be3, const float* Wc, const float* bc,
@@ -311,45 +276,20 @@ int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const float* tgt, 
                                     int* any_valid, const float* query_pos, const void* W_next, int wn_scale, const float* b_next,
                                     float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream);
 
-/* mvg_chain_attn_pose_f32s on two-part fp16 operands (three fp16 MFMAs per product; lib/models/dq_decoder.py:585-588,659-690):
- * Wp / W0 / W1 from ops.split_swizzle_weight_h2 with their power-of-two scales; activation rows are scaled by the kernel between the
- * stages (row maximum over the 8 wavefronts through LDS).  attn is stored as the exact fp32 result of its stage. */
+/* chain A in fp32 (lib/models/dq_decoder.py:585-588,659-690): samp / attn (rows, 256) f32, o (rows, 3) f32; Wp, W0, W1 planes of the
+ * (256, 256) weights with their scales; W2 (3, 256) f32; order / o_masked as in mvg_chain_attn_pose (o_masked: this entry point run
+ * on one masked row).  Activation rows are scaled between the stages (row maximum over the 8 wavefronts through LDS); attn is
+ * stored as the exact fp32 result of its stage.  Replaces mvg_linear_ordered x 3 + mvg_rowdot3 of the unfused fp32 path. */
 int mvg_chain_attn_pose_f32h(const float* samp, const uint8_t* inside, const void* Wp, int wp_scale, const float* bp, const void* W0,
                              int w0_scale, const float* b0, const void* W1, int w1_scale, const float* b1, const float* W2,
                              const float* b2, float* attn, float* o, const int32_t* order, const float* o_masked, int rows,
                              void* stream);
 
-/* mvg_pyramid_f32s on two-part fp16 operands: every product as three fp16 MFMAs (l*h + h*l + h*h, fp32 accumulate) instead of six bf16
- * ones.  W?_planes: the weight times 2^w?_scale as two fp16 planes (h, l), each in mvg_swizzle order, N padded to 256
- * (ops.split_swizzle_weight_h2); activation rows are scaled by the kernel (a power of two per row from the row's maximum).  Same
- * outputs as mvg_pyramid_f32s to the accuracy either form has against fp64 (the fp32 accumulation's, ~3e-7 of sum|a||w|). */
+/* value = feat @ Wv^T + bv  (rows, 256)  and  G = feat @ Wg^T  (rows, n_g)  in one pass over the packed fp32 pyramid feat
+ * (rows, 256): the value projection of projattn.py:169 and the pyramid side of the offsets / logits Linear (projattn.py:180-181
+ * through Linear(bilinear(feat) + x) = bilinear(feat W^T) + (x W^T + b), see mvg_msda_gfused_f32).  n_g: multiple of 32, <= 256. */
 int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv_scale, const float* bv, const void* Wg_planes, int wg_scale,
                      float* value, float* G, int64_t rows, int n_g, void* stream);
-
-/* value = feat @ Wv^T + bv  (rows, 256)  and  G = feat @ Wg^T  (rows, n_g)  in one pass over the packed pyramid feat (rows, 256):
- * the value projection of projattn.py:169 and the pyramid side of the offsets / logits Linear (projattn.py:180-181 through
- * Linear(bilinear(feat) + x) = bilinear(feat W^T) + (x W^T + b), see mvg_msda_gfused_f32).  n_g: multiple of 32, <= 256. */
-int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
-                     float* G, int64_t rows, int n_g, void* stream);
-
-/* mvg_chain_attn_pose in fp32 (dq_decoder.py:585-588,659-690): samp / attn (rows, 256) f32, o (rows, 3) f32; Wp, W0, W1 planes
- * of the (256, 256) weights; W2 (3, 256) f32; order / o_masked as in mvg_chain_attn_pose (o_masked: this entry point run on one
- * masked row).  Replaces mvg_linear_ordered x 3 + mvg_rowdot3 of the unfused fp32 path. */
-int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
-                             const float* b0, const void* W1, const float* b1, const float* W2, const float* b2,
-                             float* attn, float* o, const int32_t* order, const float* o_masked, int rows, void* stream);
-
-/* mvg_chain_update_ffn_class in fp32 (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-908): attn (V, B*NQ*J, 256)
- * f32; Wu (256,256), W1 (1024,256), W2 (256,1024), W_next (n_next padded to 256, 256) as planes; everything else as in
- * mvg_chain_update_ffn_class (n_next: multiple of 32).  Replaces mvg_mean_views + mvg_linear x 3 (+ the next layer's query-term
- * GEMM) + mvg_add_layernorm x 2 + mvg_class_head of the unfused fp32 path. */
-int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu,
-                                    const float* g2, const float* be2, const void* W1, const float* b1,
-                                    const void* W2, const float* b2, const float* g3, const float* be3,
-                                    const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
-                                    float* tgt_out, float* prob, uint8_t* valid, int* any_valid,
-                                    const float* query_pos, const void* W_next, const float* b_next,
-                                    float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream);
 
 /* Fused bf16 chain per joint token (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-908):
  *   t1 = LN2(tgt + Wu mean_v(attn_v) + bu);  tgt' = LN3(t1 + W2 relu(W1 t1 + b1) + b2) (has_ffn) else t1;

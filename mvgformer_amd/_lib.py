@@ -30,13 +30,10 @@ SIGNATURES = {
     "mvg_msda_backward_det_f32": [_vp] * 9 + [_i] * 7 + [_vp, C.c_size_t, _vp],
     "mvg_msda_forward_f64": [_vp] * 6 + [_i] * 7 + [_vp],
     "mvg_msda_backward_f64": [_vp] * 9 + [_i] * 7 + [_vp],
-    "mvg_pack_level": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvg_pack_pyramid": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "mvg_project": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_gather_ref": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvg_linear": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
-    "mvg_linear_splitk_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
-    "mvg_linear_wgrad_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "mvg_dlt_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_dlt_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_linear_wgrad_bias_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -46,15 +43,10 @@ SIGNATURES = {
     "mvg_msda_gfused_f32": [_vp] * 9 + [_i] * 5 + [_vp],
     "mvg_chain_attn_pose": [_vp] * 14 + [_i, _vp],
     "mvg_chain_update_ffn_class": [_vp, _i] + [_vp] * 13 + [_f] + [_vp] * 9 + [_i] * 5 + [_vp],
-    "mvg_pyramid_f32s": [_vp] * 6 + [C.c_int64, _i, _vp],
     "mvg_chain_update_ffn_class_f32h": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvg_chain_attn_pose_f32h": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "mvg_pyramid_f32h": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.c_int64, _i, _vp],
-    "mvg_chain_attn_pose_f32s": [_vp] * 14 + [_i, _vp],
-    "mvg_chain_update_ffn_class_f32s": [_vp, _i] + [_vp] * 13 + [_f] + [_vp] * 9 + [_i] * 5 + [_vp],
-    "mvg_value_proj_planes_ws": [_vp, _vp, _vp, _vp, _i, _i, _vp],
-    "mvg_feat_linear_ws": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mvg_pyramid_group_ws": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "mvg_msda_gsamp": [_vp] * 9 + [_i] * 5 + [_vp],
     "mvg_bin_pairs": [_vp] * 3 + [_i] + [_vp] + [_i] * 2 + [_vp, C.c_size_t, _vp],

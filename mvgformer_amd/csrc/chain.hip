@@ -425,14 +425,10 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 
 }  // namespace
 
-int g_chain_ring = 4;     // tuning knob "chain_ring": weight prefetch depth (k-steps) of chain B's stage GEMMs (4 | 8 | 16)
-int g_chain_split = 1;    // tuning knob "chain_split": 1 = column-split wave mapping of chain B (JN = 1), 0 = row-block split
-int g_chain_waves = 8;    // tuning knob "chain_waves": wavefronts per workgroup of chain B (4 | 8); measured 86 -> 69 us
-int g_chain_a_waves = 4;  // tuning knob "chain_a_waves": same for chain A (8 measured slower: 93 vs 79 us)
-int g_auto_small_a = 1;   // tuning knob "auto_small_a": chain A with 64-row tiles while the launch has at most 320 tiles of 128 rows
-int g_auto_small_b = 1;   // tuning knob "auto_small_b": chain B with 32-row tiles when that still leaves <= 128 64-row tiles
-int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128); 128: 65 -> 55 us (half the
-                       // weight bytes per row through the L1 miss path, the resource that bounds these kernels)
+extern int g_auto_small;   // tuning knob "auto_small" (msda.hip): launches with few rows pick smaller tiles (bit-identical rows)
+int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128 | 256); 128: 65 -> 55 us (half the weight
+                       // bytes per row).  Geometries measured and deleted (rounds 1-4, Appendix A of DESIGN.md): 8 wavefronts for
+                       // chain A (93 vs 79 us), 4 wavefronts / row-block split / fragment rings of 8 and 16 for chain B.
 
 template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
@@ -468,14 +464,10 @@ extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, cons
   // at most 320 tiles of 128 rows -- a rank's shard of a query-sharded run, small scenes -- 64-row tiles put twice as many
   // workgroups on the chip (measured at cfg-2 with 128 / 256 / 512 queries: -2.6 / -0.6 / -1.4 % of the forward; the full 1024
   // queries are 1.4 % faster with 128-row tiles).
-  if (g_auto_small_a && g_chain_rm == 128 && g_chain_a_waves == 4 && rows <= 320 * 128)
+  if (g_auto_small && g_chain_rm == 128 && rows <= 320 * 128)
     return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_rm == 128 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<128, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_rm == 64 && g_chain_a_waves == 8 && g_chain_split == 1) return launch_chain_a<64, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_rm == 128 && g_chain_a_waves == 8) return launch_chain_a<128, 512, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   if (g_chain_rm == 128) return launch_chain_a<128, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_a_waves == 8) return launch_chain_a<64, 512, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
   return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
 }
 
@@ -494,8 +486,7 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
   const int nq_total = B * NQ, rows = nq_total * J;
   if (rows == 0) return 0;
   // few rows (a rank's shard of a query-sharded run): 32-row tiles (2 persons) fill twice as many CUs
-  const bool small = g_auto_small_b && g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 4 && J <= 16 &&
-                     (nq_total + (64 / J) - 1) / (64 / J) <= 128;
+  const bool small = g_auto_small && J <= 16 && (nq_total + (64 / J) - 1) / (64 / J) <= 128;
   const int RMr = small ? 32 : 64;
   const int qpt = RMr / J;
   const size_t lds = 2 * RMr * ACT_PITCH + RMr * XP + RMr * 2 * sizeof(float) + 9 * 256 * sizeof(float);
@@ -504,16 +495,8 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
   const size_t lds64 = 2 * 64 * ACT_PITCH + 64 * XP + 64 * 2 * sizeof(float) + 9 * 256 * sizeof(float);
   if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 256, 2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 2>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<8, 512, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<16, 512, 1>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_b_kernel<4, 512, 1, 32>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
     if (e != hipSuccess) return (int)e;
@@ -526,11 +509,7 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
                      threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next,  \
                      n_next, rows, J, nq_total, has_ffn)
   if (small) MVG_CB(4, 512, 1, 32);
-  else if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 16) MVG_CB(16, 512, 1);
-  else if (g_chain_waves == 8 && g_chain_split == 1 && g_chain_ring == 8) MVG_CB(8, 512, 1);
-  else if (g_chain_waves == 8 && g_chain_split == 1) MVG_CB(4, 512, 1);
-  else if (g_chain_waves == 8) MVG_CB(4, 512, 2);
-  else MVG_CB(4, 256, 2);
+  else MVG_CB(4, 512, 1);
 #undef MVG_CB
   MVG_LAUNCH_CHECK();
   return 0;

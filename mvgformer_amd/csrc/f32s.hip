@@ -1,17 +1,20 @@
-// fp32 path of the decoder layer as fused kernels ("f32s": fp32 storage, products on the bf16 matrix pipe from 3-way split
-// operands -- f32s_dev.h).  The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75, the Linears of
+// fp32 path of the decoder layer as fused kernels: fp32 storage at every boundary, every product formed on the fp16 matrix pipe
+// from TWO-part operands ("f32h": x 2^s = h + l, three MFMAs per product, fp32 accumulation -- f32s_dev.h and the note in front of
+// pyramid_f32h_kernel).  The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75, the Linears of
 // lib/models/dq_decoder.py:763-848,659-717); rounds 1-3 ran it as 17 launches per layer with every intermediate in HBM.
 //
-//   mvg_pyramid_f32s             value = feat Wv^T + bv  and  G = feat [Wo; Wa]^T  in ONE pass over the pyramid
-//                                (projattn.py:169 and the pyramid side of :180-181): a 64-row tile is split once, 14 column
-//                                blocks are produced from it; persistent workgroups, the next tile's rows in flight.
-//   mvg_chain_attn_pose_f32s     chain A: attn = inside * (samp Wp^T + bp) -> stored; o = pose MLP(attn)   (dq_decoder.py:585-588,659-690)
-//   mvg_chain_update_ffn_class_f32s   chain B: view mean -> update Linear -> +tgt -> LN2 -> FFN -> LN3 -> class head -> next layer's
-//                                query term (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-893)
+//   mvg_pyramid_f32h                 value = feat Wv^T + bv  and  G = feat [Wo; Wa]^T  in ONE pass over the pyramid
+//                                    (projattn.py:169 and the pyramid side of :180-181): a 64-row tile is split once, 14 column
+//                                    blocks are produced from it; persistent workgroups.
+//   mvg_chain_attn_pose_f32h         chain A: attn = inside * (samp Wp^T + bp) -> stored; o = pose MLP(attn)   (dq_decoder.py:585-588,659-690)
+//   mvg_chain_update_ffn_class_f32h  chain B: view mean -> update Linear -> +tgt -> LN2 -> FFN -> LN3 -> class head -> next layer's
+//                                    query term (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-893)
 //
-// Geometry shared by the three: 512 threads = 8 wavefronts, one workgroup per CU (the three activation planes of a 64-row tile
-// are 101 KB of LDS), wavefront w owns the 32-column block w of every 256-column weight block and both 32-row blocks of the
-// tile.  Weight operands: three bf16 planes (h, m, l), each in ops.swizzle_weight order, plane p at p * N * K elements.
+// Geometry shared by the three: 512 threads = 8 wavefronts, wavefront w owns the 32-column block w of every 256-column weight
+// block.  Weight operands: two fp16 planes (h, l), each in ops.swizzle_weight order, plane p at p * N * K elements, and the
+// tensor's power-of-two scale.  The six-product bf16 forms of round 4's first half (pyramid_f32s / chain_*_f32s kernels, three
+// bf16 parts per operand) computed the same rows at 1.4-1.6 x the time and are deleted (profiles/r04_experiments.txt holds their
+// numbers); the range-safe alternative is the unfused path (MVG_F32_FUSED=0: mvg_linear's three-part split form per GEMM).
 #include <algorithm>
 
 #include "common.h"
@@ -21,33 +24,7 @@
 // Measurement hook (variant builds of tools/ab_f32s.sh only; the product is built without it): s_memtime stamps of one thread
 // per workgroup at phase boundaries, read back with mvg_f32s_read_stamps.
 #ifndef F32S_PRIO
-#define F32S_PRIO 1           // the two wavefronts of a SIMD alternate issue priority per k-step (f32s_dev.h: stage)
-#endif
-#ifndef F32S_PYR_BALANCE
-#define F32S_PYR_BALANCE 1    // tiled pyramid kernel: the G stage's 12 (row block, column block) units over all 8 wavefronts
-#endif
-#ifndef F32S_PYR_WIDE
-#define F32S_PYR_WIDE 0       // tiled pyramid kernel: 16-byte stores from the (row, 4 columns) accumulator layout
-#endif
-#ifndef F32S_WS_INTERLEAVE
-#define F32S_WS_INTERLEAVE 0
-#endif
-#ifdef F32S_STAMPS
-__device__ unsigned long long f32s_stamps[4096 * 64];
-#define STAMP(i)                                                                                   \
-  do {                                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) f32s_stamps[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#define STAMPW(i)                                                                                  \
-  do {                                                                                             \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) f32s_stamps[blockIdx.x * 64 + (i) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-extern "C" int mvg_f32s_read_stamps(unsigned long long* host, int n_blocks) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(f32s_stamps), sizeof(unsigned long long) * 64 * n_blocks);
-}
-#else
-#define STAMP(i)
-#define STAMPW(i)
+#define F32S_PRIO 1           // the two wavefronts of a SIMD alternate issue priority per k-step (f32s_dev.h: stage_h2)
 #endif
 
 namespace {
@@ -55,198 +32,7 @@ namespace {
 using namespace f32s;
 
 constexpr int RM = 64;                       // rows per tile
-constexpr int PLANE = RM * PLP;              // bytes per activation plane
 constexpr int NT = 512;
-
-// ------------------------------------------------------------------------------------------------------------------
-// pyramid products.  The MFMA operands are swapped against the chains (activations first): a lane then holds one output
-// COLUMN and 16 rows of it, so every store instruction writes two full 128-byte lines of the row-major outputs.
-template <int KSTEPS, int RING, int MT = 2>
-__device__ __forceinline__ void stage_swapped(const char* __restrict__ act, const bf16_t* __restrict__ wp, long wplane,
-                                              f32x16 (&acc)[MT], int rot, int lane, int row0 = 0) {
-  const int rl = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
-  f32x4 ring[RING][3];
-#pragma unroll
-  for (int p = 0; p < RING; ++p) {
-    const int kq = (p + rot) & (KSTEPS - 1);
-#pragma unroll
-    for (int s = 0; s < 3; ++s) ring[p][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
-  }
-  const char* arow = act + (row0 + rl) * PLP + 16 * h;
-  f32x4 a_nxt[MT][3];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * PLANE + mt * 32 * PLP + (rot & (KSTEPS - 1)) * 32);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    bf16x8 a[MT][3], b[3];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) a[mt][s] = __builtin_bit_cast(bf16x8, a_nxt[mt][s]);
-    if (ks + 1 < KSTEPS) {
-      const int kn = (ks + 1 + rot) & (KSTEPS - 1);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * PLANE + mt * 32 * PLP + kn * 32);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) b[s] = __builtin_bit_cast(bf16x8, ring[ks % RING][s]);
-    if (ks + RING < KSTEPS) {
-      const int kq = (ks + RING + rot) & (KSTEPS - 1);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) ring[ks % RING][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
-    }
-    constexpr int TB[6] = {2, 0, 1, 1, 0, 0}, TA[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][TA[t]], b[TB[t]], acc[mt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// acc[mt][4 g + t] = out[row 32 mt + 8 g + 4 h + t][column rl of the block]
-template <int MT = 2>
-__device__ __forceinline__ void store_swapped(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[MT],
-                                              float bias, int lane, int row0 = 0) {
-  const int h = lane >> 5;
-  float* dst = out + (r0 + row0 + 4 * h) * ld + col;
-  if (r0 + RM <= rows) {             // every tile but the last: no per-row predicate (32 exec regions per stage and wavefront)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (r0 + row0 + 4 * h + 32 * mt + 8 * (e >> 2) + (e & 3) < rows) dst[(long)(32 * mt + 8 * (e >> 2) + (e & 3)) * ld] = acc[mt][e] + bias;
-  }
-}
-
-// acc[mt][4 g + t] = out[row 32 mt + rl][column 8 g + 4 h + t of the block]  (f32s::stage, weights first): 16-byte stores
-__device__ __forceinline__ void store_rows4(float* __restrict__ out, long ld, long r0, long rows, int col0, const f32x16 (&acc)[2],
-                                            const f32x4 (&bias)[4], int lane) {
-  const int rl = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 b = bias[g];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const long row = r0 + 32 * mt + rl;
-      const f32x4 v = {acc[mt][4 * g] + b[0], acc[mt][4 * g + 1] + b[1], acc[mt][4 * g + 2] + b[2], acc[mt][4 * g + 3] + b[3]};
-      if (row < rows) *reinterpret_cast<f32x4*>(out + row * ld + col0 + 8 * g + 4 * h) = v;
-    }
-  }
-}
-
-__global__ __launch_bounds__(NT) void pyramid_f32s_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv,
-                                                          const float* __restrict__ bv, const bf16_t* __restrict__ Wg,
-                                                          float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long ntiles = (rows + RM - 1) / RM;
-  const int rot = (w * 3) & 15;
-  const bf16_t* wpv = frag_ptr(Wv, 0, w, 16, lane);
-  const bf16_t* wpg = frag_ptr(Wg, 0, w, 16, lane);
-  const bf16_t* wpg2 = frag_ptr(Wg, 0, w < 4 ? w : 4 + ((w - 4) >> 1), 16, lane);     // balanced G stage (below)
-  const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
-  f32x4 bias4[4], zero4[4];          // (row, 4 columns) layout: the value bias of this lane's columns, held for the whole launch
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    zero4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bias4[g] = bv ? *reinterpret_cast<const f32x4*>(bv + 32 * w + 8 * g + 4 * (lane >> 5)) : zero4[g];
-  }
-  const bool has_g = 32 * w < ng;
-  // (the weights do not change from tile to tile: without the empty asm below hipcc hoists all 96 fragment loads out of the
-  // tile loop -- 384 registers, spilled)
-  f32x4 x[8];
-  long tile = blockIdx.x;
-  if (tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * NT + tid;
-      x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
-    }
-  }
-  int it = 0;
-  for (; tile < ntiles; tile += gridDim.x, ++it) {
-    const long r0 = tile * RM;
-    asm volatile("" : "+v"(wpv), "+v"(wpg), "+v"(wpg2));
-    if (it == 2) STAMP(0);
-    __syncthreads();                               // the previous tile's stages have read the planes
-    if (it == 2) STAMP(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * NT + tid;
-      store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, x[i]);
-    }
-    if (it == 2) STAMP(2);
-    __syncthreads();
-    if (it == 2) STAMP(3);
-    const long nxt = tile + gridDim.x;
-    f32x16 acc[2];
-#if F32S_PYR_WIDE
-    stage<2, 16, PLP>(act, PLANE, 0, wpv, 65536, acc, nullptr, true, rot, lane);
-#else
-    stage_swapped<16, 4>(act, wpv, 65536, acc, rot, lane);
-#endif
-    if (it == 2) STAMP(4);
-    if (nxt < ntiles) {
-      // the next tile's rows: requested BEHIND the first stage's fragment loads (a wavefront's memory operations complete in
-      // order: in front of them every ring refill of that stage would wait for an HBM round trip), in flight under the second
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid;
-        x[i] = *reinterpret_cast<const f32x4*>(feat + min(nxt * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
-      }
-    }
-#if F32S_PYR_WIDE
-    store_rows4(value, 256, r0, rows, 32 * w, acc, bias4, lane);
-#else
-    store_swapped(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, lane);
-#endif
-    if (it == 2) STAMP(5);
-    if (F32S_PYR_BALANCE && !F32S_PYR_WIDE && ng == 192) {
-      // G has 6 column blocks for 8 wavefronts: wavefronts 0..3 take blocks 0..3 with both row blocks, wavefronts 4..7 ONE row block
-      // of block 4 or 5 each -- 3 units on every SIMD instead of 4 on two of them and 2 on the others.  A row's sum is the same
-      // either way: one accumulator per row block, the six products in order, the rotation of its column block.
-      if (w < 4) {
-        stage_swapped<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
-        if (it == 2) STAMP(6);
-        store_swapped(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, lane);
-      } else {
-        const int cbg = 4 + ((w - 4) >> 1), mtg = (w - 4) & 1;
-        f32x16 a1[1];
-        stage_swapped<16, 4, 1>(act, wpg2, 65536, a1, (cbg * 3 + 7) & 15, lane, 32 * mtg);
-        store_swapped<1>(G, ng, r0, rows, 32 * cbg + (lane & 31), a1, 0.f, lane, 32 * mtg);
-      }
-    } else if (has_g) {
-#if F32S_PYR_WIDE
-      stage<2, 16, PLP>(act, PLANE, 0, wpg, 65536, acc, nullptr, true, (rot + 7) & 15, lane);
-      if (it == 2) STAMP(6);
-      store_rows4(G, ng, r0, rows, 32 * w, acc, zero4, lane);
-#else
-      stage_swapped<16, 4>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
-      if (it == 2) STAMP(6);
-      store_swapped(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, lane);
-#endif
-    }
-    if (it == 2) STAMP(7);
-    if (it == 3) STAMP(8);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // pyramid products on TWO-part fp16 operands ("f32h", round 4): x 2^s = h + l with h = fp16(x 2^s), l = fp16(x 2^s - h) -- 22 bits
@@ -421,504 +207,9 @@ __global__ __launch_bounds__(NT, PAIR ? 2 : 1) void pyramid_f32h_kernel(const fl
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// pyramid products, weight-stationary.  The tiled kernel above streams 672 KB of weight planes per 64-row tile through the
-// CU's vector-memory path -- 672 one-KB fragment loads per tile next to 24.6 k cycles of MFMA: the path is as busy as the
-// matrix pipe, and every queueing delay stalls it (s_memtime: 45 k cycles per tile).  Here a workgroup keeps ONE of the two
-// weights on the CU for the whole launch -- 8 wavefronts (two per SIMD), a wavefront holds one 32-column block x 256 k x 3
-// planes, 12 of its 16 k-steps in registers -- and streams 32-row tiles of the pyramid through a double-buffered LDS image of
-// their planes.  Role of a workgroup: (blockIdx >> 3) & 1 = value or G; workgroups b and b + 8 share an XCD (b % 8) and walk
-// the same tiles, so a tile comes from HBM once and from that XCD's L2 the second time.  G is padded to 256 columns (its planes
-// are, by ops.split_swizzle_weight; wavefronts 6, 7 of a G workgroup multiply by zeros): both roles take the same time per tile.
-constexpr int WS_RM = 32, WS_PLANE = WS_RM * PLP;
-#ifndef F32S_WS_NSTREAM
-#define F32S_WS_NSTREAM 2
-#endif
-
-__global__ __launch_bounds__(NT) void pyramid_ws_f32s_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv,
-                                                             const float* __restrict__ bv, const bf16_t* __restrict__ Wg,
-                                                             float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
-  const int role = (blockIdx.x >> 3) & 1;
-  const long pair = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), npairs = gridDim.x >> 1;
-  const bf16_t* __restrict__ W = role ? Wg : Wv;
-  float* __restrict__ out = role ? G : value;
-  const int ld = role ? ng : 256;
-  const long ntiles = (rows + WS_RM - 1) / WS_RM;
-
-  // the wavefront's weights: column block w, three planes.  16 - NSTREAM of the 16 k-steps stay in registers for the whole launch
-  // (12 registers each); k-steps SLO .. SLO+NSTREAM-1 are re-read from L2 once per tile, one k-step ahead of their use, into one
-  // 12-register slot (with all 16 resident a wavefront of this 2-per-SIMD kernel would need more than its 256 registers).  The
-  // streamed k-steps sit EARLY in the loop: a wavefront's memory operations complete in order, and the second half of the
-  // loop requests the pyramid rows (HBM round trips nothing should queue behind).
-  constexpr int NSTREAM = F32S_WS_NSTREAM, SLO = 2;
-  auto resident = [](int ks) { return ks < SLO || ks >= SLO + NSTREAM; };
-  auto ridx = [](int ks) { return ks < SLO ? ks : ks - NSTREAM; };
-  f32x4 wr[16 - NSTREAM][3];
-  const bf16_t* wp = frag_ptr(W, 0, w, 16, lane);
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks)
-    if (resident(ks)) {
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) wr[ridx(ks)][sp] = *reinterpret_cast<const f32x4*>(wp + sp * 65536 + ks * 1024);
-    }
-  const float bias = (!role && bv) ? bv[32 * w + rl] : 0.f;
-  const bool col_ok = 32 * w < ld;
-
-  // The pyramid rows never pass through registers on their way in: wavefront w moves rows 4 w .. 4 w + 3 of a tile with one
-  // LDS-DMA instruction each (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KB row, lane l to byte 16 l of the row's slot in
-  // `raw`), a whole tile ahead of their use, and later reads back exactly the bytes its own lanes requested (ordered by its
-  // own vmcnt wait, no barrier).  hipcc does not see these loads (inline asm): it neither counts them (its own waits only get
-  // stricter: completion is in order) nor drains them in front of the workgroup barrier.
-  constexpr int RPW = WS_RM / 8;          // rows per wavefront and tile
-  char* raw = smem + 2 * 3 * WS_PLANE;
-  const unsigned raw_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)raw + (unsigned)w * RPW * 1024;
-  auto dma_row = [&](long tile_, int i) {
-    const float* gsrc = feat + min(tile_ * WS_RM + RPW * w + i, rows - 1) * 256 + lane * 4;
-    const unsigned dst = raw_lds + i * 1024;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-  };
-  long tile = pair;
-  if (tile < ntiles) {
-    f32x4 x[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * WS_RM + RPW * w + i, rows - 1) * 256 + lane * 4);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) store_split4<PLP>(smem, WS_PLANE, RPW * w + i, lane * 4, x[i]);
-    if (tile + npairs < ntiles) {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) dma_row(tile + npairs, i);
-    }
-  }
-  // The outputs of a tile are stored from the NEXT tile's k loop (two 4-byte-per-lane stores per k-step 0..7): a block of 16
-  // stores in front of the workgroup barrier cost every wavefront ~1.2 k cycles of an idle matrix pipe plus the skew it
-  // caused at the barrier (s_memtime: 2 k cycles).
-  f32x16 prev;
-  long prev_r0 = -1;
-  auto store_rows = [&](const f32x16& v, long r0_, int e0, int e1) {
-    if (!col_ok) return;
-    float* dst = out + (r0_ + 4 * h) * ld + 32 * w + rl;
-    if (r0_ + WS_RM <= rows) {              // every tile but the last: no per-row predicate
-#pragma unroll
-      for (int e = e0; e < e1; ++e)
-        if (!((F32S_KO & 8) && e > 1)) dst[(long)(8 * (e >> 2) + (e & 3)) * ld] = v[e] + bias;
-    } else {
-#pragma unroll
-      for (int e = e0; e < e1; ++e)
-        if (r0_ + 4 * h + 8 * (e >> 2) + (e & 3) < rows) dst[(long)(8 * (e >> 2) + (e & 3)) * ld] = v[e] + bias;
-    }
-  };
-  int buf = 0, it = 0;
-  for (; tile < ntiles; tile += npairs, buf ^= 1, ++it) {
-    if (it == 3) STAMP(16);
-    const char* act = smem + buf * 3 * WS_PLANE;
-    char* nxt = smem + (buf ^ 1) * 3 * WS_PLANE;
-    const bool has_next = tile + npairs < ntiles, has_next2 = tile + 2 * npairs < ntiles;
-    asm volatile("" : "+v"(wp));            // the streamed fragments are loop-invariant: keep their loads in the loop
-    __syncthreads();        // this tile's planes are complete; the other buffer is no longer read
-    if (it == 3) STAMP(17);
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const char* arow = act + rl * PLP + 16 * h;
-    f32x4 a_nxt[3], wst[3];
-#pragma unroll
-    for (int sp = 0; sp < 3; ++sp) a_nxt[sp] = *reinterpret_cast<const f32x4*>(arow + sp * WS_PLANE);
-    if (NSTREAM > 0 && SLO == 0) {
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) wst[sp] = *reinterpret_cast<const f32x4*>(wp + sp * 65536 + SLO * 1024);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      bf16x8 a[3];
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) a[sp] = __builtin_bit_cast(bf16x8, a_nxt[sp]);
-      if (ks + 1 < 16) {
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a_nxt[sp] = *reinterpret_cast<const f32x4*>(arow + sp * WS_PLANE + (ks + 1) * 32);
-      }
-      // filler of k-steps 8 .. 8+RPW-1: one of the wavefront's rows of the NEXT tile (in `raw` since the previous tile's k loop)
-      // is split into the other buffer.  No wait of its own: the streamed fragment loads of this tile's first k-steps were issued
-      // after those LDS-DMA loads and have been waited for -- loads complete in order.
-      if (ks >= 8 && ks < 8 + RPW && has_next && !(F32S_KO & 64)) {
-        if (NSTREAM == 0 && ks == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + (RPW * w + ks - 8) * 1024 + lane * 16);
-        store_split4<PLP>(nxt, WS_PLANE, RPW * w + ks - 8, lane * 4, xr);
-      }
-      bf16x8 bw[3];
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) bw[sp] = __builtin_bit_cast(bf16x8, resident(ks) ? wr[resident(ks) ? ridx(ks) : 0][sp] : wst[sp]);
-      constexpr int TB[6] = {2, 0, 1, 1, 0, 0}, TA[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        if (F32S_KO & 4) {
-          acc[t] += __builtin_bit_cast(f32x4, bw[TB[t]])[0] * __builtin_bit_cast(f32x4, a[TA[t]])[1];
-          continue;
-        }
-        if (col_ok) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], bw[TB[t]], acc, 0, 0, 0);   // (G: wavefronts 6, 7 own padding)
-      }
-      // streamed fragments of the next k-step into the slot this step has just consumed
-      if (NSTREAM > 0 && ks + 1 >= SLO && ks + 1 < SLO + NSTREAM && !(F32S_KO & 32)) {
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) wst[sp] = *reinterpret_cast<const f32x4*>(wp + sp * 65536 + (ks + 1) * 1024);
-      }
-      // the previous tile's outputs, two rows of the accumulator per k-step
-      if (ks < 8 && prev_r0 >= 0) store_rows(prev, prev_r0, 2 * ks, 2 * ks + 2);
-      // ... and the same row of the tile after the next is requested into the slot just read
-      if (ks >= 8 && ks < 8 + RPW && has_next2 && !(F32S_KO & 16)) dma_row(tile + 2 * npairs, ks - 8);
-      __builtin_amdgcn_sched_barrier(0);
-      if (it == 3 && (ks == 7 || ks == 11)) STAMP(ks == 7 ? 18 : 19);
-    }
-    if (it == 3) STAMP(20);
-    prev = acc;
-    prev_r0 = tile * WS_RM;
-    if (it == 3) STAMP(21);
-    if (it == 4) STAMP(22);
-  }
-  if (prev_r0 >= 0) store_rows(prev, prev_r0, 0, 16);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this wavefront is in flight when its LDS is released
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// chain A
-__global__ __launch_bounds__(NT) void chain_a_f32s_kernel(const float* __restrict__ samp, const uint8_t* __restrict__ inside,
-                                                          const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
-                                                          const bf16_t* __restrict__ W0, const float* __restrict__ b0,
-                                                          const bf16_t* __restrict__ W1, const float* __restrict__ b1,
-                                                          const float* __restrict__ W2, const float* __restrict__ b2,
-                                                          float* __restrict__ attn, float* __restrict__ o,
-                                                          const int* __restrict__ order, const float* __restrict__ o_masked,
-                                                          int R) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;
-  int* ridb = reinterpret_cast<int*>(smem + 3 * PLANE);         // [2][RM] global row of every tile row (-1: past the end), double-buffered
-  int* keepb = ridb + 2 * RM;                                   // [2][RM] in-image flag of every tile row
-  float* w2s = reinterpret_cast<float*>(keepb + 2 * RM);        // last pose layer (3 x 256 f32)
-  float* bias_s = w2s + 768;                                    // bp | b0 | b1 (3 x 256 f32): the epilogues read them from LDS
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31;
-  const int ntiles = (R + RM - 1) / RM;
-  const int rot = (w * 3) & 15;
-  for (int i = tid; i < 768; i += NT) {
-    w2s[i] = W2[i];
-    bias_s[i] = (i < 256 ? bp : i < 512 ? b0 : b1)[i & 255];
-  }
-  const bf16_t* wp1 = frag_ptr(Wp, 0, w, 16, lane);
-  const bf16_t* wp2 = frag_ptr(W0, 0, w, 16, lane);
-  const bf16_t* wp3 = frag_ptr(W1, 0, w, 16, lane);
-  const float m0 = o_masked ? o_masked[0] : 0.f, m1 = o_masked ? o_masked[1] : 0.f, m2 = o_masked ? o_masked[2] : 0.f;
-  const float bo0 = b2[0], bo1 = b2[1], bo2 = b2[2];
-  const int prio = F32S_PRIO ? (w >> 2) : -1;
-
-  // Software pipeline over the tiles of this workgroup (one workgroup per CU: nobody else hides a tile's dependent loads --
-  // order -> inside -> sampled rows, three round trips, 9 k cycles by s_memtime).  While tile t runs its stages, the row ids /
-  // flags of tile t + 1 are fetched (during stage 1) and its sampled rows are requested (behind stage 3's k loop: a
-  // wavefront's memory operations complete in order, so in front of a stage they would stall its fragment ring).
-  auto fetch_ids = [&](int tile_, int& g, int& k) {             // threads 0 .. RM-1
-    const int slot = tile_ * RM + tid;
-    g = (tile_ < ntiles && slot < R) ? (order ? order[slot] : slot) : -1;
-    k = (g >= 0 && inside[g] != 0) ? 1 : 0;
-  };
-  f32x4 x[8];
-  auto request_rows = [&](const int* rid_) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * NT + tid;
-      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid_[c >> 6], 0) * 256 + (c & 63) * 4);
-    }
-  };
-  int cur = 0;
-  {
-    int g = -1, k = 0;
-    if (tid < RM) {
-      fetch_ids(blockIdx.x, g, k);
-      ridb[tid] = g;
-      keepb[tid] = k;
-    }
-    __syncthreads();
-    if ((int)blockIdx.x < ntiles) request_rows(ridb);
-  }
-  int it = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it, cur ^= 1) {
-    int* rid = ridb + cur * RM;
-    int* keepf = keepb + cur * RM;
-    const int nxt_tile = tile + gridDim.x;
-    if (it == 1) STAMP(0);
-    asm volatile("" : "+v"(wp1), "+v"(wp2), "+v"(wp3));         // no hoisting of the (tile-invariant) weight loads: 576 registers
-    const bool any_inside = __syncthreads_or(tid < RM && keepf[tid] != 0) != 0;     // (also: the previous tile's planes are free)
-    if (it == 1) STAMP(1);
-    int g_n = -1, k_n = 0;
-    if (!any_inside && o_masked) {                              // all-masked tile: attn = 0, o = the MLP of a zero row
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid, g = rid[c >> 6];
-        if (g >= 0) *reinterpret_cast<f32x4*>(attn + (long)g * 256 + (c & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      if (tid < RM && rid[tid] >= 0) {
-        float* og = o + (long)rid[tid] * 3;
-        og[0] = m0;
-        og[1] = m1;
-        og[2] = m2;
-      }
-      if (tid < RM) {
-        fetch_ids(nxt_tile, g_n, k_n);
-        ridb[(cur ^ 1) * RM + tid] = g_n;
-        keepb[(cur ^ 1) * RM + tid] = k_n;
-      }
-      __syncthreads();
-      if (nxt_tile < ntiles) request_rows(ridb + (cur ^ 1) * RM);
-      continue;
-    }
-    f32x4 pf[4][3];
-    ring_prefetch<16, 4>(wp1, 65536, pf, rot);                  // stage 1's first fragments
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {                               // this tile's rows (requested during the previous tile) -> planes
-      const int c = i * NT + tid;
-      store_split4<PLP>(act, PLANE, c >> 6, (c & 63) * 4, rid[c >> 6] >= 0 ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f});
-    }
-    bool keep[2], all[2] = {true, true};
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) keep[mt] = keepf[mt * 32 + rl] != 0;                  // dq_decoder.py:585-586
-    if (tid < RM) fetch_ids(nxt_tile, g_n, k_n);                // next tile's ids: two dependent round trips, under stage 1
-    __syncthreads();
-    if (it == 1) STAMP(2);
-
-    // attn = inside * output_proj(samp)
-    f32x16 acc[2];
-    f32x4 bvr[4];
-    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp1, 65536, acc, nullptr, true, rot, lane, pf, prio);
-    if (it == 1) STAMP(3);
-    load_bias(bias_s + 32 * w, bvr, lane);
-    ring_prefetch<16, 4>(wp2, 65536, pf, (rot + 5) & 15);
-    if (tid < RM) {
-      ridb[(cur ^ 1) * RM + tid] = g_n;
-      keepb[(cur ^ 1) * RM + tid] = k_n;
-    }
-    uint2 pk[2][4][3];
-    split_planes<2>(pk, acc, bvr, false, keep);                 // under the other wavefronts' k loops; only the stores wait
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    store_planes<2, PLP>(act, PLANE, 0, 32 * w, pk, lane);
-    __syncthreads();
-    if (it == 1) STAMP(4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                               // attn rows -> global (needed for the view mean): 32 B per thread
-      const int c = i * NT + tid, row = c >> 5, ch = c & 31, g = rid[row];
-      const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + ch * 16);
-      const uint4 mm = *reinterpret_cast<const uint4*>(act + PLANE + row * PLP + ch * 16);
-      const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * PLANE + row * PLP + ch * 16);
-      if (g >= 0) {
-        float* dst = attn + (long)g * 256 + ch * 8;
-        *reinterpret_cast<f32x4*>(dst) = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
-        *reinterpret_cast<f32x4*>(dst + 4) = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
-      }
-    }
-    if (it == 1) STAMP(5);
-    if (it == 1) STAMPW(32);
-    // pose_embed MLP layers 0, 1 (ReLU)
-    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp2, 65536, acc, nullptr, true, (rot + 5) & 15, lane, pf, prio);
-    if (it == 1) STAMPW(40);
-    if (it == 1) STAMP(6);
-    load_bias(bias_s + 256 + 32 * w, bvr, lane);
-    ring_prefetch<16, 4>(wp3, 65536, pf, (rot + 10) & 15);
-    split_planes<2>(pk, acc, bvr, true, all);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it == 1) STAMP(20);
-    __syncthreads();
-    if (it == 1) STAMP(21);
-    store_planes<2, PLP>(act, PLANE, 0, 32 * w, pk, lane);
-    if (it == 1) STAMP(22);
-    __syncthreads();
-    if (it == 1) STAMP(7);
-    stage<2, 16, PLP, 4, true>(act, PLANE, 0, wp3, 65536, acc, nullptr, true, (rot + 10) & 15, lane, pf, prio);
-    if (it == 1) STAMP(8);
-    load_bias(bias_s + 512 + 32 * w, bvr, lane);
-    if (nxt_tile < ntiles) request_rows(ridb + (cur ^ 1) * RM);    // the next tile's rows, in flight under the rest of this tile
-    split_planes<2>(pk, acc, bvr, true, all);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    store_planes<2, PLP>(act, PLANE, 0, 32 * w, pk, lane);
-    __syncthreads();
-    if (it == 1) STAMP(9);
-    // last layer (3 outputs): 8 threads per row, 32 columns each in column order, then the balanced tree over the 8 lanes
-    {
-      const int row = tid >> 3, part = tid & 7;
-      float a3[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 32; c += 8) {
-        const int col = part * 32 + c;
-        const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + col * 2);
-        const uint4 mm = *reinterpret_cast<const uint4*>(act + PLANE + row * PLP + col * 2);
-        const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * PLANE + row * PLP + col * 2);
-        const f32x4 va = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
-        const f32x4 vb = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col);
-          const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col + 4);
-          a3[k] += va[0] * wa[0] + va[1] * wa[1] + va[2] * wa[2] + va[3] * wa[3] + vb[0] * wb[0] + vb[1] * wb[1] +
-                   vb[2] * wb[2] + vb[3] * wb[3];
-          asm volatile("" : "+v"(a3[k]));          // keep the accumulators scalar (chain_dev.h: packed-f32 miscompare)
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float v = a3[k];
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-        a3[k] = v;
-      }
-      if (part == 0 && rid[row] >= 0) {
-        float* og = o + (long)rid[row] * 3;
-        og[0] = a3[0] + bo0;
-        og[1] = a3[1] + bo1;
-        og[2] = a3[2] + bo2;
-      }
-    }
-    if (it == 1) STAMP(10);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// chain A, 32-row tiles, several workgroups per CU (knob f32s_a_rows = 32).  The 64-row kernel above holds a CU alone (101 KB of
-// planes, 256 registers per wavefront): every phase between its stage GEMMs -- tile load, three epilogues, the barriers' waits for
-// the slower wavefront of each SIMD -- is exposed, and they add up to as much as the GEMMs (s_memtime).  A 32-row tile is 51 KB:
-// two or three workgroups share a CU (128 registers per wavefront) and one's serial phases run under the others' matrix work; the
-// price is a fragment load per 6 MFMAs instead of per 12.  One workgroup per tile, no software pipeline (the neighbours are it).
-template <int RING>
-__global__ __launch_bounds__(NT, 4) void chain_a_f32s_small_kernel(const float* __restrict__ samp, const uint8_t* __restrict__ inside,
-                                                                   const bf16_t* __restrict__ Wp, const float* __restrict__ bp,
-                                                                   const bf16_t* __restrict__ W0, const float* __restrict__ b0,
-                                                                   const bf16_t* __restrict__ W1, const float* __restrict__ b1,
-                                                                   const float* __restrict__ W2, const float* __restrict__ b2,
-                                                                   float* __restrict__ attn, float* __restrict__ o,
-                                                                   const int* __restrict__ order, const float* __restrict__ o_masked,
-                                                                   int R) {
-  constexpr int RMS = 32, SPLANE = RMS * PLP;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;
-  int* rid = reinterpret_cast<int*>(smem + 3 * SPLANE);
-  int* keepf = rid + RMS;
-  float* w2l = reinterpret_cast<float*>(keepf + RMS);
-  float* bias_l = w2l + 768;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31;
-  const int r0 = blockIdx.x * RMS;
-  const int rot = (w * 3) & 15;
-  for (int i = tid; i < 768; i += NT) {
-    w2l[i] = W2[i];
-    bias_l[i] = (i < 256 ? bp : i < 512 ? b0 : b1)[i & 255];
-  }
-  const float* w2s = w2l;
-  bool mine = false;
-  if (tid < RMS) {
-    const int slot = r0 + tid;
-    const int g = slot < R ? (order ? order[slot] : slot) : -1;
-    rid[tid] = g;
-    mine = g >= 0 && inside[g] != 0;
-    keepf[tid] = mine ? 1 : 0;
-  }
-  const bool any_inside = __syncthreads_or(mine) != 0;
-  if (!any_inside && o_masked) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = i * NT + tid, g = rid[c >> 6];
-      if (g >= 0) *reinterpret_cast<f32x4*>(attn + (long)g * 256 + (c & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (tid < RMS && rid[tid] >= 0) {
-      float* og = o + (long)rid[tid] * 3;
-      og[0] = o_masked[0];
-      og[1] = o_masked[1];
-      og[2] = o_masked[2];
-    }
-    return;
-  }
-  {
-    f32x4 x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = i * NT + tid;
-      x[i] = *reinterpret_cast<const f32x4*>(samp + (long)max(rid[c >> 6], 0) * 256 + (c & 63) * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = i * NT + tid;
-      store_split4<PLP>(act, SPLANE, c >> 6, (c & 63) * 4, rid[c >> 6] >= 0 ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f});
-    }
-  }
-  const bool keep[1] = {keepf[rl] != 0}, all[1] = {true};
-  __syncthreads();
-  f32x16 acc[1];
-  f32x4 bvr[4];
-  uint2 pk[1][4][3];
-  const bf16_t* wps[3] = {frag_ptr(Wp, 0, w, 16, lane), frag_ptr(W0, 0, w, 16, lane), frag_ptr(W1, 0, w, 16, lane)};
-#pragma unroll
-  for (int st = 0; st < 3; ++st) {
-    stage<1, 16, PLP, RING, false, false>(act, SPLANE, 0, wps[st], 65536, acc, nullptr, true, (rot + 5 * st) & 15, lane);
-    load_bias(bias_l + 256 * st + 32 * w, bvr, lane);
-    split_planes<1>(pk, acc, bvr, st > 0, st == 0 ? keep : all);
-    __syncthreads();
-    store_planes<1, PLP>(act, SPLANE, 0, 32 * w, pk, lane);
-    __syncthreads();
-    if (st == 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {                             // attn rows -> global: 32 B per thread
-        const int c = i * NT + tid, row = c >> 5, ch = c & 31, g = rid[row];
-        const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + ch * 16);
-        const uint4 mm = *reinterpret_cast<const uint4*>(act + SPLANE + row * PLP + ch * 16);
-        const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * SPLANE + row * PLP + ch * 16);
-        if (g >= 0) {
-          float* dst = attn + (long)g * 256 + ch * 8;
-          *reinterpret_cast<f32x4*>(dst) = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
-          *reinterpret_cast<f32x4*>(dst + 4) = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
-        }
-      }
-    }
-  }
-  // last layer (3 outputs): 16 threads per row, 16 columns each in column order, then a balanced tree over the 16 lanes
-  {
-    const int row = tid >> 4, part = tid & 15;
-    float a3[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 16; c += 8) {
-      const int col = part * 16 + c;
-      const uint4 hh = *reinterpret_cast<const uint4*>(act + row * PLP + col * 2);
-      const uint4 mm = *reinterpret_cast<const uint4*>(act + SPLANE + row * PLP + col * 2);
-      const uint4 ll = *reinterpret_cast<const uint4*>(act + 2 * SPLANE + row * PLP + col * 2);
-      const f32x4 va = join4(uint2{hh.x, hh.y}, uint2{mm.x, mm.y}, uint2{ll.x, ll.y});
-      const f32x4 vb = join4(uint2{hh.z, hh.w}, uint2{mm.z, mm.w}, uint2{ll.z, ll.w});
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col);
-        const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + k * 256 + col + 4);
-        a3[k] += va[0] * wa[0] + va[1] * wa[1] + va[2] * wa[2] + va[3] * wa[3] + vb[0] * wb[0] + vb[1] * wb[1] + vb[2] * wb[2] + vb[3] * wb[3];
-        asm volatile("" : "+v"(a3[k]));
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float v = a3[k];
-      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
-      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror: lanes 0..7 <-> 15..8
-      a3[k] = v;
-    }
-    if (part == 0 && rid[row] >= 0) {
-      float* og = o + (long)rid[row] * 3;
-      og[0] = a3[0] + b2[0];
-      og[1] = a3[1] + b2[1];
-      og[2] = a3[2] + b2[2];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// chain A on two-part fp16 operands ("f32h"; 32-row tiles, two workgroups per CU; round 4).  Same steps as chain_a_f32s_small_kernel,
-// every product as three fp16 MFMAs.  Between the stages the activations need a scale per ROW, and a row's 256 columns are spread over
+// chain A on two-part fp16 operands ("f32h"; 32-row tiles, two workgroups per CU; round 4).  Every product as three fp16 MFMAs.  Between the stages the activations need a scale per ROW, and a row's 256 columns are spread over
 // the 8 wavefronts: each wavefront leaves the maximum of its 32 columns in an LDS table in front of the barrier that frees the planes
-// (the barrier the six-product kernel has there too), every lane then reads the 8 partials of its row -- no extra barrier.  attn
+// every lane then reads the 8 partials of its row -- no extra barrier.  attn
 // (stored for chain B) and the inputs of the 3-output layer are taken from the fp32 registers, not from the 22-bit planes: attn is
 // exactly the fp32 result of its stage, the last layer's partial sums go through an LDS table summed in wavefront order.
 template <int MT>
@@ -1143,262 +434,10 @@ __device__ __forceinline__ void layernorm_rows(f32x4 (&x)[MT][4], const float* _
   }
 }
 
-// RMT = 64: 4 persons per tile (60 rows), the launch is one workgroup per CU at 1024 queries.  RMT = 32: 2 persons per tile -- launches
-// with few rows (cfg-4's 512 queries: 128 tiles of 64 rows on 256 CUs; a rank's shard of a query-sharded run) fill twice as many CUs.
-// Both sum every row in exactly the same order (the hidden dimension in 128-column chunks, k-steps rotated by the column block
-// only, one accumulator per row block): a row's result does not depend on the tile size, the launcher may pick it by the row count.
-template <int RMT>
-__global__ __launch_bounds__(NT) void chain_b_f32s_kernel(
-    const float* __restrict__ attn, int V, const float* __restrict__ tgt, const bf16_t* __restrict__ Wu,
-    const float* __restrict__ bu, const float* __restrict__ g2, const float* __restrict__ be2,
-    const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
-    const float* __restrict__ b2, const float* __restrict__ g3, const float* __restrict__ be3,
-    const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
-    float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
-    const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
-    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
-  constexpr int MT = RMT / 32, APLANE = RMT * PLP;
-  // hidden chunk held in LDS: 128 columns (two row blocks) | 256 columns (one row block) -- 8 units of 32 x 32 for the 8 wavefronts
-  constexpr int HCOLS = RMT == 64 ? 128 : 256, HP = RMT == 64 ? PLP128 : PLP, HPL = RMT * HP;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;                                   // 3 planes x RMT rows x 256 columns: mean, then t1, then tgt' + query_pos
-  char* hb = smem + 3 * APLANE;                       // 3 planes x RMT rows x HCOLS columns: FFN hidden chunk
-  float* part = reinterpret_cast<float*>(hb + 3 * HPL);
-  float* part2 = part + RMT * 8;
-  float* pr = part2 + RMT * 8;                        // per-row class probabilities (RMT x 2)
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), rl = lane & 31, h = lane >> 5;
-  const int qpt = RMT / J, rpt = qpt * J;
-  const int q0 = blockIdx.x * qpt, r0 = q0 * J;
-  const int nrow = min(rpt, rows - r0);
-  const int rot = (w * 3) & 15;
-  const long colb = 32 * w;                           // the wavefront's column block
-
-  STAMP(0);
-  // residual rows in the accumulator layout, requested long before their use
-  f32x4 tg[MT][4];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      tg[mt][g] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(mt * 32 + rl, nrow - 1)) * 256 + colb + 8 * g + 4 * h);
-
-  // ---- mean over views (dq_decoder.py:770) -> planes
-  {
-    constexpr int NCH = RMT * 64 / NT;                 // 16-byte chunks per thread
-    f32x4 s[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < V; v += 2) {                 // two views per round
-      f32x4 xv[2][NCH];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const int c = i * NT + tid;
-          xv[u][i] = *reinterpret_cast<const f32x4*>(attn + ((long)min(v + u, V - 1) * rows + r0 + min(c >> 6, nrow - 1)) * 256 + (c & 63) * 4);
-        }
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        s[i] += xv[0][i];
-        if (v + 1 < V) s[i] += xv[1][i];
-      }
-    }
-    const float Vf = (float)V;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = i * NT + tid, row = c >> 6;
-      f32x4 m = {s[i][0] / Vf, s[i][1] / Vf, s[i][2] / Vf, s[i][3] / Vf};
-      if (row >= nrow) m = f32x4{0.f, 0.f, 0.f, 0.f};
-      store_split4<PLP>(act, APLANE, row, (c & 63) * 4, m);
-    }
-  }
-  __syncthreads();
-  STAMP(1);
-
-  // ---- t1 = LN2(tgt + feature_update_mlp(mean))   (dq_decoder.py:773-778)
-  f32x16 acc[MT];
-  f32x4 bvr[4];
-  stage<MT, 16, PLP, 4, false, false>(act, APLANE, 0, frag_ptr(Wu, 0, w, 16, lane), 65536, acc, nullptr, true, rot, lane);
-  load_bias(bu + colb, bvr, lane);
-  STAMP(2);
-  {
-    f32x4 t1[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) t1[mt][g][t] = acc[mt][4 * g + t] + bvr[g][t];
-        if (mt * 32 + rl < nrow) t1[mt][g] += tg[mt][g];
-      }
-    layernorm_rows<MT>(t1, g2 + colb, be2 + colb, part, part2, lane, w);    // (its first barrier: every wavefront is done reading `act`)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) store_split4<PLP>(act, APLANE, mt * 32 + rl, colb + 8 * g + 4 * h, t1[mt][g]);
-  }
-  __syncthreads();
-  STAMP(3);
-
-  f32x4 y[MT][4];
-  if (has_ffn) {
-    // ---- FFN (mvp_decoder.py:94-98): Y = sum over the hidden columns of relu(t1 W1^T + b1) W2^T.
-    // RMT = 64: hidden chunks of 128; first GEMM of a chunk: wavefront = (row block w & 1, 32 hidden columns w >> 1), second: all 64
-    // rows x output block w over the chunk's 8 k-steps.  RMT = 32: hidden chunks of 256 (wavefront w = hidden block w), the second
-    // GEMM as two 8-k-step halves in chunk order.  Hidden column j of a row is always summed with the rotation of j's 32-column block
-    // inside its 128-column chunk, and Y over the hidden columns in the same order.
-    f32x16 accy[MT];
-    const int mt1 = RMT == 64 ? (w & 1) : 0, cb4 = RMT == 64 ? (w >> 1) : (w & 3);
-    const bool one[1] = {true};
-    const bf16_t* wp2 = frag_ptr(W2, 0, w, 64, lane);
-    const int rot1 = (cb4 * 5) & 15;
-    auto w1_ptr = [&](int c) {       // fragments of this wavefront's 32 hidden columns of chunk c
-      return RMT == 64 ? frag_ptr(W1, c >> 1, 4 * (c & 1) + cb4, 16, lane) : frag_ptr(W1, c, w, 16, lane);
-    };
-    // every stage's first fragments are requested one stage ahead, before the barriers in front of it (ring_prefetch)
-    f32x4 pf1[4][3], pf2[4][3];
-    ring_prefetch<16, 4>(w1_ptr(0), 1024 * 256, pf1, rot1);
-    constexpr int NCHUNK = 1024 / HCOLS;
-#pragma unroll 1
-    for (int c = 0; c < NCHUNK; ++c) {
-      f32x16 a1[1], a2;
-      STAMP(4 + 4 * c);
-      stage<1, 16, PLP, 4, true>(act, APLANE, 32 * mt1, w1_ptr(c), 1024 * 256, a1, &a2, true, rot1, lane, pf1);
-      a1[0] += a2;
-      STAMP(5 + 4 * c);
-      load_bias(b1 + c * HCOLS + (RMT == 64 ? 32 * cb4 : 32 * w), bvr, lane);
-      ring_prefetch<8, 4>(wp2 + (long)c * (HCOLS / 16) * 1024, 256 * 1024, pf2, rot & 7);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                              // the previous chunk's second GEMM has read hb
-      write_planes<1, HP>(hb, HPL, 32 * mt1, RMT == 64 ? 32 * cb4 : 32 * w, a1, bvr, true, one, lane);
-      if (c + 1 < NCHUNK) ring_prefetch<16, 4>(w1_ptr(c + 1), 1024 * 256, pf1, rot1);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      STAMP(6 + 4 * c);
-      if (RMT == 64) {
-        stage<MT, 8, HP, 4, true, false>(hb, HPL, 0, wp2 + (long)c * 8 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
-      } else {
-        stage<MT, 8, HP, 4, true, false>(hb, HPL, 0, wp2 + (long)c * 16 * 1024, 256 * 1024, accy, nullptr, c == 0, rot & 7, lane, pf2);
-        stage<MT, 8, HP, 4, false, false>(hb + 256, HPL, 0, wp2 + (long)(c * 16 + 8) * 1024, 256 * 1024, accy, nullptr, false, rot & 7, lane);
-      }
-    }
-    load_bias(b2 + colb, bvr, lane);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) y[mt][g][t] = accy[mt][4 * g + t] + bvr[g][t];
-    // + t1, re-read from the planes (h + m + l is exactly the fp32 value that was split): 32 registers less across the FFN
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const char* src = act + (mt * 32 + rl) * PLP + (colb + 8 * g + 4 * h) * 2;
-        y[mt][g] += join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + APLANE),
-                          *reinterpret_cast<const uint2*>(src + 2 * APLANE));
-      }
-    STAMP(36);
-    layernorm_rows<MT>(y, g3 + colb, be3 + colb, part, part2, lane, w);
-    STAMP(37);
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const char* src = act + (mt * 32 + rl) * PLP + (colb + 8 * g + 4 * h) * 2;
-        y[mt][g] = join4(*reinterpret_cast<const uint2*>(src), *reinterpret_cast<const uint2*>(src + APLANE),
-                         *reinterpret_cast<const uint2*>(src + 2 * APLANE));
-      }
-  }
-
-  // ---- tgt' -> global; class head (dq_decoder.py:889-893): per-row logits, completed across the wavefronts
-  {
-    float c0[MT], c1[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (mt * 32 + rl < nrow)
-          *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + mt * 32 + rl) * 256 + colb + 8 * g + 4 * h) = y[mt][g];
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(Wc + colb + 8 * g + 4 * h);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(Wc + 256 + colb + 8 * g + 4 * h);
-        a0 += (y[mt][g][0] * w0[0] + y[mt][g][1] * w0[1]) + (y[mt][g][2] * w0[2] + y[mt][g][3] * w0[3]);
-        a1 += (y[mt][g][0] * w1[0] + y[mt][g][1] * w1[1]) + (y[mt][g][2] * w1[2] + y[mt][g][3] * w1[3]);
-      }
-      a0 += __shfl_xor(a0, 32, 64);
-      a1 += __shfl_xor(a1, 32, 64);
-      c0[mt] = a0;
-      c1[mt] = a1;
-    }
-    __syncthreads();                                                // part / part2 of the last LayerNorm have been read
-    if (h == 0) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        part[(mt * 32 + rl) * 8 + w] = c0[mt];
-        part2[(mt * 32 + rl) * 8 + w] = c1[mt];
-      }
-    }
-    __syncthreads();
-    if (tid < RMT) {
-      pr[2 * tid] = 1.f / (1.f + expf(-(row_total(part, tid) + bc[0])));
-      pr[2 * tid + 1] = 1.f / (1.f + expf(-(row_total(part2, tid) + bc[1])));
-    }
-    __syncthreads();
-    if (tid < qpt && q0 + tid < nq_total) {
-      float p0 = 0.f, p1 = 0.f;
-      for (int j = 0; j < J; ++j) {
-        p0 += pr[2 * (tid * J + j)];
-        p1 += pr[2 * (tid * J + j) + 1];
-      }
-      p0 /= (float)J;
-      p1 /= (float)J;
-      const int qi = q0 + tid;
-      prob[2 * (long)qi] = p0;
-      prob[2 * (long)qi + 1] = p1;
-      const bool ok = forced ? (forced[qi] != 0) : (p1 > threshold);                   // dq_decoder.py:605
-      valid[qi] = ok ? 1 : 0;
-      if (ok) atomicOr(any_valid, 1);
-    }
-  }
-  STAMP(38);
-  if (Wn) {
-    // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets / logits Linear
-    //      (projattn.py:180-181) while the rows are still on the CU.  Every wavefront passed the barriers above: `act` is free.
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 x = y[mt][g];
-        if (qpos)
-          x += *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(mt * 32 + rl, nrow - 1)) * 256 + colb + 8 * g + 4 * h);
-        store_split4<PLP>(act, APLANE, mt * 32 + rl, colb + 8 * g + 4 * h, x);
-      }
-    __syncthreads();
-    STAMP(39);
-    if (colb < n_next) {
-      stage<MT, 16, PLP, 4, false, false>(act, APLANE, 0, frag_ptr(Wn, 0, w, 16, lane), 65536, acc, nullptr, true, (rot + 7) & 15, lane);
-      STAMP(40);
-      load_bias(bn + colb, bvr, lane);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if (mt * 32 + rl < nrow) {
-            f32x4 v;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = acc[mt][4 * g + t] + bvr[g][t];
-            *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + mt * 32 + rl) * n_next + colb + 8 * g + 4 * h) = v;
-          }
-    }
-  }
-  STAMP(41);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // chain B on two-part fp16 operands ("f32h"; round 4): 32-row tiles (2 persons), 71 KB of LDS -- two workgroups per CU, which the
-// six-product form's 32-row tile (101 KB) could not have.  Same steps as chain_b_f32s_kernel; every plane write is preceded by the
+// six-product form's 32-row tile (101 KB) could not have.  Every plane write is preceded by the
 // row-maximum exchange of chain_a_f32h_small_kernel (partials in an LDS table in front of a barrier that is there anyway).  The FFN's
 // hidden activations get a scale per (row, 256-column chunk): each chunk's second GEMM starts from a zero accumulator and its result is
 // un-scaled and added to the fp32 sum in chunk order.  t1 (the residual of the FFN) stays in registers: planes hold 22 bits.
@@ -1703,13 +742,7 @@ int cu_count() {
 
 }  // namespace
 
-int g_f32s_a_rows = 32;   // tuning knob "f32s_a_rows": 32 = 32-row tiles, two workgroups per CU (default: cfg-2 184 -> 140 us in the forward), 64 = one
-                          // persistent 64-row workgroup per CU, 31 = the 32-row kernel with a 2-deep fragment ring
-int g_f32s_pyr_ws = 0;    // tuning knob "f32s_pyr_ws": 1 = weight-stationary pyramid kernel, 0 = the tiled one (weights streamed per tile)
-int g_f32h_b_rows = 0;    // tuning knob "f32h_b_rows": rows per tile of mvg_chain_update_ffn_class_f32h (0 = by the row count | 32 | 64)
-int g_f32h_a_rows = 0;    // tuning knob "f32h_a_rows": rows per tile of mvg_chain_attn_pose_f32h (0 = by the row count | 32 | 64); both sum a row identically
-int g_f32h_pair = 1;      // tuning knob "f32h_pair": mvg_pyramid_f32h as two workgroups per CU (no row prefetch, fragment ring 2)
-int g_f32s_grid = 0;      // tuning knob "f32s_grid": persistent workgroups of the f32s kernels (0 = one per CU)
+int g_f32h_rows = 0;      // tuning knob "f32h_rows": rows per tile of the two fp32 chains (0 = by the row count | 32 | 64); both sizes sum a row identically
 
 extern "C" int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const float* tgt, const void* Wu, int wu_scale, const float* bu,
                                               const float* g2, const float* be2, const void* W1, int w1_scale, const float* b1,
@@ -1729,7 +762,7 @@ extern "C" int mvg_chain_update_ffn_class_f32h(const float* attn, int V, const f
   // both tile sizes sum a row identically: 64-row tiles (one workgroup per CU, fragment ring 4) unless they would leave a quarter of
   // the CUs without a workgroup (then 32-row tiles, two workgroups per CU)
   const int tiles64 = (nq_total + 64 / J - 1) / (64 / J);
-  const bool big = J <= 32 && (g_f32h_b_rows == 64 || (g_f32h_b_rows == 0 && tiles64 > (cu_count() * 3) / 4));
+  const bool big = J <= 32 && (g_f32h_rows == 64 || (g_f32h_rows == 0 && tiles64 > (cu_count() * 3) / 4));
   static bool configured[MVG_MAX_DEVICES] = {}, configured2[MVG_MAX_DEVICES] = {};
 #define MVG_CBH(MTV, CFG)                                                                                                              \
   {                                                                                                                                    \
@@ -1761,7 +794,7 @@ extern "C" int mvg_chain_attn_pose_f32h(const float* samp, const uint8_t* inside
     return MVG_E_BADARG;
   static bool configured[MVG_MAX_DEVICES] = {}, configured2[MVG_MAX_DEVICES] = {};
   // both tile sizes sum a row identically: 64-row tiles (half the fragment loads per row) once they fill the CUs
-  if (g_f32h_a_rows == 64 || (g_f32h_a_rows == 0 && (rows + 63) / 64 >= cu_count())) {
+  if (g_f32h_rows == 64 || (g_f32h_rows == 0 && (rows + 63) / 64 >= cu_count())) {
     const size_t lds = 2 * 64 * PLP + 3 * 64 * sizeof(int) + 64 * 8 * sizeof(float) + 2 * 768 * sizeof(float);
     if (int rc = configure_lds(&chain_a_f32h_small_kernel<2>, lds, configured2)) return rc;
     hipLaunchKernelGGL(chain_a_f32h_small_kernel<2>, dim3((rows + 63) / 64), dim3(NT), lds, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp,
@@ -1785,127 +818,15 @@ extern "C" int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv
        reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
     return MVG_E_BADARG;
   const size_t lds = 2 * HPLANE + RM * sizeof(int);
-  static bool configured[MVG_MAX_DEVICES] = {}, configured2[MVG_MAX_DEVICES] = {};
+  static bool configured[MVG_MAX_DEVICES] = {};
   const long ntiles = (rows + RM - 1) / RM;
-  if (g_f32h_pair) {
-    if (int rc = configure_lds(&pyramid_f32h_kernel<true>, lds, configured2)) return rc;
-    const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : 2 * cu_count());
-    hipLaunchKernelGGL(pyramid_f32h_kernel<true>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale,
-                       bv, (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
-  } else {
-    if (int rc = configure_lds(&pyramid_f32h_kernel<false>, lds, configured)) return rc;
-    const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
-    hipLaunchKernelGGL(pyramid_f32h_kernel<false>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale,
-                       bv, (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
-  }
+  // two persistent workgroups per CU (no row prefetch, fragment ring 2); the one-workgroup form with a row prefetch measured slower
+  if (int rc = configure_lds(&pyramid_f32h_kernel<true>, lds, configured)) return rc;
+  const int grid = (int)std::min<long>(ntiles, 2 * cu_count());
+  hipLaunchKernelGGL(pyramid_f32h_kernel<true>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale,
+                     bv, (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
   MVG_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mvg_pyramid_f32s(const float* feat, const void* Wv_planes, const float* bv, const void* Wg_planes, float* value,
-                                float* G, int64_t rows, int n_g, void* stream) {
-  if (!feat || !Wv_planes || !Wg_planes || !value || !G || rows < 0 || n_g <= 0 || n_g > 256 || n_g % 32 != 0) return MVG_E_BADARG;
-  if (rows == 0) return 0;
-  if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(G) |
-       reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
-    return MVG_E_BADARG;
-  if (g_f32s_pyr_ws) {
-    const size_t lds_ws = 2 * 3 * WS_PLANE + WS_RM * 1024;
-    static bool configured_ws[MVG_MAX_DEVICES] = {};
-    if (int rc = configure_lds(&pyramid_ws_f32s_kernel, lds_ws, configured_ws)) return rc;
-    const long nt32 = (rows + WS_RM - 1) / WS_RM;
-    long pairs = std::min<long>(nt32, (g_f32s_grid > 0 ? g_f32s_grid : cu_count()) / 2);
-    pairs = std::max<long>(8, (pairs / 8) * 8);          // whole groups of 8 pairs: role = (blockIdx >> 3) & 1
-    hipLaunchKernelGGL(pyramid_ws_f32s_kernel, dim3((int)(2 * pairs)), dim3(NT), lds_ws, (hipStream_t)stream, feat,
-                       (const bf16_t*)Wv_planes, bv, (const bf16_t*)Wg_planes, value, G, (long)rows, n_g);
-    MVG_LAUNCH_CHECK();
-    return 0;
-  }
-  const size_t lds = 3 * PLANE;
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&pyramid_f32s_kernel, lds, configured)) return rc;
-  const long ntiles = (rows + RM - 1) / RM;
-  const int grid = (int)std::min<long>(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
-  hipLaunchKernelGGL(pyramid_f32s_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, bv,
-                     (const bf16_t*)Wg_planes, value, G, (long)rows, n_g);
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
 
-extern "C" int mvg_chain_attn_pose_f32s(const float* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
-                                        const float* b0, const void* W1, const float* b1, const float* W2, const float* b2,
-                                        float* attn, float* o, const int32_t* order, const float* o_masked, int rows,
-                                        void* stream) {
-  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
-  if (rows == 0) return 0;
-  if (g_f32s_a_rows != 64) {       // 32: the default; 31: measurement variant with a 2-deep fragment ring
-    const size_t lds32 = 3 * 32 * PLP + 2 * 32 * sizeof(int) + 2 * 768 * sizeof(float);
-    static bool c32[MVG_MAX_DEVICES] = {}, c31[MVG_MAX_DEVICES] = {};
-    if (int rc = configure_lds(&chain_a_f32s_small_kernel<4>, lds32, c32)) return rc;
-    if (int rc = configure_lds(&chain_a_f32s_small_kernel<2>, lds32, c31)) return rc;
-#define MVG_CAS(K)                                                                                                            \
-    hipLaunchKernelGGL(K, dim3((rows + 31) / 32), dim3(NT), lds32, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp, bp,  \
-                       (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows)
-    if (g_f32s_a_rows == 31) MVG_CAS(chain_a_f32s_small_kernel<2>);
-    else MVG_CAS(chain_a_f32s_small_kernel<4>);
-#undef MVG_CAS
-    MVG_LAUNCH_CHECK();
-    return 0;
-  }
-  const size_t lds = 3 * PLANE + 4 * RM * sizeof(int) + 2 * 768 * sizeof(float);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&chain_a_f32s_kernel, lds, configured)) return rc;
-  const int ntiles = (rows + RM - 1) / RM;
-  const int grid = std::min(ntiles, g_f32s_grid > 0 ? g_f32s_grid : cu_count());
-  hipLaunchKernelGGL(chain_a_f32s_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, samp, inside, (const bf16_t*)Wp, bp,
-                     (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, attn, o, order, o_masked, rows);
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int RMT>
-static int launch_chain_b_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu, const float* g2,
-                               const float* be2, const void* W1, const float* b1, const void* W2, const float* b2, const float* g3,
-                               const float* be3, const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
-                               float* tgt_out, float* prob, uint8_t* valid, int* any_valid, const float* query_pos, const void* W_next,
-                               const float* b_next, float* xw_next, int n_next, int nq_total, int rows, int J, int has_ffn,
-                               hipStream_t st) {
-  constexpr int HP = RMT == 64 ? PLP128 : PLP;
-  const int qpt = RMT / J;
-  const size_t lds = 3 * RMT * PLP + 3 * RMT * HP + 2 * RMT * 8 * sizeof(float) + RMT * 2 * sizeof(float);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  if (int rc = configure_lds(&chain_b_f32s_kernel<RMT>, lds, configured)) return rc;
-  hipLaunchKernelGGL(chain_b_f32s_kernel<RMT>, dim3((nq_total + qpt - 1) / qpt), dim3(NT), lds, st, attn, V, tgt, (const bf16_t*)Wu, bu,
-                     g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc, threshold, forced_valid, tgt_out, prob,
-                     valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next, n_next, rows, J, nq_total, has_ffn);
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
-
-int g_f32s_b_rows = 0;    // tuning knob "f32s_b_rows": rows per tile of the fp32 chain B (0 = by the row count, 32, 64)
-
-extern "C" int mvg_chain_update_ffn_class_f32s(const float* attn, int V, const float* tgt, const void* Wu, const float* bu,
-                                               const float* g2, const float* be2, const void* W1, const float* b1,
-                                               const void* W2, const float* b2, const float* g3, const float* be3,
-                                               const float* Wc, const float* bc, float threshold, const uint8_t* forced_valid,
-                                               float* tgt_out, float* prob, uint8_t* valid, int* any_valid,
-                                               const float* query_pos, const void* W_next, const float* b_next,
-                                               float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream) {
-  if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
-  if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
-  if (V <= 0 || J <= 0 || J > 32 || B < 0 || NQ < 0) return MVG_E_BADARG;
-  if (W_next && (!b_next || !xw_next || n_next <= 0 || n_next > 256 || n_next % 32 != 0)) return MVG_E_BADARG;
-  const int nq_total = B * NQ, rows = nq_total * J;
-  if (rows == 0) return 0;
-  // every tile size computes a row bit-identically (chain_b_f32s_kernel): 32-row tiles while 64-row tiles would leave a
-  // quarter of the CUs without a workgroup
-  const int tiles64 = (nq_total + 64 / J - 1) / (64 / J);
-  const bool small = g_f32s_b_rows == 32 || (g_f32s_b_rows == 0 && tiles64 <= (cu_count() * 3) / 4);
-#define MVG_CBF(R)                                                                                                          \
-  return launch_chain_b_f32s<R>(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, forced_valid, tgt_out, \
-                                prob, valid, any_valid, query_pos, W_next, b_next, xw_next, n_next, nq_total, rows, J, has_ffn,  \
-                                (hipStream_t)stream)
-  if (small) MVG_CBF(32);
-  MVG_CBF(64);
-#undef MVG_CBF
-}

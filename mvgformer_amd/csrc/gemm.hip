@@ -23,7 +23,7 @@
 #include "common.h"
 
 int g_linear_tiles = 1;     // tuning knob "linear_tiles": 0 = always 128 x 128 tiles (rounds 1-2)
-int g_linear_xcd = 1;       // tuning knob "linear_xcd": 1 = the column tiles of one row tile run on the same XCD (shared L2)
+static const int g_linear_xcd = 1;   // the column tiles of one row tile run on the same XCD (shared L2); 0 measured slower (round 3)
 int g_f32_split = 1;        // tuning knob "f32_split": 1 = fp32 GEMMs as six bf16 MFMAs on 3-way split operands (see above)
 
 namespace {
@@ -588,18 +588,6 @@ extern "C" int mvg_linear_ordered(const float* A, int lda, const float* W, const
   return launch_linear_idx<128>(A, lda, W, bias, out, ldc, rowmask, relu, M, N, K, order, inside, masked_row, st);
 }
 
-extern "C" int mvg_linear_wgrad_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, int rows, int N, int K, int splits,
-                                    void* stream) {
-  if (!dY || !X || !partial || rows <= 0 || N <= 0 || K <= 0 || splits <= 0) return MVG_E_BADARG;
-  if (N % 4 != 0 || K % 4 != 0 || ldy % 4 != 0 || ldx % 4 != 0 || ldy < N || ldx < K) return MVG_E_BADARG;
-  if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(partial)) % 16 != 0) return MVG_E_BADARG;
-  const int rps = ((rows + splits - 1) / splits + 31) / 32 * 32;          // whole 32-row slabs per slice
-  dim3 grid((K + 127) / 128, (N + 127) / 128, splits);
-  hipLaunchKernelGGL(wgrad_f32s_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dY, (long)ldy, X, (long)ldx, partial, rows, N, K, rps,
-                     (float*)nullptr);
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
 
 extern "C" int mvg_linear_wgrad_bias_f32(const float* dY, int ldy, const float* X, int ldx, float* partial, float* partial_db, float* dW,
                                          float* db, int rows, int N, int K, int splits, void* stream) {
@@ -620,23 +608,6 @@ extern "C" int mvg_linear_wgrad_bias_f32(const float* dY, int ldy, const float* 
   return 0;
 }
 
-extern "C" int mvg_linear_splitk_f32(const float* A, int lda, const float* W, int ldw, float* partial, int M, int N, int K, int splits,
-                                     void* stream) {
-  if (!A || !W || !partial || M <= 0 || N <= 0 || K <= 0 || splits <= 0) return MVG_E_BADARG;
-  if (K % splits != 0 || (K / splits) % 32 != 0 || N % 8 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K) return MVG_E_BADARG;
-  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(partial)) % 16 != 0) return MVG_E_BADARG;
-  dim3 grid((N + 127) / 128, (M + 127) / 128, splits);
-  if (g_f32_split)
-    hipLaunchKernelGGL((linear_kernel<float, false, float, 128, 128, false, true>), grid, dim3(256), 0, (hipStream_t)stream, A,
-                       (const float*)nullptr, (long)lda, (const void*)W, (const float*)nullptr, partial, (long)N, (const uint8_t*)nullptr, 0,
-                       M, N, K, nullptr, nullptr, nullptr, 0, ldw, K / splits);
-  else
-    hipLaunchKernelGGL((linear_kernel<float, false, float, 128, 128>), grid, dim3(256), 0, (hipStream_t)stream, A, (const float*)nullptr,
-                       (long)lda, (const void*)W, (const float*)nullptr, partial, (long)N, (const uint8_t*)nullptr, 0, M, N, K, nullptr,
-                       nullptr, nullptr, 0, ldw, K / splits);
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
 
 extern "C" int mvg_linear(const void* A, int a_dtype, int lda, const void* W, int w_dtype, const float* bias, void* out,
                           int out_dtype, int ldc, const uint8_t* rowmask, int relu, int M, int N, int K, void* stream) {

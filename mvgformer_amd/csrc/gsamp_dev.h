@@ -57,73 +57,14 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
   dx = (unsigned)(wr_c - wl_c) * 64u;
 }
 
-// ---- LDS window of the coarsest level (round 3, msda_gsamp_win_kernel).  The 64 pairs of a sampling workgroup are neighbours in
-// the image (Morton order), so the samples they take from the coarsest level fall into a small rectangle of the (image, head)
-// plane: the workgroup stages that rectangle (WIN x WIN pixels x 64 B, 80-byte pitch) in LDS once and serves every sample
-// whose 2 x 2 footprint lies inside it with ds_read_b128 instead of a gather through the L1; all others take the global
-// path as before.  Same bytes either way: results are bit-identical to the plain kernel.
-typedef __attribute__((address_space(3))) const unsigned char* lds_bytes_t;
-constexpr int GSAMP_WIN = 16, GSAMP_WIN_PITCH = 80;
-struct GsampWin {
-  lds_bytes_t base;      // LDS copy of the window, pixel (y, x) at ((y - y0) * wx + (x - x0)) * GSAMP_WIN_PITCH
-  int x0, y0, wx, wy;    // window origin / extent in pixels of level L - 1
-  int n;                 // image the window was staged from
-};
-
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
+
 #ifndef MVG_GSAMP_NT0
 #define MVG_GSAMP_NT0 0
 #endif
 __device__ __forceinline__ uint4 gs_load_nt(const char* p) {
   const gs_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(p));      // global_load_dwordx4 ... nt
   return uint4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ uint4 lds_load16(lds_bytes_t p) {
-  const gs_u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const gs_u32x4*>(p);   // ds_read_b128
-  return uint4{v.x, v.y, v.z, v.w};
-}
-
-// gsamp_coords for a kernel with a staged window: for samples of the coarsest level whose four (clamped) corner pixels are
-// inside the window -- and whose pair belongs to the staged image -- ot / ob / dx are byte offsets into the LDS copy and fl = 1
-template <int L>
-__device__ __forceinline__ void gsamp_coords_win(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
-                                                 int sub, const GsampWin& win, bool win_ok, unsigned& wt, unsigned& wb,
-                                                 unsigned& ot, unsigned& ob, unsigned& dx, unsigned& fl) {
-  constexpr int P = 8, NB = 4, LP = L * P;
-  const int l = (it * NB) / P;
-  const int H = lv.H[l], W = lv.W[l];
-  const float Wf = (float)W, Hf = (float)H;
-  const float2 rr = *reinterpret_cast<const float2*>(sc + 3 * LP + 2 * l);
-  const float rx = rr.x, ry = rr.y;
-  const float lgs = sc[it * NB + sub];
-  const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
-  const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];
-  const float h_raw = ly * Hf - 0.5f, w_raw = lx * Wf - 0.5f;
-  const bool inside = (h_raw > -1.f) & (w_raw > -1.f) & (h_raw < Hf) & (w_raw < Wf);
-  const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
-  const float hl_f = floorf(h_im), wl_f = floorf(w_im);
-  const int h_low = (int)hl_f, w_low = (int)wl_f;
-  const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-  const float e = __expf(lgs - mx);
-  const float a = inside ? e : 0.f;
-  const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-  const float t0 = hh * hw * a, t1 = hh * lw * a, t2 = lh * hw * a, t3 = lh * lw * a;
-  const float c0 = (hl_ok & wl_ok) ? t0 : 0.f, c1 = (hl_ok & wh_ok) ? t1 : 0.f;
-  const float c2 = (hh_ok & wl_ok) ? t2 : 0.f, c3 = (hh_ok & wh_ok) ? t3 : 0.f;
-  wt = pack_bf16x2(c0, c1);
-  wb = pack_bf16x2(c2, c3);
-  const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-  const int wl_c = min(max(w_low, 0), W - 1), wr_c = min(max(w_low + 1, 0), W - 1);
-  const bool in_win = (l == L - 1) & win_ok & (wl_c >= win.x0) & (wr_c < win.x0 + win.wx) & (hl_c >= win.y0) &
-                      (hh_c < win.y0 + win.wy);
-  const unsigned base = (unsigned)lv.start[l];
-  const unsigned g_t = (base + (unsigned)(hl_c * W + wl_c)) * 64u, g_b = (base + (unsigned)(hh_c * W + wl_c)) * 64u;
-  const unsigned w_t = (unsigned)((hl_c - win.y0) * win.wx + (wl_c - win.x0)) * (unsigned)GSAMP_WIN_PITCH;
-  const unsigned w_b = (unsigned)((hh_c - win.y0) * win.wx + (wl_c - win.x0)) * (unsigned)GSAMP_WIN_PITCH;
-  ot = in_win ? w_t : g_t;
-  ob = in_win ? w_b : g_b;
-  dx = (unsigned)(wr_c - wl_c) * (in_win ? (unsigned)GSAMP_WIN_PITCH : 64u);
-  fl = in_win ? 1u : 0u;
 }
 
 // One (image-query pair, head) of the G-sampling kernel, computed by the 4 lanes of a quad (lane `sub` owns channels
@@ -387,197 +328,3 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
 #undef MVG_BLEND
   }
 }
-
-// ---- the unit in three pieces for msda_gsamp_win_kernel, so that the workgroup can put its
-// window staging and its ONE barrier between them.  gsamp_prepare = phase A + pass 1 of gsamp_unit (same code), returns the
-// softmax offset; gsamp_plain_levels = the batches of the levels above the coarsest; gsamp_window_level = the coarsest level.
-template <int L>
-__device__ __forceinline__ float gsamp_prepare(const bf16_t* __restrict__ G, const float* __restrict__ xw,
-                                               const float* __restrict__ r, const LevelTable& lv, float* __restrict__ sc,
-                                               int pair, int m, int sub, int Lq, int S, int B) {
-  constexpr int P = 8, LP = L * P, NCHK = 3 * L;
-  const int n = pair / Lq, q = pair - n * Lq, b = n % B;
-
-  if (sub < L) *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = *reinterpret_cast<const float2*>(r + ((long)pair * L + sub) * 2);
-  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk
-#pragma unroll
-  for (int k = 0; k < (NCHK + 3) / 4; ++k) {
-    const int ci = sub + 4 * k;
-    if (ci < NCHK) {
-      // G / xw columns are grouped per (16 offsets | 8 logits): group g of a level row = columns [24g, 24g+24) =
-      // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
-      // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
-      const int t = ci / 3, part = ci - 3 * t;
-      const int fg = m * L + t;
-      const int l = fg >> 3;                                               // level row of the reinterpreted view
-      const int col = 24 * (fg & 7) + 8 * part;
-      const bool is_logit = part == 2;
-      const int H = lv.H[l], W = lv.W[l];
-      const float Wf = (float)W, Hf = (float)H;
-      const float refx = r[((long)pair * L + l) * 2], refy = r[((long)pair * L + l) * 2 + 1];
-      const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
-      const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
-      const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
-      const float x0f = floorf(ix), y0f = floorf(iy);
-      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-      const float tx = ix - x0f, ty = iy - y0f;
-      const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
-      const float w00 = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f, w10 = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
-      const float w01 = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f, w11 = (x1ok && y1ok) ? tx * ty : 0.f;
-      const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
-      const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
-      // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
-      const char* g_bytes = reinterpret_cast<const char*>(G);
-      const unsigned gb = ((unsigned)(n * S + lv.start[l]) * 192u + (unsigned)col) * 2u;
-      const uint4 c00 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x0c) * 384u));
-      const uint4 c10 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x1c) * 384u));
-      const uint4 c01 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x0c) * 384u));
-      const uint4 c11 = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x1c) * 384u));
-      const float* xq = xw + ((long)b * Lq + q) * 192 + col;
-      const f32x4 xa = *reinterpret_cast<const f32x4*>(xq), xb = *reinterpret_cast<const f32x4*>(xq + 4);
-      const unsigned a4[4] = {c00.x, c00.y, c00.z, c00.w}, b4[4] = {c10.x, c10.y, c10.z, c10.w};
-      const unsigned c4[4] = {c01.x, c01.y, c01.z, c01.w}, d4[4] = {c11.x, c11.y, c11.z, c11.w};
-      float v[8];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        v[2 * t] = w00 * __uint_as_float(a4[t] << 16) + w10 * __uint_as_float(b4[t] << 16) +
-                   w01 * __uint_as_float(c4[t] << 16) + w11 * __uint_as_float(d4[t] << 16);
-        v[2 * t + 1] = w00 * __uint_as_float(a4[t] & 0xffff0000u) + w10 * __uint_as_float(b4[t] & 0xffff0000u) +
-                       w01 * __uint_as_float(c4[t] & 0xffff0000u) + w11 * __uint_as_float(d4[t] & 0xffff0000u);
-      }
-      float* dst = sc + (is_logit ? 8 * t : LP + 16 * t + 8 * part);
-      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0] + xa[0], v[1] + xa[1], v[2] + xa[2], v[3] + xa[3]};
-      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4] + xb[0], v[5] + xb[1], v[6] + xb[2], v[7] + xb[3]};
-    }
-  }
-  // quad-private scratch: LDS operations of one wavefront execute in order, only the compiler must not reorder
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- pass 1: softmax denominator of the head's logits; the 4 lanes of the quad split the LP logits and combine
-  //      with DPP (same value in all four: the butterfly adds commute)
-  float mx = -INFINITY;
-  {
-    constexpr int MYC = (LP / 4 + 3) / 4;            // 16-byte chunks per lane
-    f32x4 lg[MYC];
-#pragma unroll
-    for (int i = 0; i < MYC; ++i) {
-      const int c = sub + 4 * i;
-      lg[i] = (c < LP / 4) ? *reinterpret_cast<const f32x4*>(sc + 4 * c) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
-    }
-    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xf, 0xf, false)));
-    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xf, 0xf, false)));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MYC; ++i)     // exp(-inf) = 0 for the padding chunks
-      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
-    sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0xB1, 0xf, 0xf, false));
-    sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x4E, 0xf, 0xf, false));
-    mx += __logf(sum);
-  }
-
-  return mx;
-}
-
-#define MVG_GW_BLEND4()                                                                                 \
-    {                                                                                                   \
-      unsigned wt[NB], wb[NB];                                                                          \
-      wt[0] = quad_bcast<0>(pw_t); wt[1] = quad_bcast<1>(pw_t); wt[2] = quad_bcast<2>(pw_t); wt[3] = quad_bcast<3>(pw_t); \
-      wb[0] = quad_bcast<0>(pw_b); wb[1] = quad_bcast<1>(pw_b); wb[2] = quad_bcast<2>(pw_b); wb[3] = quad_bcast<3>(pw_b); \
-      _Pragma("unroll") for (int s = 0; s < NB; ++s)                                                    \
-        _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                           \
-          const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);                        \
-          const unsigned l4[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};                 \
-          const unsigned r4[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w}; \
-          _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
-            const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);                       \
-            const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);                       \
-            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);         \
-            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false); \
-          }                                                                                             \
-        }                                                                                               \
-    }
-
-// levels 0 .. L-2 (plain global gathers, gsamp_unit's default loop); leaves the first window batch's coordinates in `st`
-template <int L>
-__device__ __forceinline__ void gsamp_plain_levels(const bf16_t* __restrict__ vp, const LevelTable& lv, const float* __restrict__ sc,
-                                                   int pair, int m, int sub, int Lq, int S, const GsampWin& w, float (&acc)[8], const float mx, unsigned& cw_t,
-                                                   unsigned& cw_b, unsigned& co_t, unsigned& co_b, unsigned& co_x, unsigned& co_f) {
-  constexpr int P = 8, LP = L * P, NB = 4, NPLAIN = (L - 1) * P / NB;
-  const int n = pair / Lq;
-  const bool win_ok = n == w.n;
-  const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
-  const char* vp_bytes = reinterpret_cast<const char*>(vp);
-#pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-  co_f = 0u;
-  if (NPLAIN > 0) gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
-  else gsamp_coords_win<L>(0, sc, mx, lv, sub, w, win_ok, cw_t, cw_b, co_t, co_b, co_x, co_f);
-#pragma unroll 1
-  for (int it = 0; it < NPLAIN; ++it) {
-    uint4 raw[NB][4];
-#define MVG_QS(SS)                                                                                      \
-    {                                                                                                   \
-      const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;  \
-      const unsigned dxs = quad_bcast<SS>(co_x);                                                     \
-      raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + ot);                                      \
-      raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs));                              \
-      raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                      \
-      raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                              \
-    }
-    MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
-#undef MVG_QS
-    const unsigned pw_t = cw_t, pw_b = cw_b;
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < NPLAIN) gsamp_coords<L>(it + 1, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
-    else gsamp_coords_win<L>(NPLAIN, sc, mx, lv, sub, w, win_ok, cw_t, cw_b, co_t, co_b, co_x, co_f);
-    __builtin_amdgcn_sched_barrier(0);
-    MVG_GW_BLEND4()
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// level L-1 through the LDS window (samples outside it: global), after the workgroup's barrier
-template <int L>
-__device__ __forceinline__ void gsamp_window_level(const bf16_t* __restrict__ vp, const LevelTable& lv, const float* __restrict__ sc,
-                                                   int pair, int m, int sub, int Lq, int S, const GsampWin& w, float (&acc)[8], const float mx, unsigned& cw_t,
-                                                   unsigned& cw_b, unsigned& co_t, unsigned& co_b, unsigned& co_x, unsigned& co_f) {
-  constexpr int P = 8, LP = L * P, NB = 4, NIT = LP / NB, NPLAIN = (L - 1) * P / NB;
-  const int n = pair / Lq;
-  const bool win_ok = n == w.n;
-  const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
-  const char* vp_bytes = reinterpret_cast<const char*>(vp);
-  const lds_bytes_t wl_base = w.base + sub * 16;
-#pragma unroll 1
-  for (int it = NPLAIN; it < NIT; ++it) {
-    uint4 raw[NB][4];
-#define MVG_QW(SS)                                                                                      \
-    {                                                                                                   \
-      const unsigned ot = quad_bcast<SS>(co_t), ob = quad_bcast<SS>(co_b);                        \
-      const unsigned dxs = quad_bcast<SS>(co_x), fls = quad_bcast<SS>(co_f);                      \
-      if (fls) {                                                                                        \
-        raw[SS][0] = lds_load16(wl_base + ot);                                                          \
-        raw[SS][1] = lds_load16(wl_base + (ot + dxs));                                                  \
-        raw[SS][2] = lds_load16(wl_base + ob);                                                          \
-        raw[SS][3] = lds_load16(wl_base + (ob + dxs));                                                  \
-      } else {                                                                                          \
-        raw[SS][0] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + lane_off));                       \
-        raw[SS][1] = *reinterpret_cast<const uint4*>(vp_bytes + (ot + dxs + lane_off));                 \
-        raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + lane_off));                       \
-        raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs + lane_off));                 \
-      }                                                                                                 \
-    }
-    MVG_QW(0) MVG_QW(1) MVG_QW(2) MVG_QW(3)
-#undef MVG_QW
-    const unsigned pw_t = cw_t, pw_b = cw_b;
-    __builtin_amdgcn_sched_barrier(0);
-    gsamp_coords_win<L>(it + 1 < NIT ? it + 1 : NPLAIN, sc, mx, lv, sub, w, win_ok, cw_t, cw_b, co_t, co_b,
-                        co_x, co_f);
-    __builtin_amdgcn_sched_barrier(0);
-    MVG_GW_BLEND4()
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-#undef MVG_GW_BLEND4

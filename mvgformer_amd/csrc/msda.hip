@@ -582,213 +582,15 @@ __global__ __launch_bounds__(256, (CPL * NB * (int)sizeof(T) >= 64 ? 3 : 4)) voi
 }
 
 // ------------------------------------------------------------------------------------------
-// msda_gfused_f32_kernel -- G-sampling in the reference's own arithmetic (fp32 storage, fp32 math; round 2).
+// msda_gfused_f32_hp_kernel -- G-sampling in the reference's own arithmetic (fp32 storage, fp32 math; rounds 2 / 4).
 // msda_fused_kernel needs the (pairs * L, 192) tensor `oa` of offsets / logits, i.e. a gather of 256-channel reference-point
 // rows (`ain`, 236 MB per layer at cfg-2) and a (V * Lq * L) x 256 x 192 GEMM (177 MB out) per layer.  Bilinear sampling commutes
 // with the Linear (see msda_gsamp_kernel), so here the Linear is applied once to the pyramid (G = feat @ Woa^T, fp32, columns
 // in ops.gsamp_column_order) and every (pair, head) gathers its 24 logits + 48 offsets from G at the reference point and adds
-// xw = (tgt + query_pos) @ Woa^T + b -- phase A below, 8 lanes per head, one (image, query) pair per wavefront, results parked
-// in LDS --, then softmax, locations and sampling exactly as msda_fused_kernel<float> does them.
-template <int L>
-__global__ __launch_bounds__(256, 4) void msda_gfused_f32_kernel(const float* __restrict__ value, const float* __restrict__ G,
-                                                                 const float* __restrict__ xw, const float* __restrict__ r,
-                                                                 LevelTable lv, float* __restrict__ samp,
-                                                                 const uint8_t* __restrict__ pair_mask,
-                                                                 const int* __restrict__ order, int n_pairs,
-                                                                 int Lq, int S, int B) {
-  constexpr int D = 32, P = 8, C = 256, LP = L * P, NCHK = 3 * L, NB = 4, CPL = 4, SCP = 3 * LP + 8;
-  typedef RawVec<float, CPL> RV;
-  __shared__ __attribute__((aligned(16))) float scratch[4][8][SCP];
-  // XCD-aware block remap (bijective): XCD x = blockIdx % 8 walks a contiguous block range
-  const int nb = gridDim.x;
-  const int q8 = nb >> 3, r8 = nb & 7;
-  const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-  const int lblock = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = lblock * 4 + wave;
-  const int m = lane >> 3, sub = lane & 7;
-  if (slot >= n_pairs) return;                         // one (image, query) pair per wavefront: whole wavefronts leave
-  // slot -> pair through the image-space processing order (mvg_bin_pairs: neighbours in the maps are neighbours in the
-  // launch, pairs outside the image last); pairs the caller masks out (their rows are multiplied by 0 by the consumer,
-  // dq_decoder.py:585-586) are written as zeros without being sampled
-  const int pair = order ? order[slot] : slot;
-  if (pair_mask && !pair_mask[pair]) {
-    *reinterpret_cast<f32x4*>(samp + (long)pair * C + m * D + sub * CPL) = f32x4{0.f, 0.f, 0.f, 0.f};
-    return;
-  }
-  const bool live = true;
-  const int n = pair / Lq, q = pair - n * Lq, b = n % B;
-  float* sc = &scratch[wave][m][0];
-
-  // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk, one chunk per lane.
-  // All loads of the lane's (NCHK + 7) / 8 chunks are requested before the first is used (lanes without a last chunk fetch
-  // chunk NCHK - 1 again and do not store it), the reference points once per lane: see gsamp_unit (same transformation).
-  constexpr int NK = (NCHK + 7) / 8;
-  float2 rr[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
-  f32x4 ga[NK][2], gb[NK][2], gc[NK][2], gd[NK][2], gx4[NK][2];
-  float w00[NK], w10[NK], w01[NK], w11[NK];
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int ci = min(sub + 8 * k, NCHK - 1);
-    const int t = ci / 3, part = ci - 3 * t;           // group t of the head (= level of its samples), 16 offsets | 8 logits
-    const int fg = m * L + t;
-    const int l = fg >> 3;                             // level row of the reinterpreted view (projattn.py:180-184)
-    const int col = 24 * (fg & 7) + 8 * part;
-    const int H = lv.H[l], W = lv.W[l];
-    const float Wf = (float)W, Hf = (float)H;
-    float refx = rr[0].x, refy = rr[0].y;
-#pragma unroll
-    for (int ll = 1; ll < L; ++ll) {
-      refx = l == ll ? rr[ll].x : refx;
-      refy = l == ll ? rr[ll].y : refy;
-    }
-    const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
-    const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
-    const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;    // grid_sample, align_corners=False
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-    const float tx = ix - x0f, ty = iy - y0f;
-    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
-    w00[k] = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
-    w10[k] = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
-    w01[k] = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
-    w11[k] = (x1ok && y1ok) ? tx * ty : 0.f;
-    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
-    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
-    const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
-    const float* p00 = gp + (long)(y0c * W + x0c) * 192;
-    const float* p10 = gp + (long)(y0c * W + x1c) * 192;
-    const float* p01 = gp + (long)(y1c * W + x0c) * 192;
-    const float* p11 = gp + (long)(y1c * W + x1c) * 192;
-    const float* xq = xw + ((long)b * Lq + q) * 192 + col;
-#pragma unroll
-    for (int hlf = 0; hlf < 2; ++hlf) {
-      ga[k][hlf] = *reinterpret_cast<const f32x4*>(p00 + 4 * hlf);
-      gb[k][hlf] = *reinterpret_cast<const f32x4*>(p10 + 4 * hlf);
-      gc[k][hlf] = *reinterpret_cast<const f32x4*>(p01 + 4 * hlf);
-      gd[k][hlf] = *reinterpret_cast<const f32x4*>(p11 + 4 * hlf);
-      gx4[k][hlf] = *reinterpret_cast<const f32x4*>(xq + 4 * hlf);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int ci = sub + 8 * k;
-    const int cc = min(ci, NCHK - 1);
-    const int t = cc / 3, part = cc - 3 * t;
-    if (ci < NCHK) {
-      float* dst = sc + (part == 2 ? 8 * t : LP + 16 * t + 8 * part);
-#pragma unroll
-      for (int hlf = 0; hlf < 2; ++hlf)
-        *reinterpret_cast<f32x4*>(dst + 4 * hlf) = w00[k] * ga[k][hlf] + w10[k] * gb[k][hlf] + w01[k] * gc[k][hlf] + w11[k] * gd[k][hlf] + gx4[k][hlf];
-    }
-  }
-  // head-private scratch rows inside one wavefront: LDS operations of a wavefront execute in order
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- pass 1: max and sum of the head's L*P logits (softmax denominator), redundantly on the 8 lanes of a head
-  float mx = -INFINITY;
-  {
-    f32x4 lg[LP / 4];
-#pragma unroll
-    for (int i = 0; i < LP / 4; ++i) {
-      lg[i] = *reinterpret_cast<const f32x4*>(sc + 4 * i);
-      mx = fmaxf(fmaxf(fmaxf(mx, lg[i][0]), fmaxf(lg[i][1], lg[i][2])), lg[i][3]);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < LP / 4; ++i)
-      sum += __expf(lg[i][0] - mx) + __expf(lg[i][1] - mx) + __expf(lg[i][2] - mx) + __expf(lg[i][3] - mx);
-    mx += __logf(sum);                                   // fold 1/sum into the exponent: w = exp(x - mx - log(sum))
-  }
-
-  const float* vbase = value + (long)n * S * C + m * D + sub * CPL;
-  float acc[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
-  // ---- pass 2 (round 3).  The first form computed every sample's coordinates, zero padding and softmax weight on all 8 lanes of
-  // the head (PMC: 2 425 VALU instructions per wavefront, the VALU 57 % busy -- the kernel's bound).  Now lane `sub` computes ONE of
-  // the 8 samples of a level (P = 8) and the 8 lanes exchange the results with ds_swizzle (crossbar only, no LDS memory): 4 corner
-  // weights + 3 element offsets per sample; two half batches of 4 samples = 16 gathers in flight as before.  Same operations in
-  // the same order for every sample and every accumulation: bit-identical to the first form.
-  static_assert(P == 8 && NB == 4, "one sample per lane of the head's 8");
-#define MVG_SW8(K, X) __builtin_amdgcn_ds_swizzle((X), 24 | ((K) << 5))      /* value of lane K of every group of 8 lanes */
-#pragma unroll 1
-  for (int l = 0; l < L; ++l) {
-    const int H = lv.H[l], W = lv.W[l];
-    const float Wf = (float)W, Hf = (float)H;
-    float refx = rr[0].x, refy = rr[0].y;
-#pragma unroll
-    for (int ll = 1; ll < L; ++ll) {
-      refx = l == ll ? rr[ll].x : refx;
-      refy = l == ll ? rr[ll].y : refy;
-    }
-    const float* lvl = vbase + (long)lv.start[l] * C;
-    int my_w[4], my_t, my_b, my_x;
-    {
-      const float lgs = sc[l * P + sub];
-      const float2 of = *reinterpret_cast<const float2*>(sc + LP + (l * P + sub) * 2);
-      const float lx = refx + of.x * lv.invW[l];                         // projattn.py:186-191
-      const float ly = refy + of.y * lv.invH[l];
-      const float h_raw = ly * Hf - 0.5f;                                // cuh:295-296
-      const float w_raw = lx * Wf - 0.5f;
-      const bool inside = (h_raw > -1.f) && (w_raw > -1.f) && (h_raw < Hf) && (w_raw < Wf);   // cuh:298
-      const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
-      const float hl_f = floorf(h_im), wl_f = floorf(w_im);
-      const int h_low = (int)hl_f, w_low = (int)wl_f;
-      const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
-      const float a = inside ? __expf(lgs - mx) : 0.f;                   // softmax weight (projattn.py:184)
-      const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-      my_w[0] = __float_as_int((hl_ok && wl_ok) ? hh * hw * a : 0.f);   // cuh:66-88 zero padding
-      my_w[1] = __float_as_int((hl_ok && wh_ok) ? hh * lw * a : 0.f);
-      my_w[2] = __float_as_int((hh_ok && wl_ok) ? lh * hw * a : 0.f);
-      my_w[3] = __float_as_int((hh_ok && wh_ok) ? lh * lw * a : 0.f);
-      const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-      const int wl_c = min(max(w_low, 0), W - 1), wh_c = min(max(w_low + 1, 0), W - 1);
-      my_t = (hl_c * W + wl_c) * C;
-      my_b = (hh_c * W + wl_c) * C;
-      my_x = (wh_c - wl_c) * C;
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float cw[NB][4];
-      typename RV::type raw[NB][4];
-#define MVG_GS8(S_, K)                                                                                \
-      {                                                                                               \
-        const int et = MVG_SW8(K, my_t), eb = MVG_SW8(K, my_b), ex = MVG_SW8(K, my_x);                \
-        cw[S_][0] = __int_as_float(MVG_SW8(K, my_w[0]));                                              \
-        cw[S_][1] = __int_as_float(MVG_SW8(K, my_w[1]));                                              \
-        cw[S_][2] = __int_as_float(MVG_SW8(K, my_w[2]));                                              \
-        cw[S_][3] = __int_as_float(MVG_SW8(K, my_w[3]));                                              \
-        raw[S_][0] = RV::load(lvl + et);                                                              \
-        raw[S_][1] = RV::load(lvl + (et + ex));                                                       \
-        raw[S_][2] = RV::load(lvl + eb);                                                              \
-        raw[S_][3] = RV::load(lvl + (eb + ex));                                                       \
-      }
-      if (half == 0) {
-        MVG_GS8(0, 0) MVG_GS8(1, 1) MVG_GS8(2, 2) MVG_GS8(3, 3)
-      } else {
-        MVG_GS8(0, 4) MVG_GS8(1, 5) MVG_GS8(2, 6) MVG_GS8(3, 7)
-      }
-#undef MVG_GS8
-      __builtin_amdgcn_sched_barrier(0);   // all 16 loads are issued before the first blend
-#pragma unroll
-      for (int s_ = 0; s_ < NB; ++s_)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) RV::fma(acc, raw[s_][k], cw[s_][k]);
-    }
-  }
-#undef MVG_SW8
-  if (live) store_acc<float, CPL>(samp + (long)pair * C + m * D + sub * CPL, acc);
-}
-
-// msda_gfused_f32_hp_kernel -- the same unit of work (one (pair, head) on 8 lanes: identical operations in identical order, bit-identical
-// rows) under the bf16 kernel's decomposition (round 4): a wavefront takes 8 NEIGHBOURING pairs of ONE head instead of the 8 heads of one
-// pair.  The 8 heads of a pair follow 8 different rays, so no two lanes groups of a gather instruction shared a 128-byte line and the
+// xw = (tgt + query_pos) @ Woa^T + b -- phase A below, 8 lanes per head, results parked in LDS --, then softmax, locations and
+// sampling exactly as msda_fused_kernel<float> does them.
+// Work decomposition (round 4; the round-2 kernel -- a wavefront took the 8 heads of one pair -- computed identical rows, 368 us
+// against 238 at cfg-2, and is deleted): one (pair, head) on 8 lanes, a wavefront takes 8 NEIGHBOURING pairs of ONE head.  The 8 heads of a pair follow 8 different rays, so no two lanes groups of a gather instruction shared a 128-byte line and the
 // lines in flight (16 loads x 8 heads per wavefront) turned the 32-KB L1 over before a neighbour could reuse them: 43 % L1 hits, 29.8 M
 // L2 requests per launch against the bf16 kernel's 7.3 M (profiles/r04_rocprofv3_summary_fp32.txt).  Neighbouring pairs of one head sample
 // the same or adjacent pixels: the lane groups of one instruction coalesce, and a workgroup's footprint is one head's patch.
@@ -1061,8 +863,9 @@ __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, c
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 }
 
-// Two builds of the same body.  The kernel is bound by (gather latency) x (wavefronts per CU): hipcc's own allocation is 101 VGPRs
-// = 4 wavefronts per SIMD; pinned to 5 per SIMD it fits 96 VGPRs with 5 dwords of scratch spill outside the sampling loop.
+// (hipcc's own allocation is 101 VGPRs = 4 wavefronts per SIMD; a build pinned to 5 per SIMD -- 96 VGPRs, 5 dwords of scratch
+// spill -- was 5 % slower: more loads in flight per CU only thrash the L1s.  An LDS window for the coarsest level was built twice
+// and lost at 5 views and at 31: profiles/r03_experiments.txt, r05_experiments.txt.)
 template <int L, int NT>
 __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                         const float* __restrict__ xw, const float* __restrict__ r,
@@ -1071,112 +874,6 @@ __global__ __launch_bounds__(NT) void msda_gsamp_kernel(const bf16_t* __restrict
                                                         int n_pairs, int Lq, int S, int B, int map_ch) {
   msda_gsamp_body<L, NT>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
 }
-template <int L, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 5))) void msda_gsamp_occ5_kernel(
-    const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G, const float* __restrict__ xw, const float* __restrict__ r,
-    LevelTable lv, bf16_t* __restrict__ samp, const uint8_t* __restrict__ pair_mask, const int* __restrict__ order, int n_pairs,
-    int Lq, int S, int B, int map_ch) {
-  msda_gsamp_body<L, NT>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
-}
-
-// msda_gsamp_win_kernel (round 3; VERDICT r2 item 4, the north_star's "LDS staging of sampling windows"): the same work
-// decomposition and arithmetic as msda_gsamp_kernel plus one LDS window per workgroup for the COARSEST level: a GSAMP_WIN x GSAMP_WIN
-// rectangle of the (image, head) plane (16 x 16 pixels x 64 B at an 80-byte pitch = 20 KB next to the 20 KB of quad scratch: still
-// four workgroups per CU); samples whose 2 x 2 footprint is inside it are read with ds_read_b128, the others gathered from global
-// memory -- bit-identical results.  (A first form with a bounding-box pass, three barriers and the staging waited for up front was
-// 35 us per launch slower than the plain kernel; this one is 7.)  The window is centred on the reference pixel of the workgroup's FIRST slot (read by every wavefront itself:
-// no exchange; the 64 pairs of a workgroup are Morton neighbours), its 16 KB are requested before anything else and parked in
-// LDS right after the wavefront's own phase-A loads have returned (in-order vmcnt: they have arrived by then), the levels above
-// the coarsest run the plain loop, and ONE barrier sits in front of the coarsest level's two batches.
-template <int L, int NT>
-__global__ __launch_bounds__(NT) void msda_gsamp_win_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
-                                                             const float* __restrict__ xw, const float* __restrict__ r,
-                                                             LevelTable lv, bf16_t* __restrict__ samp,
-                                                             const uint8_t* __restrict__ pair_mask, const int* __restrict__ order,
-                                                             int n_pairs, int Lq, int S, int B, int map_ch) {
-  constexpr int SCP = 3 * L * 8 + 8;
-  constexpr int NST = GSAMP_WIN * GSAMP_WIN * 4 / NT;       // staged 16-byte chunks per thread (4 at 256 threads)
-  static_assert(GSAMP_WIN * GSAMP_WIN * 4 % NT == 0, "whole passes of the workgroup");
-  __shared__ __attribute__((aligned(16))) float scratch[NT / 64][16][SCP];
-  __shared__ __attribute__((aligned(16))) unsigned char winbuf[GSAMP_WIN * GSAMP_WIN * GSAMP_WIN_PITCH];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane & 3, pl = lane >> 2;
-  int m, pblk;
-  if (map_ch == 0) {
-    m = blockIdx.x & 7;
-    pblk = blockIdx.x >> 3;
-  } else {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    m = j & 7;
-    const int t = j >> 3;
-    pblk = ((t / map_ch) * 8 + xcd) * map_ch + t % map_ch;
-  }
-  const int slot0 = pblk * (NT / 4);
-  if (slot0 >= n_pairs) return;                              // uniform: nothing in this workgroup
-  const int slot = slot0 + wave * 16 + pl;
-  const bool in_range = slot < n_pairs;
-  const int pair = in_range ? (order ? order[slot] : slot) : 0;
-  const bool act = in_range && !(pair_mask && !pair_mask[pair]);
-  if (in_range && !act) *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
-  // window: coarsest level, centred on the first slot's reference pixel (uniform over the workgroup)
-  constexpr int lw = L - 1;
-  const int Hc = lv.H[lw], Wc = lv.W[lw];
-  const int pair0 = order ? order[slot0] : slot0;
-  if (pair_mask && !pair_mask[pair0]) {                      // masked pairs come last: the whole workgroup is (almost always) masked
-    if (!act) return;                                        // no window for the few that are not: plain path below
-  }
-  GsampWin w;
-  w.wx = min(GSAMP_WIN, Wc);
-  w.wy = min(GSAMP_WIN, Hc);
-  w.n = pair0 / Lq;
-  {
-    const float2 rr = *reinterpret_cast<const float2*>(r + ((long)pair0 * L + lw) * 2);
-    const int px = min(max((int)floorf(index_safe(rr.x * (float)Wc - 0.5f, (float)Wc)), 0), Wc - 1);
-    const int py = min(max((int)floorf(index_safe(rr.y * (float)Hc - 0.5f, (float)Hc)), 0), Hc - 1);
-    w.x0 = min(max(px - (w.wx / 2 - 1), 0), Wc - w.wx);
-    w.y0 = min(max(py - (w.wy / 2 - 1), 0), Hc - w.wy);
-  }
-  w.base = (lds_bytes_t)winbuf;
-  const bool use_win = !(pair_mask && !pair_mask[pair0]);    // uniform
-  // staging loads first (NST x 16 B per thread, consecutive threads -> consecutive chunks of a window row)
-  static_assert(NST == 4, "four staged chunks per thread, kept in named registers (an indexed array went to scratch)");
-  uint4 stg0 = uint4{0u, 0u, 0u, 0u}, stg1 = stg0, stg2 = stg0, stg3 = stg0;
-  const int nchunk = w.wx * w.wy * 4;
-  if (use_win) {
-    const char* plane = reinterpret_cast<const char*>(vp) + (((long)w.n * 8 + m) * S + lv.start[lw]) * 64;
-#define MVG_STG(K, DST)                                                                                   \
-    {                                                                                                     \
-      const int i = min((int)threadIdx.x + K * NT, nchunk - 1);                                           \
-      const int c = i & 3, p = i >> 2;                                                                    \
-      const int y = p / w.wx, x = p - y * w.wx;                                                           \
-      DST = *reinterpret_cast<const uint4*>(plane + ((long)(w.y0 + y) * Wc + (w.x0 + x)) * 64 + c * 16);  \
-    }
-    MVG_STG(0, stg0) MVG_STG(1, stg1) MVG_STG(2, stg2) MVG_STG(3, stg3)
-#undef MVG_STG
-  } else {
-    w.wx = 0;                                                // nothing is "inside" an empty window
-    w.wy = 0;
-  }
-  float acc[8], mx = 0.f;
-  unsigned cw_t = 0, cw_b = 0, co_t = 0, co_b = 0, co_x = 0, co_f = 0;
-  float* sc = &scratch[wave][pl][0];
-  if (act) mx = gsamp_prepare<L>(G, xw, r, lv, sc, pair, m, sub, Lq, S, B);
-  if (use_win) {
-#define MVG_STW(K, SRC)                                                                                   \
-    {                                                                                                     \
-      const int i = (int)threadIdx.x + K * NT;                                                            \
-      if (i < nchunk) *reinterpret_cast<uint4*>(&winbuf[(i >> 2) * GSAMP_WIN_PITCH + (i & 3) * 16]) = SRC; \
-    }
-    MVG_STW(0, stg0) MVG_STW(1, stg1) MVG_STW(2, stg2) MVG_STW(3, stg3)
-#undef MVG_STW
-  }
-  if (act) gsamp_plain_levels<L>(vp, lv, sc, pair, m, sub, Lq, S, w, acc, mx, cw_t, cw_b, co_t, co_b, co_x, co_f);
-  if (use_win) __syncthreads();
-  if (!act) return;
-  gsamp_window_level<L>(vp, lv, sc, pair, m, sub, Lq, S, w, acc, mx, cw_t, cw_b, co_t, co_b, co_x, co_f);
-  store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
-}
-
 // PIPE = 1: the gathers double-buffered in half batches (gsamp_dev.h) -- same results bit for bit
 template <int L, int NT>
 __global__ __launch_bounds__(NT) void msda_gsamp_pipe_kernel(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
@@ -1190,12 +887,9 @@ __global__ __launch_bounds__(NT) void msda_gsamp_pipe_kernel(const bf16_t* __res
 static int g_gsamp_pipe = 0;       // tuning knob "gsamp_pipe": 1 = double-buffered gathers in half batches (round 3: 93 VGPRs = 5 waves / SIMD,
                                    // isolated launch with a warm Infinity Cache 105 -> 100 us, but 1.303 -> 1.314 ms per forward: the extra
                                    // wavefronts thrash the L1s once the planes come from HBM; pinned to 4 waves / SIMD it equals the default)
-static int g_fused_cpl_bf16 = 8;   // tuning knob (mvg_set_tuning): channels per lane of the bf16 fused kernel
 int g_auto_small = 1;              // tuning knob "auto_small": small launches pick their own workgroup / tile sizes (see mvg_msda_gsamp)
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
-static int g_gsamp_occ5 = 0;      // tuning knob "gsamp_occ5": the 5-wavefronts-per-SIMD build of the 256-thread kernel
-static int g_gfused_map = 1;       // tuning knob "gfused_map": fp32 G-sampling kernel, 0 = a wavefront takes the 8 heads of one pair, 1 = 8 neighbouring pairs of one head
 static int g_gfused_chunk = 4;     // tuning knob "gfused_chunk": hp kernel, 0 = one head per XCD (270 us at cfg-2), n > 0 = chunks of n pair blocks per XCD with their 8 heads back to back (1..4: 252 us, 16: 263)
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
@@ -1223,9 +917,6 @@ static int launch_msda_fused(const float* value, const float* oa, const float* r
 static int launch_msda_fused(const bf16_t* value, const float* oa, const float* r, const LevelTable& lv, bf16_t* samp,
                              int n_pairs, int Lq, int S, hipStream_t st) {
   if (n_pairs <= 0) return 0;
-  if (g_fused_cpl_bf16 == 4) {
-    return launch_msda_fused_cpl<bf16_t, 4, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
-  }
   return launch_msda_fused_cpl<bf16_t, 8, 4>(value, oa, r, lv, samp, n_pairs, Lq, S, st);
 }
 
@@ -1437,15 +1128,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   {                                                                                                               \
     int npb = (int)((pairs + NT / 4 - 1) / (NT / 4));                                                             \
     if (map > 0) npb = (npb + 8 * map - 1) / (8 * map) * (8 * map);                                               \
-    if (g_gsamp_occ5 && NT == 256)                                                                                \
-      hipLaunchKernelGGL((msda_gsamp_occ5_kernel<LL, 256>), dim3(8 * npb), dim3(256), 0, st, (const bf16_t*)vp,   \
-                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
-                         B, map);                                                                                 \
-    else if (g_gsamp_pipe == 2 && NT == 256)                                                                      \
-      hipLaunchKernelGGL((msda_gsamp_win_kernel<LL, 256>), dim3(8 * npb), dim3(256), 0, st, (const bf16_t*)vp,    \
-                         (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
-                         B, map);                                                                                 \
-    else if (g_gsamp_pipe == 1)                                                                                   \
+    if (g_gsamp_pipe == 1)                                                                                   \
       hipLaunchKernelGGL((msda_gsamp_pipe_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,     \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
@@ -1473,56 +1156,23 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
 extern int g_chain_rm;
 extern int g_linear_tiles;
 extern int g_f32_split;
-extern int g_f32s_grid;
-extern int g_f32s_b_rows;
-extern int g_f32s_a_rows;
-extern int g_f32h_pair;
-extern int g_f32h_a_rows;
-extern int g_f32h_b_rows;
-extern int g_f32s_pyr_ws;
-extern int g_tri_lanes;
-extern int g_linear_xcd;
-extern int g_chain_waves;
-extern int g_chain_a_waves;
-extern int g_chain_split;
-extern int g_chain_ring;
 extern int g_wreg_grid;
-extern int g_wreg_gweight;
-extern int g_auto_small_b;
-extern int g_auto_small_a;
+extern int g_f32h_rows;
 extern int g_bin_multi;
 
 int mvg_set_tuning(const char* key, int value) {
   if (!key) return MVG_E_BADARG;
-  if (!strcmp(key, "chain_a_waves") && (value == 4 || value == 8)) { g_chain_a_waves = value; return 0; }
-  if (!strcmp(key, "chain_waves") && (value == 4 || value == 8)) { g_chain_waves = value; return 0; }
-  if (!strcmp(key, "chain_split") && (value == 0 || value == 1)) { g_chain_split = value; return 0; }
-  if (!strcmp(key, "chain_ring") && (value == 4 || value == 8 || value == 16)) { g_chain_ring = value; return 0; }
   if (!strcmp(key, "linear_tiles") && value >= 0 && value <= 2) { g_linear_tiles = value; return 0; }
-  if (!strcmp(key, "linear_xcd") && (value == 0 || value == 1)) { g_linear_xcd = value; return 0; }
-  if (!strcmp(key, "tri_lanes") && (value == 0 || value == 1)) { g_tri_lanes = value; return 0; }
   if (!strcmp(key, "f32_split") && (value == 0 || value == 1)) { g_f32_split = value; return 0; }
-  if (!strcmp(key, "f32s_grid") && value >= 0 && value <= 4096) { g_f32s_grid = value; return 0; }
-  if (!strcmp(key, "f32s_pyr_ws") && (value == 0 || value == 1)) { g_f32s_pyr_ws = value; return 0; }
-  if (!strcmp(key, "f32s_a_rows") && (value == 31 || value == 32 || value == 64)) { g_f32s_a_rows = value; return 0; }
-  if (!strcmp(key, "f32h_b_rows") && (value == 0 || value == 32 || value == 64)) { g_f32h_b_rows = value; return 0; }
-  if (!strcmp(key, "f32h_a_rows") && (value == 0 || value == 32 || value == 64)) { g_f32h_a_rows = value; return 0; }
-  if (!strcmp(key, "f32h_pair") && (value == 0 || value == 1)) { g_f32h_pair = value; return 0; }
-  if (!strcmp(key, "f32s_b_rows") && (value == 0 || value == 32 || value == 64)) { g_f32s_b_rows = value; return 0; }
+  if (!strcmp(key, "f32h_rows") && (value == 0 || value == 32 || value == 64)) { g_f32h_rows = value; return 0; }
   if (!strcmp(key, "chain_rm") && (value == 64 || value == 128 || value == 256)) { g_chain_rm = value; return 0; }
-  if (!strcmp(key, "fused_cpl_bf16") && (value == 4 || value == 8)) { g_fused_cpl_bf16 = value; return 0; }
   if (!strcmp(key, "wreg_grid") && value > 0) { g_wreg_grid = value; return 0; }
-  if (!strcmp(key, "wreg_gweight") && value >= 100 && value <= 400) { g_wreg_gweight = value; return 0; }
   if (!strcmp(key, "bin_multi") && (value == 0 || value == 1)) { g_bin_multi = value; return 0; }
   if (!strcmp(key, "auto_small") && (value == 0 || value == 1)) { g_auto_small = value; return 0; }
-  if (!strcmp(key, "auto_small_b") && (value == 0 || value == 1)) { g_auto_small_b = value; return 0; }
-  if (!strcmp(key, "auto_small_a") && (value == 0 || value == 1)) { g_auto_small_a = value; return 0; }
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
-  if (!strcmp(key, "gsamp_occ5") && (value == 0 || value == 1)) { g_gsamp_occ5 = value; return 0; }
   if (!strcmp(key, "fwd_map") && (value >= 0 && value <= 2)) { g_fwd_map = value; return 0; }
   if (!strcmp(key, "gfused_chunk") && value >= 0 && value <= 4096) { g_gfused_chunk = value; return 0; }
-  if (!strcmp(key, "gfused_map") && (value == 0 || value == 1)) { g_gfused_map = value; return 0; }
-  if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
+  if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 1) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }
@@ -1538,7 +1188,7 @@ int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, con
   if (pairs > 0x7fffffffL / 4 || (long)N_img * S * 256 > 0x7fffffffL) return MVG_E_BADARG;     // int pixel offsets x C
   if (pairs == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (g_gfused_map == 1) {
+  {
     int npb = (int)((pairs + 31) / 32);
     const int mc = g_gfused_chunk;
     if (mc > 0) npb = (npb + 8 * mc - 1) / (8 * mc) * (8 * mc);
@@ -1553,16 +1203,6 @@ int mvg_msda_gfused_f32(const float* value, const float* G, const float* xw, con
     MVG_LAUNCH_CHECK();
     return 0;
   }
-  const int grid = (int)((pairs + 3) / 4);
-  switch (L) {
-    case 1: hipLaunchKernelGGL((msda_gfused_f32_kernel<1>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-    case 2: hipLaunchKernelGGL((msda_gfused_f32_kernel<2>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-    case 3: hipLaunchKernelGGL((msda_gfused_f32_kernel<3>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-    case 4: hipLaunchKernelGGL((msda_gfused_f32_kernel<4>), dim3(grid), dim3(256), 0, st, value, G, xw, ref_lvl, lv, samp, pair_mask, order, (int)pairs, Lq, S, B); break;
-    default: return MVG_E_BADARG;
-  }
-  MVG_LAUNCH_CHECK();
-  return 0;
 }
 
 int mvg_msda_fused(const void* value, int dtype, const float* oa, const float* r, const int64_t* shapes_host,

@@ -285,8 +285,8 @@ __device__ __forceinline__ void wreg2_body(const WregParams& p, char* smem, cons
 // (block b runs on XCD b & 7 -- observed dispatch order, used for speed only) are divided among the jobs in proportion to their
 // column counts; every job sweeps the XCD's row tiles (tiles t = 8 u + xcd) in the same order and at the same pace, so a tile
 // fetched by the first job's workgroup is served to the others by the XCD's L2: the pyramid crosses the fabric once per launch.
-// A workgroup keeps ONE job's weight slice in registers for its whole life exactly like wreg2_gemm_kernel -- same loop, same k
-// order, bit-identical outputs.
+// A workgroup keeps ONE job's weight slice in registers for its whole life (same loop and k order whatever the
+// job mix: a product's bytes do not depend on what it is launched with).
 constexpr int WREG_MAX_JOBS = 8;
 constexpr int WREG_MAX_SLOTS = 64;       // workgroups per XCD: 32 CUs x 2
 struct WregJob {
@@ -304,12 +304,6 @@ struct WregGroupParams {
   unsigned char job_slots[WREG_MAX_JOBS];   // slots per XCD of job j
 };
 
-// SMALL_S: images of fewer than 32 pixels (a tile may cross several image boundaries: the head-plane stores divide per lane)
-template <bool PLANES, bool SMALL_S>
-__global__ __launch_bounds__(256, 2) void wreg2_gemm_kernel(WregParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  wreg2_body<PLANES, SMALL_S>(p, smem, blockIdx.x, gridDim.x);
-}
 
 template <bool SMALL_S>
 __global__ __launch_bounds__(256, 2) void wreg2_group_kernel(WregGroupParams gp) {
@@ -330,10 +324,7 @@ int wreg2_configure() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
   if (!configured[dev]) {
-    const void* fns[] = {reinterpret_cast<const void*>(&wreg2_gemm_kernel<true, false>),
-                         reinterpret_cast<const void*>(&wreg2_gemm_kernel<true, true>),
-                         reinterpret_cast<const void*>(&wreg2_gemm_kernel<false, false>),
-                         reinterpret_cast<const void*>(&wreg2_group_kernel<false>),
+    const void* fns[] = {reinterpret_cast<const void*>(&wreg2_group_kernel<false>),
                          reinterpret_cast<const void*>(&wreg2_group_kernel<true>)};
     hipError_t e = hipSuccess;
     for (const void* f : fns)
@@ -344,38 +335,12 @@ int wreg2_configure() {
   return 0;
 }
 
-int launch_wreg(const WregParams& p, hipStream_t st) {
-  if (p.N % 64 != 0 || p.N > 256) return MVG_E_BADARG;
-  if (int e = wreg2_configure()) return e;
-  const int ntiles = (p.M + RM - 1) / RM;
-  const int grid = ntiles < g_wreg_grid ? ntiles : g_wreg_grid;      // persistent: 2 workgroups per CU
-  if (p.rowmajor) hipLaunchKernelGGL((wreg2_gemm_kernel<false, false>), dim3(grid), dim3(256), W2_LDS, st, p);
-  else if (p.S_img >= RM) hipLaunchKernelGGL((wreg2_gemm_kernel<true, false>), dim3(grid), dim3(256), W2_LDS, st, p);
-  else hipLaunchKernelGGL((wreg2_gemm_kernel<true, true>), dim3(grid), dim3(256), W2_LDS, st, p);
-  MVG_LAUNCH_CHECK();
-  return 0;
-}
 
 }  // namespace
 
-extern "C" int mvg_value_proj_planes_ws(const void* feat, const void* Wf, const float* bias, void* vp, int n_img, int S,
-                                        void* stream) {
-  if (!feat || !Wf || !bias || !vp || n_img <= 0 || S <= 0) return MVG_E_BADARG;
-  WregParams p = {};
-  p.A = (const bf16_t*)feat; p.Wf = (const bf16_t*)Wf; p.bias = bias; p.out = vp;
-  p.M = n_img * S; p.N = 256; p.S_img = S; p.rowmajor = 0;
-  return launch_wreg(p, (hipStream_t)stream);
-}
 
-extern "C" int mvg_feat_linear_ws(const void* feat, const void* Wf, void* G, int n_img, int S, int N, void* stream) {
-  if (!feat || !Wf || !G || n_img <= 0 || S <= 0 || N <= 0 || N > 256 || N % 64 != 0) return MVG_E_BADARG;
-  WregParams p = {};
-  p.A = (const bf16_t*)feat; p.Wf = (const bf16_t*)Wf; p.bias = nullptr; p.out = G;
-  p.M = n_img * S; p.N = N; p.S_img = S; p.rowmajor = 1;
-  return launch_wreg(p, (hipStream_t)stream);
-}
 
-int g_wreg_gweight = 300;   // tuning knob "wreg_gweight": share of an XCD's workgroups a 192-column job gets, x100 (a 256-column job: 400)
+static const int g_wreg_gweight = 300;   // share of an XCD's workgroups a 192-column job gets, x100 (a 256-column job: 400); 300-400 measured alike
 
 extern "C" int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njobs, const void* const* Wf, const float* const* bias,
                                     void* const* out, const int* N, const int* planes, int slots_per_xcd, void* stream) {

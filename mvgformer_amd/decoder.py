@@ -26,8 +26,6 @@ from . import ops
 from .projattn import ProjAttn, WeightCache
 
 
-# fp32 chain A on two-part fp16 operands (csrc/f32s.hip: chain_a_f32h_small_kernel); 0 = the six-product bf16 form
-F32_CHAIN_H2 = os.environ.get("MVG_F32_CHAIN_H2", "1") != "0"
 
 class MLP(nn.Module):
     """multi_view_pose_transformer.py:81-102"""
@@ -111,58 +109,6 @@ class DecoderContext:
                            src_views[0].device).pack(src_views)
 
 
-class PyramidPipeline:
-    """View-group schedule of the query-independent GEMMs for pyramids that do not fit the 256-MB Infinity Cache (cfg-5: 31 views,
-    value planes + G of one layer = 1.1 GB).  The plain schedule issues every layer's products up front on the side stream; by the
-    time a layer's sampler gathers from them they come from HBM (the same launch measured 109 us warm against 143 us cold at
-    cfg-2).  Here the images are cut into groups of `group` views; item k = (layer, group) of the sequence is produced on the
-    side stream `depth` items ahead of the sampler launch that consumes it -- its production is issued when item k - depth has
-    been consumed (an event recorded on the main stream) -- so a sampler launch finds its planes written a group ago.
-    Everything is fork / join of two streams: capturable as one HIP graph."""
-
-    def __init__(self, layers, feat, n_img, group, depth, side):
-        self.layers, self.feat, self.side, self.depth = list(layers), feat, side, depth
-        self.bounds = [(i, min(i + group, n_img)) for i in range(0, n_img, group)]
-        self.n_groups = len(self.bounds)
-        self.items = [(l, g) for l in range(len(self.layers)) for g in range(self.n_groups)]
-        self.ready = {}
-        self.next_item = 0
-        self.index = {id(layer.proj_attn): l for l, layer in enumerate(self.layers)}
-        for layer in self.layers:
-            layer.proj_attn._pipeline = self
-        feat.record_stream(side)
-        for _ in range(min(depth, len(self.items))):
-            self._produce(None)
-
-    def _produce(self, after):
-        if self.next_item >= len(self.items):
-            return
-        l, g = self.items[self.next_item]
-        self.next_item += 1
-        if after is not None:
-            self.side.wait_event(after)
-        with torch.cuda.stream(self.side):
-            i0, i1 = self.bounds[g]
-            self.layers[l].proj_attn.project_pyramid_group(self.feat, i0, i1)
-            ev = torch.cuda.Event()
-            ev.record()
-        self.ready[(l, g)] = ev
-
-    def wait_ready(self, proj_attn, g):
-        torch.cuda.current_stream().wait_event(self.ready[(self.index[id(proj_attn)], g)])
-        return self.bounds[g]
-
-    def consumed(self, proj_attn, g):
-        ev = torch.cuda.Event()
-        ev.record()
-        self._produce(ev)
-
-    def close(self):
-        for layer in self.layers:
-            layer.proj_attn._pipeline = None
-        torch.cuda.current_stream().wait_stream(self.side)
-
-
 class MvPDecoderLayer(nn.Module):
     """helpers shared with the MvP base class (mvp_decoder.py:49-105)."""
 
@@ -233,7 +179,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self.use_fused_chains_f32 = os.environ.get("MVG_F32_FUSED", "1") != "0"
         self.fuse_boundary = True       # the triangulation launch also projects the new points for the next layer
         # fp32 path: output projection + pose MLP skip the tiles whose pairs are all outside their image (round 3)
-        self.skip_masked_f32 = os.environ.get("MVG_SKIP_MASKED_F32", "1") != "0"
+        self.skip_masked_f32 = True
         self._wc = WeightCache()
         self._ctx = None   # set by DQDecoder.forward so the pyramid / cameras are packed once
         self._tgt_out = None   # set by DQDecoder.forward: this layer's slice of the stacked hidden states
@@ -331,20 +277,6 @@ class DQDecoderLayer(MvPDecoderLayer):
                 self._w("b3", (self.norm3.bias,), f32) if ffn else None,
                 self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
 
-    def _chain_a_weights_f32s(self):
-        f32, bf = torch.float32, torch.bfloat16
-        pose_layers = self.pose_embed.MLP.layers
-        sp = ops.split_swizzle_weight
-        wts = (self._w("Wp_f32s", (self.proj_attn.output_proj.weight,), bf, sp), self._w("bp", (self.proj_attn.output_proj.bias,), f32),
-               self._w("Wpe0_f32s", (pose_layers[0].weight,), bf, sp), self._w("bpe0", (pose_layers[0].bias,), f32),
-               self._w("Wpe1_f32s", (pose_layers[1].weight,), bf, sp), self._w("bpe1", (pose_layers[1].bias,), f32),
-               self._w("Wpe_last", (pose_layers[2].weight,), f32), self._w("bpe_last", (pose_layers[2].bias,), f32))
-        pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias))
-        from . import _lib      # (the tile variants sum the last pose layer in different orders: the constant comes from the active one)
-        o_masked = self._w("o_masked_f32s/a_rows=%d" % _lib.TUNING.get("f32s_a_rows", 32), pose_params, f32,
-                           lambda *_: ops.chain_masked_row_output_f32s(*wts))
-        return wts, o_masked
-
     def _chain_a_weights_f32h(self):
         """operands of ops.chain_attn_pose_f32h (two-part fp16 planes + their scales) and the masked-row constant of that kernel"""
         f32, f16 = torch.float32, torch.float16
@@ -359,20 +291,6 @@ class DQDecoderLayer(MvPDecoderLayer):
         pose_params = tuple(p for lin in pose_layers for p in (lin.weight, lin.bias)) + (self.proj_attn.output_proj.bias,)
         o_masked = self._w("o_masked_f32h", pose_params, f32, lambda *_: ops.chain_masked_row_output_f32h(*wts))
         return wts, o_masked
-
-    def _chain_b_weights_f32s(self):
-        f32, bf = torch.float32, torch.bfloat16
-        sp = ops.split_swizzle_weight
-        ffn = self.open_forward_ffn
-        return (self._w("Wu_f32s", (self.feature_update_mlp.weight,), bf, sp), self._w("bu", (self.feature_update_mlp.bias,), f32),
-                self._w("g2", (self.norm2.weight,), f32), self._w("b2", (self.norm2.bias,), f32),
-                self._w("W1_f32s", (self.linear1.weight,), bf, sp) if ffn else None,
-                self._w("b1", (self.linear1.bias,), f32) if ffn else None,
-                self._w("W2_f32s", (self.linear2.weight,), bf, sp) if ffn else None,
-                self._w("bb2", (self.linear2.bias,), f32) if ffn else None,
-                self._w("g3", (self.norm3.weight,), f32) if ffn else None,
-                self._w("b3", (self.norm3.bias,), f32) if ffn else None,
-                self._w("Wc", (self.class_embed.weight,), f32), self._w("bc", (self.class_embed.bias,), f32))
 
     def _chain_b_weights_f32h(self):
         """operands of ops.chain_update_ffn_class_f32h, in its argument order"""
@@ -430,26 +348,19 @@ class DQDecoderLayer(MvPDecoderLayer):
                     self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192:
                 self.proj_attn._fast_query_weights(dt)      # the fp32 G-sampling branch of native_sample (Woa_perm / boa_perm)
                 if self.proj_attn.f32_fused_active() and self.proj_attn.rayconv.weight.shape == (256, 256):
-                    self.proj_attn.query_term_weights_f32s()
-                    from . import projattn as _pa
-                    if _pa.F32_H2:
-                        self.proj_attn.pyramid_planes_f32h()
+                    self.proj_attn.query_term_weights_f32h()
+                    self.proj_attn.pyramid_planes_f32h()
             fa32, fb32 = self._fuses_chains_f32(dt)
             if fa32:
-                self._chain_a_weights_f32h() if F32_CHAIN_H2 else self._chain_a_weights_f32s()
+                self._chain_a_weights_f32h()
             if fb32:
                 # (the query-term operand indexes rows 0..191 of [offsets; logits]: only with the G form's geometry, like every
                 # other operand of that form)
                 g_geometry = (self.proj_attn.sampling_offsets.out_features + self.proj_attn.attention_weights.out_features == 192
                               and self.proj_attn.rayconv.weight.shape == (256, 256))
-                if F32_CHAIN_H2:
-                    self._chain_b_weights_f32h()
-                    if g_geometry:
-                        self.proj_attn.query_term_weights_f32h()
-                else:
-                    self._chain_b_weights_f32s()
-                    if g_geometry:
-                        self.proj_attn.query_term_weights_f32s()
+                self._chain_b_weights_f32h()
+                if g_geometry:
+                    self.proj_attn.query_term_weights_f32h()
         fuse_a, fuse_b = self._fuses_chains(dt)
         if fuse_a:
             self._chain_a_weights(dt)
@@ -600,7 +511,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         else:
             r, ref_lvl, inside = ops.project(X, ctx.cams, ctx.levels, V, B)
         x = lambda: self.with_pos_embed(tgt.float(), None if query_pos is None else query_pos.float()).contiguous()
-        if (os.environ.get("MVG_LINEAR_SUM", "1") != "0" and query_pos is not None and tgt.dtype == torch.float32 and query_pos.dtype == torch.float32 and tgt.is_contiguous()
+        if (query_pos is not None and tgt.dtype == torch.float32 and query_pos.dtype == torch.float32 and tgt.is_contiguous()
                 and query_pos.is_contiguous() and query_pos.shape == tgt.shape):
             x.parts = (tgt, query_pos)          # lets the fast path fold the add into the query-term GEMM
         xw_in, self._xw_in = self._xw_in, None     # query term computed by the previous layer's chain B (or None)
@@ -632,12 +543,8 @@ class DQDecoderLayer(MvPDecoderLayer):
             order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels) if (self.proj_attn.sort_pairs and Lq <= 65536) else None
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1), order=order,
                                                 xw=xw_in)
-            if F32_CHAIN_H2:
-                wts, o_masked = self._chain_a_weights_f32h()
-                attn, o = ops.chain_attn_pose_f32h(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
-            else:
-                wts, o_masked = self._chain_a_weights_f32s()
-                attn, o = ops.chain_attn_pose_f32s(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+            wts, o_masked = self._chain_a_weights_f32h()
+            attn, o = ops.chain_attn_pose_f32h(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         else:
             # fp32 (reference arithmetic): the per-view output projection and pose MLP run over the pairs in processing order and
             # skip the tiles whose pairs are all outside their image (their rows are zero / a cached constant either way).
@@ -667,20 +574,11 @@ class DQDecoderLayer(MvPDecoderLayer):
             if (nxt is not None and nxt.compute_dtype == dt and nxt._fuses_chains_f32(dt, Lq, ctx.levels)[0]
                     and (query_pos is None or query_pos.shape == tgt.shape)):
                 qp = None if query_pos is None else query_pos.float().reshape(B * Lq, C).contiguous()
-                if F32_CHAIN_H2:
-                    (Wn, sn), bn, n_next = nxt.proj_attn.query_term_weights_f32h()
-                    next_proj = (qp, Wn, sn, bn, n_next)
-                else:
-                    Wn, bn, n_next = nxt.proj_attn.query_term_weights_f32s()
-                    next_proj = (qp, Wn, bn, n_next)
-            if F32_CHAIN_H2:
-                res = ops.chain_update_ffn_class_f32h(
-                    attn, V, tgt32, *self._chain_b_weights_f32h(), threshold, B, NQ, J, forced, self.open_forward_ffn,
-                    tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
-            else:
-                res = ops.chain_update_ffn_class_f32s(
-                    attn, V, tgt32, *self._chain_b_weights_f32s(), threshold, B, NQ, J, forced, self.open_forward_ffn,
-                    tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
+                (Wn, sn), bn, n_next = nxt.proj_attn.query_term_weights_f32h()
+                next_proj = (qp, Wn, sn, bn, n_next)
+            res = ops.chain_update_ffn_class_f32h(
+                attn, V, tgt32, *self._chain_b_weights_f32h(), threshold, B, NQ, J, forced, self.open_forward_ffn,
+                tgt_out=self._tgt_out, any_valid=self._flag, next_query_proj=next_proj)
             tgt_update, prob, valid, any_valid = res[:4]
             if next_proj is not None:
                 nxt._xw_in = res[4]
@@ -790,9 +688,6 @@ class DQDecoder(MvPDecoder):
         self._side_stream = None
         # layer l's fused chain B also computes layer l+1's query term xw = (tgt' + query_pos) W^T + b (bf16 path)
         self.fuse_next_query_term = True
-        # view groups (PyramidPipeline): MVG_VIEW_GROUP = views per group (0 = off, the default: measured SLOWER at cfg-5, 15.7 ->
-        # 16.3-17.7 ms, with the sampler's FETCH_SIZE unchanged -- profiles/r04_experiments.txt; "auto" = 3 views once one layer's
-        # value planes + G exceed the Infinity Cache), MVG_VIEW_GROUP_DEPTH = groups produced ahead of the sampler
         # bf16: layers per grouped launch of the pyramid products behind layer 0's own (0 = one launch per product, rounds 1-4)
         self.pyramid_group = int(os.environ.get("MVG_PYRAMID_GROUP", "3"))
         # pack the pyramid on the side stream in front of its consumers: the first layer's query-side prologue (projection, pair
@@ -801,8 +696,6 @@ class DQDecoder(MvPDecoder):
         pool = {}
         for layer in self.layers:       # the inline fp32 pyramid products share one (value, G) pair per stream -- of THIS decoder
             layer.proj_attn._f32_pool = pool
-        self.view_group = os.environ.get("MVG_VIEW_GROUP", "0")
-        self.view_group_depth = int(os.environ.get("MVG_VIEW_GROUP_DEPTH", "2"))
 
     def set_compute_dtype(self, dtype):
         for layer in self.layers:
@@ -831,19 +724,6 @@ class DQDecoder(MvPDecoder):
                 l.prepare_caches()
         self._side_stream.wait_stream(torch.cuda.current_stream())
         return self._side_stream
-
-    def _view_group_size(self, ctx):
-        """views per group of the PyramidPipeline, or 0 for the plain schedule (bf16 fast path with the pairs binned per layer only)"""
-        l0 = self.layers[0]
-        if not (l0.compute_dtype == torch.bfloat16 and all(l.proj_attn.sort_pairs not in (False, "first") for l in self.layers)):
-            return 0
-        if ctx.feat.shape[1] * l0.num_joints == 0 or ctx.feat.shape[0] // max(ctx.B, 1) < 2:
-            return 0
-        if self.view_group == "auto":
-            per_layer = ctx.feat.shape[0] * ctx.levels.S * (512 + 384)          # bytes of one layer's value planes + G
-            return 3 if per_layer > (256 << 20) and ctx.V >= 6 else 0
-        g = int(self.view_group)
-        return g if 0 < g < ctx.V else 0
 
     def launch_pyramid_projections(self, ctx, side=None, forked=False):
         """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
@@ -934,7 +814,7 @@ class DQDecoder(MvPDecoder):
         output = tgt
         layer0 = self.layers[0]
         ctx = context
-        side = pipeline = None
+        side = None
         hs_buf = flags = geo_buf = None
         try:
             deferred_pack = None
@@ -954,13 +834,8 @@ class DQDecoder(MvPDecoder):
             side = self.fork_side_stream(tgt.device, (tgt.shape[1], ctx.levels.L, ctx.levels.S))
             if deferred_pack is not None:
                 self.pack_pyramid(ctx, deferred_pack, side)
-            pipeline = None
             if side is not None:
-                group = self._view_group_size(ctx)
-                if group:
-                    pipeline = PyramidPipeline(self.layers, ctx.feat, ctx.feat.shape[0], group * ctx.B, self.view_group_depth, side)
-                else:
-                    self.launch_pyramid_projections(ctx, side, forked=True)
+                self.launch_pyramid_projections(ctx, side, forked=True)
             # the fused chain writes every layer's hidden state straight into its slice of the stacked output
             hs_buf = None
             if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
@@ -1000,9 +875,6 @@ class DQDecoder(MvPDecoder):
                 layer._next_layer = None
                 layer._xw_in = None
                 layer._proj_in = None
-            if pipeline is not None:
-                pipeline.close()
-                side = None
             self.join_pyramid_projections(side)
         if self.return_intermediate:
             in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape

@@ -18,7 +18,6 @@ from . import _lib as L
 # fp32-atomics form of round 1 (the reference's own scheme)
 BACKWARD_MODE = __import__("os").environ.get("MVG_BACKWARD", "det")
 
-ONE_LAUNCH_PACK = __import__("os").environ.get("MVG_ONE_LAUNCH_PACK", "1") != "0"
 
 # ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) -----
 PROFILE = None   # None (off) or dict name -> list[(start_event, end_event)]
@@ -198,7 +197,7 @@ def pack_pyramid(src_views, levels, dtype, out=None):
     dst_views = pyramid_level_views(feat, levels)
     if len(src_views) != levels.L:
         raise RuntimeError("pack_pyramid: %d feature maps for %d levels" % (len(src_views), levels.L))
-    if (ONE_LAUNCH_PACK and all(s.dtype == torch.float32 and s.is_contiguous() and s.is_cuda and tuple(s.shape) ==
+    if (all(s.dtype == torch.float32 and s.is_contiguous() and s.is_cuda and tuple(s.shape) ==
                                 (n_img, Cc, int(levels.shapes[l, 0]), int(levels.shapes[l, 1])) and s.data_ptr() != dst_views[l].data_ptr()
                                 for l, s in enumerate(src_views))):
         # the reference's hand-over format on every level: one launch for the whole pyramid
@@ -220,9 +219,10 @@ def pack_pyramid(src_views, levels, dtype, out=None):
                 dst.copy_(src)
             continue
         s = src.float().contiguous()
-        with _timed("pack_level"):
-          L.check(lib.mvg_pack_level(L.ptr(s), L.ptr(feat), L.dtype_code(dtype), n_img, Cc, H, W, levels.S,
-                                     int(levels.starts[l]), L.stream_ptr()), "mvg_pack_level")
+        one = (C.c_void_p * 1)(s.data_ptr())
+        with _timed("pack_level"):      # the same kernel on this level alone
+          L.check(lib.mvg_pack_pyramid(one, L.ptr(feat), L.dtype_code(dtype), n_img, Cc, (C.c_int64 * 2)(H, W),
+                                       (C.c_int64 * 1)(int(levels.starts[l])), 1, levels.S, L.stream_ptr()), "mvg_pack_pyramid")
     return feat
 
 
@@ -268,44 +268,9 @@ def linear(a, w, bias, out_dtype=None, relu=False, rowmask=None, out=None, add=N
     return out
 
 
-def linear_splitk(a, w, splits=None):
-    """a (M, K) @ w (N, K)^T in fp32 with the reduction cut into `splits` slices (mvg_linear_splitk_f32) -> (M, N): the weight
-    gradient of a Linear, dW = dY^T X, whose K is the row count.  The partials are summed here in slice order."""
-    M, K = a.shape
-    N = w.shape[0]
-    if a.dtype != torch.float32 or w.dtype != torch.float32 or a.stride(1) != 1 or w.stride(1) != 1 or w.shape[1] != K:
-        raise RuntimeError("mvg_linear_splitk: fp32 K-contiguous operands with equal K required")
-    if splits is None:      # enough slices to fill the chip with 128 x 128 tiles, slices of whole 32-element slabs
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        splits = max(1, min(K // 32, (512 + tiles - 1) // tiles))
-        while K % (splits * 32) != 0 and splits > 1:
-            splits -= 1
-    if K % (splits * 32) != 0:
-        raise RuntimeError("mvg_linear_splitk: K = %d is not %d slices of whole 32-element slabs" % (K, splits))
-    partial = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
-    with _timed("linear_splitk_%dx%dx%d" % (M, N, K)):
-      L.check(L.load().mvg_linear_splitk_f32(L.ptr(a), a.stride(0), L.ptr(w), w.stride(0), L.ptr(partial), M, N, K, splits,
-                                             L.stream_ptr()), "mvg_linear_splitk_f32")
-    return partial.sum(0) if splits > 1 else partial[0]
-
-
 def linear_wgrad(dy, x, splits=None):
-    """dW (N, K) = dy^T x for dy (rows, N), x (rows, K) fp32 row-major (mvg_linear_wgrad_f32): the weight gradient of a Linear,
-    straight from the tensors autograd holds.  The per-slice partials are summed here in slice order."""
-    rows, N = dy.shape
-    K = x.shape[1]
-    if (dy.dtype != torch.float32 or x.dtype != torch.float32 or dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != rows
-            or N % 4 or K % 4):
-        raise RuntimeError("mvg_linear_wgrad: fp32 row-major (rows, N) / (rows, K) operands with N, K multiples of 4 required")
-    if splits is None:
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        # ~512 workgroups (two per CU), at most 128 slices, at least 256 rows per slice (tools/bench_wgrad.py)
-        splits = max(1, min((rows + 255) // 256, 128, (512 + tiles - 1) // tiles))
-    partial = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
-    with _timed("linear_wgrad_%dx%dx%d" % (N, K, rows)):
-      L.check(L.load().mvg_linear_wgrad_f32(L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(partial), rows, N, K, splits,
-                                            L.stream_ptr()), "mvg_linear_wgrad_f32")
-    return partial.sum(0) if splits > 1 else partial[0]
+    """dW (N, K) = dy^T x for dy (rows, N), x (rows, K) fp32 row-major: linear_wgrad_bias without the bias gradient"""
+    return linear_wgrad_bias(dy, x, want_bias=False, splits=splits)[0]
 
 
 def linear_wgrad_bias(dy, x, want_bias=True, splits=None):
@@ -393,26 +358,24 @@ def msda_gfused_f32(value, G, xw, r, levels, B, pair_mask=None, order=None):
 
 
 def value_proj_planes_ws(feat, w_frag, bias, vp):
-    """weight-stationary value projection (bf16 feat, swizzled weight) into head planes vh[img][head][s][32]."""
-    n_img, S, K = feat.shape
-    with _timed("value_proj_ws"):
-      L.check(L.load().mvg_value_proj_planes_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(bias), L.ptr(vp), n_img, S, L.stream_ptr()),
-              "mvg_value_proj_planes_ws")
+    """weight-stationary value projection (bf16 feat, swizzled weight) into head planes vh[img][head][s][32]: a one-product launch
+    of mvg_pyramid_group_ws."""
+    pyramid_group_ws(feat, [(w_frag, bias, vp, True)], label="value_proj_ws")
     return vp
 
 
 def feat_linear_ws(feat, w_frag, N=192, out=None):
-    """G = feat @ W^T, row-major bf16 (n_img*S, N) (weight-stationary kernel, no bias)."""
+    """G = feat @ W^T, row-major bf16 (n_img*S, 192) (weight-stationary kernel, no bias): a one-product launch of
+    mvg_pyramid_group_ws."""
     n_img, S, _ = feat.shape
+    if N != 192:
+        raise RuntimeError("feat_linear_ws: 192 columns (the [offsets | logits] Linear of the G-sampling form)")
     G = out if out is not None else torch.empty((n_img * S, N), dtype=torch.bfloat16, device=feat.device)
-    assert G.dtype == torch.bfloat16 and G.is_contiguous() and tuple(G.shape) == (n_img * S, N)
-    with _timed("feat_linear_ws"):
-      L.check(L.load().mvg_feat_linear_ws(L.ptr(feat), L.ptr(w_frag), L.ptr(G), n_img, S, N, L.stream_ptr()),
-              "mvg_feat_linear_ws")
+    pyramid_group_ws(feat, [(w_frag, None, G, False)], label="feat_linear_ws")
     return G
 
 
-def pyramid_group_ws(feat, jobs, slots=0):
+def pyramid_group_ws(feat, jobs, slots=0, label=None):
     """Several weight-stationary products of the same packed bf16 pyramid in one launch (mvg_pyramid_group_ws): jobs = list of
     (w_frag, bias or None, out, planes) -- planes: value projection into head planes (out = vh (n_img, 8, S, 32)), else
     G = feat @ W^T row-major (out (n_img*S, 192)).  Outputs bit-identical to value_proj_planes_ws / feat_linear_ws.
@@ -429,7 +392,7 @@ def pyramid_group_ws(feat, jobs, slots=0):
     outs = vpp(*[o.data_ptr() for _, _, o, _ in jobs])
     Ns = (C.c_int * n)(*[256 if p else 192 for _, _, _, p in jobs])
     planes = (C.c_int * n)(*[1 if p else 0 for _, _, _, p in jobs])
-    with _timed("pyramid_group_ws_%d" % n):
+    with _timed(label or "pyramid_group_ws_%d" % n):
       L.check(L.load().mvg_pyramid_group_ws(L.ptr(feat), n_img, S, n, Wf, bias, outs, Ns, planes, int(slots), L.stream_ptr()),
               "mvg_pyramid_group_ws")
 
@@ -443,13 +406,10 @@ def gsamp_column_order(device=None):
     return torch.where(w < 16, 16 * g + w, 128 + 8 * g + (w - 16))
 
 
-def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None, out=None, images=None):
+def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None, out=None):
     """fused sampling with in-kernel gather of the offsets/logits from G (see include/mvg_decoder.h); the 192
     columns of G and xw are in gsamp_column_order().
-    pair_mask (n_img*Lq) u8: rows with 0 are zero-filled, not sampled; order (n_img*Lq) i32 from bin_pairs.
-    images = (i0, i1): only the pairs of images i0 .. i1-1 (their slots of `order` -- mvg_bin_pairs sorts per image, so they are
-    the contiguous range [i0 * Lq, i1 * Lq) -- into their rows of `out`): the per-view-group launches of a pyramid that is
-    sampled while it is being produced (DQDecoder: view groups)."""
+    pair_mask (n_img*Lq) u8: rows with 0 are zero-filled, not sampled; order (n_img*Lq) i32 from bin_pairs."""
     n_img = vp.shape[0]
     Lq = r.shape[1]
     samp = out if out is not None else torch.empty((n_img * Lq, 256), dtype=torch.bfloat16, device=vp.device)
@@ -458,16 +418,10 @@ def msda_gsamp(vp, G, xw, r, levels, B, pair_mask=None, order=None, out=None, im
         assert pair_mask.dtype == torch.uint8 and pair_mask.numel() == n_img * Lq and pair_mask.is_contiguous()
     if order is not None:
         assert order.dtype == torch.int32 and order.numel() == n_img * Lq and order.is_contiguous()
-    n_launch, order_arg = n_img, order
-    if images is not None:
-        i0, i1 = images
-        if order is None or not (0 <= i0 < i1 <= n_img):
-            raise RuntimeError("msda_gsamp: an image range needs the processing order of mvg_bin_pairs")
-        n_launch, order_arg = i1 - i0, order[i0 * Lq:i1 * Lq]
     with _timed("msda_gsamp"):
       L.check(L.load().mvg_msda_gsamp(L.ptr(vp), L.ptr(G), L.ptr(xw), L.ptr(r), levels.shapes_c, levels.starts_c,
                                       L.ptr(samp), None if pair_mask is None else L.ptr(pair_mask),
-                                      None if order_arg is None else L.ptr(order_arg), n_launch, Lq, levels.L, levels.S, B,
+                                      None if order is None else L.ptr(order), n_img, Lq, levels.L, levels.S, B,
                                       L.stream_ptr()), "mvg_msda_gsamp")
     return samp
 
@@ -515,22 +469,6 @@ def swizzle_weight(w):
     return t.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)
 
 
-def split_swizzle_weight(w, pad_rows_to=256):
-    """fp32 nn.Linear weight (N, K) -> the operand of the f32s kernels (csrc/f32s.hip): its three bf16 parts h = bf16(w),
-    m = bf16(w - h), l = bf16(w - h - m) (round to nearest even at each step, as the kernels split the activations), each
-    in swizzle_weight order, concatenated (part p at element offset p * Np * K; N zero-padded to a multiple of 256)."""
-    w = w.detach().float()
-    N, K = w.shape
-    Np = (N + pad_rows_to - 1) // pad_rows_to * pad_rows_to
-    if Np != N:
-        w = torch.cat([w, w.new_zeros(Np - N, K)], 0)
-    h = w.to(torch.bfloat16)
-    r1 = w - h.float()
-    m = r1.to(torch.bfloat16)
-    l = (r1 - m.float()).to(torch.bfloat16)
-    return torch.cat([swizzle_weight(p) for p in (h, m, l)])
-
-
 def split_swizzle_weight_h2(w, pad_rows_to=256):
     """fp32 nn.Linear weight (N, K) -> the operand of the two-part fp16 kernels (csrc/f32s.hip, "f32h"): (planes, s) with
     w 2^s = h + l, h = fp16(w 2^s), l = fp16(w 2^s - h), s chosen so that max |w| 2^s lies in [2^13, 2^14); each plane in swizzle_weight
@@ -549,7 +487,9 @@ def split_swizzle_weight_h2(w, pad_rows_to=256):
 
 
 def pyramid_f32h(feat, Wv_planes, wv_scale, bv, Wg_planes, wg_scale, n_g, value=None, G=None):
-    """pyramid_f32s on two-part fp16 operands (include/mvg_decoder.h: mvg_pyramid_f32h); weights from split_swizzle_weight_h2."""
+    """value = feat Wv^T + bv (n_img, S, 256) and G = feat Wg^T (n_img*S, n_g), fp32, in one pass over the channels-last fp32
+    pyramid feat (n_img, S, 256) on two-part fp16 operands (include/mvg_decoder.h: mvg_pyramid_f32h); weights from
+    split_swizzle_weight_h2."""
     n_img, S, Cc = feat.shape
     if feat.dtype != torch.float32 or Cc != 256 or not feat.is_contiguous():
         raise RuntimeError("mvg_pyramid_f32h: contiguous fp32 (n_img, S, 256) pyramid required")
@@ -563,55 +503,10 @@ def pyramid_f32h(feat, Wv_planes, wv_scale, bv, Wg_planes, wg_scale, n_g, value=
         G = torch.empty((rows, n_g), dtype=torch.float32, device=feat.device)
     assert value.dtype == torch.float32 and value.numel() == rows * 256 and value.is_contiguous()
     assert G.dtype == torch.float32 and tuple(G.shape) == (rows, n_g) and G.is_contiguous()
-    with _timed("pyramid_f32s"):
+    with _timed("pyramid_f32h"):
       L.check(L.load().mvg_pyramid_f32h(L.ptr(feat), L.ptr(Wv_planes), int(wv_scale), L.ptr(bv), L.ptr(Wg_planes), int(wg_scale),
                                         L.ptr(value), L.ptr(G), rows, n_g, L.stream_ptr()), "mvg_pyramid_f32h")
     return value, G
-
-
-def pyramid_f32s(feat, Wv_planes, bv, Wg_planes, n_g, value=None, G=None):
-    """value (n_img, S, 256) f32 = feat @ Wv^T + bv and G (n_img * S, n_g) f32 = feat @ Wg^T in one pass over the packed fp32
-    pyramid feat (n_img, S, 256) (include/mvg_decoder.h: mvg_pyramid_f32s)."""
-    n_img, S, Cc = feat.shape
-    if feat.dtype != torch.float32 or Cc != 256 or not feat.is_contiguous():
-        raise RuntimeError("mvg_pyramid_f32s: contiguous fp32 (n_img, S, 256) pyramid required")
-    rows = n_img * S
-    for t, n in ((Wv_planes, 3 * 256 * 256), (Wg_planes, 3 * 256 * 256)):
-        if t.dtype != torch.bfloat16 or t.numel() != n or not t.is_contiguous():
-            raise RuntimeError("mvg_pyramid_f32s: weight planes from split_swizzle_weight required")
-    if value is None:
-        value = torch.empty((n_img, S, 256), dtype=torch.float32, device=feat.device)
-    if G is None:
-        G = torch.empty((rows, n_g), dtype=torch.float32, device=feat.device)
-    assert value.dtype == torch.float32 and value.numel() == rows * 256 and value.is_contiguous()
-    assert G.dtype == torch.float32 and tuple(G.shape) == (rows, n_g) and G.is_contiguous()
-    with _timed("pyramid_f32s"):
-      L.check(L.load().mvg_pyramid_f32s(L.ptr(feat), L.ptr(Wv_planes), L.ptr(bv), L.ptr(Wg_planes), L.ptr(value), L.ptr(G),
-                                        rows, n_g, L.stream_ptr()), "mvg_pyramid_f32s")
-    return value, G
-
-
-def chain_attn_pose_f32s(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
-    """fp32 chain A (include/mvg_decoder.h: mvg_chain_attn_pose_f32s): samp (rows, 256) f32 -> (attn f32 (rows, 256),
-    o f32 (rows, 3)); Wp / W0 / W1 from split_swizzle_weight."""
-    rows = samp.shape[0]
-    if samp.dtype != torch.float32 or samp.shape[1] != 256 or not samp.is_contiguous():
-        raise RuntimeError("mvg_chain_attn_pose_f32s: contiguous fp32 (rows, 256) samples required")
-    for t in (Wp, W0, W1):
-        if t.dtype != torch.bfloat16 or t.numel() != 3 * 256 * 256 or not t.is_contiguous():
-            raise RuntimeError("mvg_chain_attn_pose_f32s: weight planes from split_swizzle_weight required")
-    assert inside.dtype == torch.uint8 and inside.numel() == rows and inside.is_contiguous()
-    if order is not None:
-        assert order.dtype == torch.int32 and order.numel() == rows and order.is_contiguous()
-    attn = torch.empty((rows, 256), dtype=torch.float32, device=samp.device)
-    o = torch.empty((rows, 3), dtype=torch.float32, device=samp.device)
-    with _timed("chain_attn_pose_f32s"):
-      L.check(L.load().mvg_chain_attn_pose_f32s(L.ptr(samp), L.ptr(inside), L.ptr(Wp), L.ptr(bp), L.ptr(W0), L.ptr(b0),
-                                                L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
-                                                None if order is None else L.ptr(order),
-                                                None if o_masked is None else L.ptr(o_masked), rows, L.stream_ptr()),
-              "mvg_chain_attn_pose_f32s")
-    return attn, o
 
 
 def chain_attn_pose_f32h(samp, inside, Wp, swp, bp, W0, sw0, b0, W1, sw1, b1, W2, b2, order=None, o_masked=None):
@@ -631,7 +526,7 @@ def chain_attn_pose_f32h(samp, inside, Wp, swp, bp, W0, sw0, b0, W1, sw1, b1, W2
         assert order.dtype == torch.int32 and order.numel() == rows and order.is_contiguous()
     attn = torch.empty((rows, 256), dtype=torch.float32, device=samp.device)
     o = torch.empty((rows, 3), dtype=torch.float32, device=samp.device)
-    with _timed("chain_attn_pose_f32s"):
+    with _timed("chain_attn_pose_f32h"):
       L.check(L.load().mvg_chain_attn_pose_f32h(L.ptr(samp), L.ptr(inside), L.ptr(Wp), int(swp), L.ptr(bp), L.ptr(W0), int(sw0), L.ptr(b0),
                                                 L.ptr(W1), int(sw1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
                                                 None if order is None else L.ptr(order),
@@ -654,64 +549,10 @@ def chain_masked_row_output_f32h(Wp, swp, bp, W0, sw0, b0, W1, sw1, b1, W2, b2):
     return o.reshape(3)
 
 
-def chain_masked_row_output_f32s(Wp, bp, W0, b0, W1, b1, W2, b2):
-    """o (3,) f32 of a row with inside == 0 as the fp32 chain A computes it (the chain run on one masked row)."""
-    dev = Wp.device
-    samp = torch.zeros((1, 256), dtype=torch.float32, device=dev)
-    inside = torch.zeros((1,), dtype=torch.uint8, device=dev)
-    global PROFILE
-    saved, PROFILE = PROFILE, None
-    try:
-        _, o = chain_attn_pose_f32s(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2)
-    finally:
-        PROFILE = saved
-    return o.reshape(3)
-
-
-def chain_update_ffn_class_f32s(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
-                                forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None):
-    """fp32 chain B (include/mvg_decoder.h: mvg_chain_update_ffn_class_f32s); arguments and results as chain_update_ffn_class,
-    attn (V * rows, 256) f32, weights from split_swizzle_weight."""
-    dev = attn.device
-    rows = B * NQ * J
-    if attn.dtype != torch.float32 or attn.numel() != V * rows * 256 or not attn.is_contiguous():
-        raise RuntimeError("mvg_chain_update_ffn_class_f32s: contiguous fp32 (V * rows, 256) attn required")
-    assert tgt.dtype == torch.float32 and tgt.numel() == rows * 256 and tgt.is_contiguous()
-    assert Wu.dtype == torch.bfloat16 and Wu.numel() == 3 * 256 * 256
-    if has_ffn:
-        assert W1.dtype == torch.bfloat16 and W1.numel() == 3 * 1024 * 256 and W2.dtype == torch.bfloat16 and W2.numel() == 3 * 256 * 1024
-    if tgt_out is None:
-        tgt_out = torch.empty((rows, 256), dtype=torch.float32, device=dev)
-    else:
-        assert tgt_out.dtype == torch.float32 and tgt_out.numel() == rows * 256 and tgt_out.is_contiguous()
-        tgt_out = tgt_out.view(rows, 256)
-    prob = torch.empty((B, NQ, 2), dtype=torch.float32, device=dev)
-    valid = torch.empty((B, NQ), dtype=torch.uint8, device=dev)
-    qpos = Wn = bn = xw_next = None
-    n_next = 0
-    if next_query_proj is not None:
-        qpos, Wn, bn, n_next = next_query_proj
-        assert Wn.dtype == torch.bfloat16 and Wn.numel() == 3 * 256 * 256 and bn.numel() == 256 and bn.dtype == torch.float32
-        if qpos is not None:
-            assert qpos.dtype == torch.float32 and qpos.numel() == rows * 256 and qpos.is_contiguous()
-        xw_next = torch.empty((rows, n_next), dtype=torch.float32, device=dev)
-    if any_valid is None:
-        any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
-    with _timed("chain_update_ffn_class_f32s"):
-      L.check(L.load().mvg_chain_update_ffn_class_f32s(
-          L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
-          L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out), L.ptr(prob),
-          L.ptr(valid), L.ptr(any_valid), L.ptr(qpos), L.ptr(Wn), L.ptr(bn), L.ptr(xw_next), n_next, B, NQ, J,
-          1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class_f32s")
-    if next_query_proj is not None:
-        return tgt_out, prob, valid, any_valid, xw_next
-    return tgt_out, prob, valid, any_valid
-
-
 def chain_update_ffn_class_f32h(attn, V, tgt, Wu, su, bu, g2, be2, W1, s1, b1, W2, s2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
                                 forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None):
     """fp32 chain B on two-part fp16 operands (include/mvg_decoder.h: mvg_chain_update_ffn_class_f32h); arguments and results as
-    chain_update_ffn_class_f32s, weights (planes, scale) from split_swizzle_weight_h2, next_query_proj = (qpos, Wn, sn, bn, n_next)."""
+    chain_update_ffn_class, attn (V * rows, 256) f32, weights (planes, scale) from split_swizzle_weight_h2, next_query_proj = (qpos, Wn, sn, bn, n_next)."""
     dev = attn.device
     rows = B * NQ * J
     if attn.dtype != torch.float32 or attn.numel() != V * rows * 256 or not attn.is_contiguous():
@@ -737,7 +578,7 @@ def chain_update_ffn_class_f32h(attn, V, tgt, Wu, su, bu, g2, be2, W1, s1, b1, W
         xw_next = torch.empty((rows, n_next), dtype=torch.float32, device=dev)
     if any_valid is None:
         any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
-    with _timed("chain_update_ffn_class_f32s"):
+    with _timed("chain_update_ffn_class_f32h"):
       L.check(L.load().mvg_chain_update_ffn_class_f32h(
           L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), int(su), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), int(s1 or 0), L.ptr(b1), L.ptr(W2),
           int(s2 or 0), L.ptr(b2), L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out),

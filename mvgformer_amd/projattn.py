@@ -36,8 +36,6 @@ def _is_power_of_2(n):
     return (n & (n - 1) == 0) and n != 0
 
 
-# fp32 pyramid products on two-part fp16 operands (three MFMAs per product instead of six; same accuracy against fp64); 0 = the six-product bf16 form
-F32_H2 = os.environ.get("MVG_F32_H2", "1") != "0"
 
 class WeightCache:
     """Contiguous copies of module parameters in the compute dtype, rebuilt when a parameter
@@ -188,7 +186,7 @@ class ProjAttn(nn.Module):
         MVG_G_SAMPLING_F32, else whenever the gathered rows (Lq * L per image) outnumber the pyramid's (S)"""
         geometry = self.sampling_offsets.out_features + self.attention_weights.out_features == 192 and self.rayconv.weight.shape == (256, 256)
         if self.g_sampling_f32 == "auto" and self.f32_fused_active() and geometry:
-            # with the one-pass pyramid kernel (mvg_pyramid_f32s) the G form moves fewer bytes at every shipped shape: the gather
+            # with the one-pass pyramid kernel (mvg_pyramid_f32h) the G form moves fewer bytes at every shipped shape: the gather
             # form re-fetched 2.6 x its algorithmic bytes at cfg-4 (profiles/r03_bench_cfg4_fp32.json)
             return True
         use_g = self.g_sampling_f32 if self.g_sampling_f32 != "auto" else Lq * L >= S
@@ -228,12 +226,9 @@ class ProjAttn(nn.Module):
                                                torch.empty((n_img * S, 192), dtype=dt, device=feat.device))
                 self._vp, self._G = cur
             if self.f32_fused_active() and Cc == 256 and feat.is_contiguous():
-                if F32_H2:     # two-part fp16 operands, three products (csrc/f32s.hip: pyramid_f32h_kernel)
-                    (Wv_pl, sv), (Wg_pl, sg) = self.pyramid_planes_f32h()
-                    ops.pyramid_f32h(feat, Wv_pl, sv, bv, Wg_pl, sg, 192, value=self._vp, G=self._G)   # projattn.py:169 + 180-181
-                else:
-                    Wv_pl, Wg_pl = self.pyramid_planes_f32s()
-                    ops.pyramid_f32s(feat, Wv_pl, bv, Wg_pl, 192, value=self._vp, G=self._G)
+                # two-part fp16 operands, three products (csrc/f32s.hip: pyramid_f32h_kernel)
+                (Wv_pl, sv), (Wg_pl, sg) = self.pyramid_planes_f32h()
+                ops.pyramid_f32h(feat, Wv_pl, sv, bv, Wg_pl, sg, 192, value=self._vp, G=self._G)   # projattn.py:169 + 180-181
             else:
                 ops.linear(feat.view(n_img * S, Cc), Wv, bv, out=self._vp.view(n_img * S, Cc))       # projattn.py:169
                 ops.linear(feat.view(n_img * S, Cc), Wq, None, out=self._G)
@@ -252,20 +247,6 @@ class ProjAttn(nn.Module):
             self._vp_event = torch.cuda.Event()
             self._vp_event.record()
         return vp, self._G
-
-    def project_pyramid_group(self, feat, i0, i1):
-        """project_pyramid for images i0 .. i1-1 only (bf16 fast path; the buffers hold all images): one step of the view-group
-        pipeline of DQDecoder (PyramidPipeline)."""
-        dt = feat.dtype
-        n_img, S, _ = feat.shape
-        bv = self._wc.get("bv", (self.rayconv.bias,), torch.float32)
-        Wv_f = self._wc.get("Wv_frag", (self.rayconv.weight,), dt, lambda w: ops.swizzle_weight(w.to(dt)))
-        vp = self._plane_buffer(n_img, S, feat.device)
-        shape = (n_img * S, 192)
-        if self._G is None or self._G.dtype != torch.bfloat16 or tuple(self._G.shape) != shape or self._G.device != feat.device:
-            self._G = torch.empty(shape, dtype=torch.bfloat16, device=feat.device)
-        ops.value_proj_planes_ws(feat[i0:i1], Wv_f, bv, vp[i0:i1])
-        ops.feat_linear_ws(feat[i0:i1], self.query_term_weights(dt)[0], 192, out=self._G[i0 * S:i1 * S])
 
     def pyramid_jobs(self, feat):
         """this layer's two products as jobs of ops.pyramid_group_ws (value planes, G), into the buffers project_pyramid uses"""
@@ -315,13 +296,6 @@ class ProjAttn(nn.Module):
         bn = self._wc.get("boa_pad", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, bpad)
         return Wf, bn, 192
 
-    def pyramid_planes_f32s(self):
-        """operands of mvg_pyramid_f32s: the value projection and the [offsets; logits] Linear (gsamp_column_order) as split planes"""
-        bf = torch.bfloat16
-        perm = lambda a, b: ops.split_swizzle_weight(torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)])
-        return (self._wc.get("Wv_f32s", (self.rayconv.weight,), bf, ops.split_swizzle_weight),
-                self._wc.get("Woa_f32s", (self.sampling_offsets.weight, self.attention_weights.weight), bf, perm))
-
     def pyramid_planes_f32h(self):
         """operands of mvg_pyramid_f32h: ((value planes, scale), (G planes, scale)) -- two fp16 parts of each weight times a power of two"""
         f16 = torch.float16
@@ -333,12 +307,6 @@ class ProjAttn(nn.Module):
         """operands of the next layer's query term as the two-part fp16 chain B of the PREVIOUS layer takes them: ((planes, scale) of the
         (192 -> 256, 256) weight in gsamp_column_order, bias (256,) f32 zero-padded, n = 192)"""
         Wpl = self.pyramid_planes_f32h()[1]
-        return Wpl, self.query_term_weights_f32s()[1], 192
-
-    def query_term_weights_f32s(self):
-        """operands of xw = (tgt + query_pos) @ [Woff; Wattn]^T + b as the fp32 chain B of the PREVIOUS layer takes them: (split
-        planes of the (192 -> 256, 256) weight in gsamp_column_order, bias (256,) f32 zero-padded, n = 192)"""
-        Wpl = self.pyramid_planes_f32s()[1]
         perm = lambda a, b: torch.cat([a, b], 0)[ops.gsamp_column_order(a.device)]
         bpad = lambda a, b: torch.cat([perm(a, b), a.new_zeros(64)], 0)
         bn = self._wc.get("boa_pad", (self.sampling_offsets.bias, self.attention_weights.bias), torch.float32, bpad)
@@ -376,16 +344,6 @@ class ProjAttn(nn.Module):
                     xw = ops.linear(parts[0].reshape(-1, Cc), Wq, bq, out_dtype=torch.float32, add=parts[1].reshape(-1, Cc))
                 else:
                     xw = ops.linear(x.reshape(-1, Cc), Wq, bq, out_dtype=torch.float32)
-            pipe = getattr(self, "_pipeline", None)
-            if pipe is not None and order is not None:
-                # view groups: every group is sampled right behind the GEMMs that produced its planes (still in the Infinity
-                # Cache), while the side stream produces the next groups (DQDecoder: PyramidPipeline)
-                samp = torch.empty((n_img * r.shape[1], 256), dtype=torch.bfloat16, device=feat.device)
-                for g in range(pipe.n_groups):
-                    i0, i1 = pipe.wait_ready(self, g)
-                    ops.msda_gsamp(self._vp, self._G, xw, r, levels, B, pair_mask=pair_mask, order=order, out=samp, images=(i0, i1))
-                    pipe.consumed(self, g)
-                return samp
             vp, G = self.project_pyramid(feat) if self._vp_event is None else self._wait_pyramid()
             return ops.msda_gsamp(vp, G, xw, r, levels, B, pair_mask=pair_mask, order=order)   # projattn.py:148-200
         if f32_g:

@@ -49,9 +49,3 @@ print("chain B full                 %7.1f us" % t(lambda: run()))
 print("chain B without next-xw tail %7.1f us" % t(lambda: run(nxt=False)))
 print("chain B without FFN          %7.1f us" % t(lambda: run(ffn=False, nxt=False)))
 print("chain B 1 view, no FFN       %7.1f us" % t(lambda: run(v=1, ffn=False, nxt=False)))
-for ring in (4, 8):
-    lib.mvg_set_tuning(b"chain_ring", ring)
-    print("ring %d: full %7.1f us" % (ring, t(lambda: run())))
-lib.mvg_set_tuning(b"chain_ring", 4)
-lib.mvg_set_tuning(b"chain_split", 0)
-print("row-block split (old)        %7.1f us" % t(lambda: run()))

@@ -105,16 +105,7 @@ with torch.no_grad():
         e_.record()
         torch.cuda.synchronize()
         print("%-28s %8.1f us" % ("  bin_pairs", s_.elapsed_time(e_) / 20 * 1e3))
-        lib.mvg_set_tuning(b"fused_cpl_bf16", 8)
         ref = ops.msda_fused(value, oa, ref_lvl, ctx.levels)
         d = (outp.float() - ref.float()).abs()
         print("    vs generic fused kernel: max |diff| %.3e  mean %.3e  (|ref| max %.2f)" % (float(d.max()), float(d.mean()), float(ref.float().abs().max())))
-    base = None
-    knobs = [("fused_cpl_bf16", 8), ("fused_cpl_bf16", 4)] if dtype == torch.bfloat16 else [("fused_cpl_bf16", 8)]
-    for ck, cv in knobs:
-        lib.mvg_set_tuning(ck.encode(), cv)
-        out = run("generic fused kernel cpl=%d" % cv)
-        if base is None:
-            base = out.float()
-        else:
-            print("    max |diff| vs first variant: %.3e" % float((out.float() - base).abs().max()))
+    run("generic fused kernel")

@@ -47,16 +47,13 @@ mb = lambda nj: (n_img * S * 512 + nj // 2 * n_img * S * (512 + 384)) / 1e6
 print("%d images x %d pixels, %d layers" % (n_img, S, layers))
 a = t(single)
 print("one launch per product (%d launches): %7.1f us" % (len(jobs), a))
-for gw in (300, 280, 320, 340, 400):
-    lib.mvg_set_tuning(b"wreg_gweight", gw)
-    line = "gweight %d:" % gw
-    for nl in (1, 2, 3, 4):
-        if nl > layers:
-            break
-        us = t(lambda: ops.pyramid_group_ws(feat, jobs[:2 * nl]))
-        line += "  %d layer%s %6.1f us (%4.0f GB/s min traffic)" % (nl, "s" if nl > 1 else " ", us, mb(2 * nl) / us * 1e3 / 1e3)
-    print(line)
-lib.mvg_set_tuning(b"wreg_gweight", 300)
+line = "grouped:"
+for nl in (1, 2, 3, 4):
+    if nl > layers:
+        break
+    us = t(lambda: ops.pyramid_group_ws(feat, jobs[:2 * nl]))
+    line += "  %d layer%s %6.1f us (%4.0f GB/s min traffic)" % (nl, "s" if nl > 1 else " ", us, mb(2 * nl) / us * 1e3 / 1e3)
+print(line)
 for grid in (384, 448, 512):
     lib.mvg_set_tuning(b"wreg_grid", grid)
     us1, us3 = t(lambda: ops.pyramid_group_ws(feat, jobs[:2])), t(lambda: ops.pyramid_group_ws(feat, jobs[2:8]))
