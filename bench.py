@@ -372,6 +372,11 @@ def main():
     ap.add_argument("--queries", type=int, default=None,
                     help="override the configuration's query count (diagnostics: --queries 128 is the per-rank workload "
                          "of the 8-GPU query-sharded run; the metric name then no longer applies)")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="one GPU runs the workload of rank R of an --of N query-sharded job: ITS contiguous block of the person grid "
+                         "(dist.shard_bounds), not --queries persons spread over the whole space; no collectives.  Adds "
+                         "config.emulated_rank and the share of 16 x 16-pixel pyramid tiles its samples can touch per layer")
+    ap.add_argument("--of", type=int, default=8, help="rank count of --emulate-rank")
     ap.add_argument("--speculative", type=int, default=1,
                     help="query-sharded runs: 1 = the whole forward as one graph, assuming every layer has a valid query "
                          "somewhere, verified after the forward and redone exactly on a miss (dist.SpeculativeShardedDecoder); "
@@ -457,9 +462,12 @@ def main():
         cpu_case = copy.copy(case)      # keeps the host tensors; case_to_device() rebinds `case`'s attributes
     dec = build_decoder_for_case(case, dev, dtype)
     g = case_to_device(case, dev)
-    lo, hi = mdist.shard_bounds(NQ, world if sharded else 1, rank if sharded else 0)
-    tgt, qpos, ref, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, J, world if sharded else 1,
-                                            rank if sharded else 0)
+    emul = args.emulate_rank is not None
+    if emul and (world != 1 or not 0 <= args.emulate_rank < args.of):
+        raise SystemExit("--emulate-rank R --of N needs one GPU and 0 <= R < N")
+    sh_world, sh_rank = (args.of, args.emulate_rank) if emul else ((world, rank) if sharded else (1, 0))
+    lo, hi = mdist.shard_bounds(NQ, sh_world, sh_rank)
+    tgt, qpos, ref, _ = mdist.shard_queries(g.tgt, g.query_pos, g.reference_points, J, sh_world, sh_rank)
     if sharded:
         mdist.install_any_valid_sync(dec, None)
 
@@ -669,7 +677,8 @@ def main():
                     ops.PROFILE = None
 
     default_headline = (args.config == "cfg2" and args.dtype == "bf16" and args.queries is None and args.valid_fraction is None
-                        and args.inside == "grid" and args.inflight == 1 and args.batch == 1 and args.producer == "nchw")
+                        and args.inside == "grid" and args.inflight == 1 and args.batch == 1 and args.producer == "nchw"
+                        and args.emulate_rank is None)
     want_secondary = default_headline if args.secondary < 0 else bool(args.secondary)
     secondary = {}
     if want_secondary and sharded:
@@ -813,6 +822,37 @@ def main():
         split = {"fixed_us": round(fx * 1e3, 1), "variable_us": round(var * 1e3, 1),
                  "note": "rank 0, kernels timed one at a time; fixed = replicated query-independent work"}
 
+    touched = None
+    if emul:
+        # Which part of the pyramid can this rank's samples touch?  Per layer: the reference points it projects (the initial grid
+        # block, then its own previous layer's output points) -> 16 x 16-pixel tiles of every level within the offsets' reach
+        # (+- 8 cells: the rays of projattn.py:98-108) of an in-image projection, as a share of each level's tiles, weighted by pixels.
+        with torch.no_grad():
+            outs = forward()
+            pts = [ref] + [outs[1][l] for l in range(Ly - 1)]
+            shp = [(int(h), int(w)) for h, w in g.spatial_shapes.tolist()]
+            per_layer = []
+            for X in pts:
+                r_, _, ins_ = ops.project(X.reshape(args.batch, -1, 3).float().contiguous(), ctx.cams, ctx.levels, V, args.batch)
+                num = den = 0.0
+                for (Hl, Wl) in shp:
+                    th, tw = -(-Hl // 16), -(-Wl // 16)
+                    px = r_[..., 0] * Wl
+                    py = r_[..., 1] * Hl
+                    hit = torch.zeros((r_.shape[0], th, tw), dtype=torch.bool, device=dev)
+                    for dy in (-9, 0, 9):
+                        for dx in (-9, 0, 9):
+                            tx = ((px + dx) // 16).long().clamp(0, tw - 1)
+                            ty = ((py + dy) // 16).long().clamp(0, th - 1)
+                            img = torch.arange(r_.shape[0], device=dev)[:, None].expand_as(tx)
+                            m = ins_.view(r_.shape[0], -1).bool()
+                            hit[img[m], ty[m], tx[m]] = True
+                    num += float(hit.float().mean()) * Hl * Wl
+                    den += Hl * Wl
+                per_layer.append(round(num / den, 4))
+            touched = {"per_layer": per_layer, "note": "share of the pyramid's pixels in 16 x 16 tiles within +- 9 cells of an in-image reference "
+                       "point of this rank's queries (layer l: the points layer l projects)"}
+
     if want_secondary and world == 1:
         # the other named workloads, driver-witnessed: same process, same command, after the headline's timed region
         for name, cfg_name, dt_name, inside, batch in SECONDARY:
@@ -884,6 +924,8 @@ def main():
                    "initial_poses": {"grid": "'sample_space' grid over the whole space (SURVEY 8(d))",
                                      "all": "grid over 30 % of the space: > 99 % of the (view, query) pairs inside their image"}[args.inside],
                    "samples_in_flight": args.inflight, "samples_per_forward": args.batch,
+                   **({"emulated_rank": "%d of %d: persons %d..%d of %d (contiguous block of the grid), no collectives" % (
+                       args.emulate_rank, args.of, lo, hi - 1, NQ), "touched_pyramid_share": touched} if emul else {}),
                    **({"fp32_gemm": {"split": "fused kernels (pyramid products, chains A / B): operands scaled per row / tensor by a power of two and "
                                               "split into 2 fp16 parts, 3 fp16 MFMA products, fp32 accumulate; the first layer's query term: 3 "
                                               "bf16 parts, 6 bf16 MFMA products",
