@@ -1,11 +1,11 @@
 // fp32 path of the decoder layer as fused kernels: fp32 storage at every boundary, every product formed on the fp16 matrix pipe
 // from TWO-part operands ("f32h": x 2^s = h + l, three MFMAs per product, fp32 accumulation -- f32s_dev.h and the note in front of
-// pyramid_f32h_kernel).  The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75, the Linears of
+// pyramid_ws_f32h_kernel).  The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75, the Linears of
 // lib/models/dq_decoder.py:763-848,659-717); rounds 1-3 ran it as 17 launches per layer with every intermediate in HBM.
 //
-//   mvg_pyramid_f32h                 value = feat Wv^T + bv  and  G = feat [Wo; Wa]^T  in ONE pass over the pyramid
-//                                    (projattn.py:169 and the pyramid side of :180-181): a 64-row tile is split once, 14 column
-//                                    blocks are produced from it; persistent workgroups.
+//   mvg_pyramid_f32h                 value = feat Wv^T + bv  and  G = feat [Wo; Wa]^T  in ONE launch over the pyramid
+//                                    (projattn.py:169 and the pyramid side of :180-181): weight-stationary persistent workgroups,
+//                                    each owning one of the two products (pyramid_ws_f32h_kernel).
 //   mvg_chain_attn_pose_f32h         chain A: attn = inside * (samp Wp^T + bp) -> stored; o = pose MLP(attn)   (dq_decoder.py:585-588,659-690)
 //   mvg_chain_update_ffn_class_f32h  chain B: view mean -> update Linear -> +tgt -> LN2 -> FFN -> LN3 -> class head -> next layer's
 //                                    query term (dq_decoder.py:770-778, mvp_decoder.py:94-98, dq_decoder.py:889-893)
@@ -16,6 +16,7 @@
 // bf16 parts per operand) computed the same rows at 1.4-1.6 x the time and are deleted (profiles/r04_experiments.txt holds their
 // numbers); the range-safe alternative is the unfused path (MVG_F32_FUSED=0: mvg_linear's three-part split form per GEMM).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -25,6 +26,24 @@
 // per workgroup at phase boundaries, read back with mvg_f32s_read_stamps.
 #ifndef F32S_PRIO
 #define F32S_PRIO 1           // the two wavefronts of a SIMD alternate issue priority per k-step (f32s_dev.h: stage_h2)
+#endif
+
+// measurement builds (tools/probes/stamps_pyr_ws.py): s_memtime per wavefront at the phase boundaries of one steady-state tile
+#ifdef PYRWS_STAMPS
+__device__ unsigned long long pyrws_stamps[512 * 8 * 16];
+#define PWSTAMP(i)                                                                                                        \
+  do {                                                                                                                    \
+    if (k == PYRWS_STAMPS && lane == 0) {                                                                                 \
+      asm volatile("" ::: "memory");                                                                                      \
+      pyrws_stamps[(blockIdx.x * 8 + w) * 16 + (i)] = __builtin_amdgcn_s_memtime();                                       \
+      asm volatile("" ::: "memory");                                                                                      \
+    }                                                                                                                     \
+  } while (0)
+extern "C" int mvg_pyrws_read_stamps(unsigned long long* host, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pyrws_stamps), sizeof(unsigned long long) * 128 * n_blocks);
+}
+#else
+#define PWSTAMP(i)
 #endif
 
 namespace {
@@ -43,167 +62,212 @@ constexpr int NT = 512;
 // rounding (2^-23 of an entry, or 2^-25 of the row / tensor maximum for entries in fp16's subnormal range) -- measured against fp64 on
 // operands with exact accumulation 4e-8 of sum|a||w| (six-product bf16 form: 3e-9), an order of magnitude under the 3e-7 the fp32
 // accumulation itself leaves in either form.  A row's scale depends on that row only: results are position-independent as before.
-constexpr int HPLANE = RM * PLP;             // bytes per fp16 activation plane (same pitch as the bf16 planes)
+// ------------------------------------------------------------------------------------------------------------------
+// pyramid products, weight-stationary (round 5).  Round 4's tiled kernel (pyramid_f32h_kernel, deleted) streamed 448 KB of weight
+// planes per 64-row tile through the CU's vector-memory path, found each row's maximum with a 64-lane butterfly and stored its outputs
+// as 4-byte-per-lane stores (32 store instructions per stage and wavefront): ~100 vector-memory instructions per wavefront and tile
+// next to 168 MFMAs -- 191 us per layer at cfg-2 with the matrix pipe 32 % busy.  Here a workgroup owns ONE of the two products for the whole launch, the way the bf16 kernels of wreg_gemm.hip do: wavefront w
+// keeps the two planes of column block w (32 columns x 256 k x 2 planes = 128 registers, loaded in the k order it will walk them),
+// 32-row tiles of the pyramid go through a double-buffered LDS image of their planes, the outputs through wavefront-private staging
+// rows as 16-byte stores (8 x 128-byte lines per instruction).  Per wavefront and tile: 4 row loads, 4 stores, 48 MFMAs; the
+// split of the NEXT tile's rows (row maximum over 16 lanes by four DPP steps, scale, two fp16 parts) and the stores of the PREVIOUS tile are
+// issued between the MFMAs of the k loop.  One workgroup barrier per tile.  Workgroups of an XCD (block b -> XCD b & 7) are divided
+// between the two products in proportion to their columns and walk the XCD's tiles in the same order: a tile comes from HBM once.
+// Same products, same k order per column block (rot), same three-term order as the tiled kernel: bit-identical outputs
+// (checked at six shapes before it was deleted; cfg-2 fp32 2.47 -> 2.36 ms, cfg-4 1.82 -> 1.71 ms on one box: profiles/r05_experiments.txt).
+constexpr int WS_RM = 32;
+constexpr int WS_PLANES = 2 * WS_RM * PLP;             // one slot: two fp16 planes of a 32-row tile (528-byte pitch)
+constexpr int WS_STP = 144;                            // staging pitch: 32 fp32 + 16 B
+constexpr int WS_LDS = 2 * WS_PLANES + 8 * WS_RM * WS_STP + 2 * WS_RM * (int)sizeof(int);
 
-template <int KSTEPS, int RING, int MT = 2>
-__device__ __forceinline__ void stage_swapped_h2(const char* __restrict__ act, const bf16_t* __restrict__ wp, long wplane,
-                                                 f32x16 (&acc)[MT], int rot, int lane, int row0 = 0) {
-  const int rl = lane & 31, h = lane >> 5;
+struct PyrWsParams {
+  const float* feat;
+  const bf16_t* W[2];     // weight planes of product 0 (value) / 1 (G)
+  const float* bias[2];
+  float* out[2];
+  int sw[2], n[2], slots[2];
+  long rows;
+  unsigned char slot_job[32], slot_idx[32];
+};
+
+__global__ __launch_bounds__(NT, 1) void pyramid_ws_f32h_kernel(PyrWsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int job = p.slot_job[slot];
+  const int ncol = p.n[job], ld = ncol;
+  const bool has_cols = 32 * w < ncol;
+  char* stage = smem + 2 * WS_PLANES + w * WS_RM * WS_STP;
+  int* rs = reinterpret_cast<int*>(smem + 2 * WS_PLANES + 8 * WS_RM * WS_STP);       // [slot][row]: s_row
+  const int rot = (w * 3 + (job ? 7 : 0)) & 15;
+  // the weight planes of this wavefront's column block, in the order its k loop walks them: wr[i] = fragment (i + rot) & 15
+  f32x4 wr[16][2];
+  {
+    const bf16_t* wp = frag_ptr(p.W[job], 0, has_cols ? w : 0, 16, lane);
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
-  f32x4 ring[RING][2];
-#pragma unroll
-  for (int p = 0; p < RING; ++p) {
-    const int kq = (p + rot) & (KSTEPS - 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) ring[p][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
+    for (int i = 0; i < 16; ++i) {
+      const int kq = (i + rot) & 15;
+      wr[i][0] = *reinterpret_cast<const f32x4*>(wp + kq * 1024);
+      wr[i][1] = *reinterpret_cast<const f32x4*>(wp + 65536 + kq * 1024);
+    }
   }
-  const char* arow = act + (row0 + rl) * PLP + 16 * h;
-  f32x4 a_nxt[MT][2];
+  const float bias = (p.bias[job] && has_cols) ? p.bias[job][32 * w + rl] : 0.f;
+  const int sw = p.sw[job];
+  const long ntiles = (p.rows + WS_RM - 1) / WS_RM;
+  const long first = p.slot_idx[slot] * 8 + xcd, G = (long)p.slots[job] * 8;
+  float* outp = p.out[job];
+
+  // rows of a tile: wavefront w takes rows 4 w .. 4 w + 3, 16 lanes per row; chunk i of a lane = columns 64 i + 4 (lane & 15) .. + 3 (one
+  // load instruction = the i-th 256-byte quarter of four rows).  A lane holds 16 values of ONE row: the row maximum is a local
+  // maximum + four DPP steps over the row's 16 lanes (the 64-lane butterfly of the tiled kernel, per row, was 6 cross-lane steps).
+  // (two register sets -- rows in flight for two tiles instead of one -- measured the same: the row loads are never waited for)
+  f32x4 xa[4];
+  const int xrow = 4 * w + (lane >> 4), xcol = (lane & 15) * 4;
+  auto load_rows = [&](long tile, f32x4 (&x)[4]) {
+    const long r0 = min(tile, ntiles - 1) * WS_RM;
+    const float* src = p.feat + min(r0 + xrow, p.rows - 1) * 256 + xcol;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(src + 64 * i);
+  };
+  int xsr = 0;
+  auto split_scale = [&](const f32x4 (&x)[4], int ps) {   // s_row of this lane's row (the row maximum's exponent)
+    float m = 0.f;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * HPLANE + mt * 32 * PLP + (rot & (KSTEPS - 1)) * 32);
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fmaxf(fabsf(x[i][2]), fabsf(x[i][3]))));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, false)));    // lane ^ 1
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xf, 0xf, false)));    // lane ^ 2
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xf, 0xf, false)));   // half mirror
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xf, 0xf, false)));   // mirror
+    xsr = row_scale(m);
+    if ((lane & 15) == 0) rs[ps * WS_RM + xrow] = xsr;
+  };
+  auto split_row = [&](const f32x4 (&x)[4], int i, int ps) {     // chunk i -> two fp16 parts -> plane slot `ps`
+    f32x4 xs;
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    half8 a[MT][2], b[2];
+    for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(x[i][t], xsr);
+    uint2 ph, pl;
+    split4_h2(xs, ph, pl);
+    char* dst = smem + ps * WS_PLANES + xrow * PLP + (64 * i + xcol) * 2;
+    *reinterpret_cast<uint2*>(dst) = ph;
+    *reinterpret_cast<uint2*>(dst + WS_RM * PLP) = pl;
+  };
+  // stores of a finished tile from the wavefront's staging rows: instruction i writes rows 8 i .. 8 i + 7, 128 bytes each
+  f32x4 sv[4];
+  auto st_read = [&](long tile, int i) {
+    const int last_row = (int)(p.rows - 1 - tile * WS_RM);
+    sv[i] = *reinterpret_cast<const f32x4*>(stage + min(8 * i + (lane >> 3), last_row) * WS_STP + (lane & 7) * 16);
+  };
+  auto st_store = [&](long tile, int i) {
+    const int last_row = (int)(p.rows - 1 - tile * WS_RM);
+    *reinterpret_cast<f32x4*>(outp + (tile * WS_RM + min(8 * i + (lane >> 3), last_row)) * ld + 32 * w + (lane & 7) * 4) = sv[i];
+  };
+
+  long tile = first;
+  if (tile >= ntiles) return;
+  load_rows(tile, xa);
+  split_scale(xa, 0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+  for (int i = 0; i < 4; ++i) split_row(xa, i, 0);
+  load_rows(tile + G, xa);
+  int ps = 0, k = 0;
+  long prev = -1;
+  if (!has_cols) {
+    // a wavefront without columns (the last two of a 192-column product) only moves and splits its share of the rows
+#pragma unroll 1
+    for (; tile < ntiles; tile += G, ps ^= 1) {
+      __syncthreads();
+      if (tile + G < ntiles) {
+        split_scale(xa, ps ^ 1);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) a[mt][s] = __builtin_bit_cast(half8, a_nxt[mt][s]);
-    if (ks + 1 < KSTEPS) {
-      const int kn = (ks + 1 + rot) & (KSTEPS - 1);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) a_nxt[mt][s] = *reinterpret_cast<const f32x4*>(arow + s * HPLANE + mt * 32 * PLP + kn * 32);
+        for (int i = 0; i < 4; ++i) split_row(xa, i, ps ^ 1);
+        load_rows(tile + 2 * G, xa);
+      }
     }
+    return;
+  }
+  // One tile; WITH_PREV: the previous tile's stores ride on this k loop; HAS_NEXT: the next tile's rows (requested a tile ago) are
+  // split under it and their registers re-used for the tile after.  Compile-time cases instead of branches: the k loop is ONE
+  // basic block, pinned step by step.
+  auto tile_body = [&](auto with_prev, auto has_next_t, const long t) {
+    constexpr bool WITH_PREV = decltype(with_prev)::value, HAS_NEXT = decltype(has_next_t)::value;
+    f32x4 (&x)[4] = xa;
+    PWSTAMP(0);
+    __syncthreads();            // planes + scales of this tile are complete; slot ps ^ 1 is no longer read
+    PWSTAMP(1);
+    const char* arow = smem + ps * WS_PLANES + rl * PLP + 16 * h;
+    f32x16 acc;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) b[s] = __builtin_bit_cast(half8, ring[ks % RING][s]);
-    if (ks + RING < KSTEPS) {
-      const int kq = (ks + RING + rot) & (KSTEPS - 1);
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 a[2][2];
+    int4 srv[4];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) ring[ks % RING][s] = *reinterpret_cast<const f32x4*>(wp + s * wplane + kq * 1024);
+    for (int i = 0; i < 2; ++i) {
+      const int kq = (i + rot) & 15;
+      a[i][0] = *reinterpret_cast<const f32x4*>(arow + kq * 32);
+      a[i][1] = *reinterpret_cast<const f32x4*>(arow + WS_RM * PLP + kq * 32);
     }
-    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};        // smallest terms first
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][TA[t]], b[TB[t]], acc[mt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// acc[mt][4 g + t] = 2^(s_row + s_w) out[row 32 mt + 8 g + 4 h + t][column rl of the block]; rs = the tile's s_row table in LDS
-template <int MT = 2>
-__device__ __forceinline__ void store_swapped_h2(float* __restrict__ out, long ld, long r0, long rows, int col, const f32x16 (&acc)[MT],
-                                                 float bias, const int* __restrict__ rs, int sw, int lane, int row0 = 0) {
-  const int h = lane >> 5;
-  float* dst = out + (r0 + row0 + 4 * h) * ld + col;
-  const bool whole = r0 + RM <= rows;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < 16; ++i) {
+      const half8 ah = __builtin_bit_cast(half8, a[i & 1][0]), al = __builtin_bit_cast(half8, a[i & 1][1]);
+      const half8 bh = __builtin_bit_cast(half8, wr[i][0]), bl = __builtin_bit_cast(half8, wr[i][1]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);          // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      if (i + 2 < 16) {
+        const int kq = (i + 2 + rot) & 15;
+        a[i & 1][0] = *reinterpret_cast<const f32x4*>(arow + kq * 32);
+        a[i & 1][1] = *reinterpret_cast<const f32x4*>(arow + WS_RM * PLP + kq * 32);
+      }
+      // fillers in the shadow of this step's MFMAs
+      if (WITH_PREV) {
+        if (i == 0) { st_read(prev, 0); st_read(prev, 1); }
+        if (i == 1) { st_read(prev, 2); st_read(prev, 3); }
+        if (i == 2) { st_store(prev, 0); st_store(prev, 1); }
+        if (i == 3) { st_store(prev, 2); st_store(prev, 3); }
+      }
+      if (HAS_NEXT) {
+        if (i == 5) split_scale(x, ps ^ 1);
+        if (i >= 6 && i < 10) split_row(x, i - 6, ps ^ 1);
+        if (i == 11) load_rows(t + 2 * G, x);
+      }
+      if (i == 13) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) srv[g] = *reinterpret_cast<const int4*>(rs + ps * WS_RM + 8 * g + 4 * h);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 3) PWSTAMP(2);
+      if (i == 4) PWSTAMP(3);
+      if (i == 9) PWSTAMP(4);
+      if (i == 11) PWSTAMP(5);
+    }
+    PWSTAMP(6);
+    // epilogue: acc[4 g + t] = 2^(s_row + s_w) out[row 8 g + 4 h + t][column rl] -> staging, un-scaled, + bias
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int4 sr = *reinterpret_cast<const int4*>(rs + row0 + 32 * mt + 8 * g + 4 * h);
-      const int se[4] = {sr.x, sr.y, sr.z, sr.w};
+      const int se[4] = {srv[g].x, srv[g].y, srv[g].z, srv[g].w};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float v = __builtin_ldexpf(acc[mt][4 * g + t], -(se[t] + sw)) + bias;
-        if (whole || r0 + row0 + 4 * h + 32 * mt + 8 * g + t < rows) dst[(long)(32 * mt + 8 * g + t) * ld] = v;
-      }
+      for (int tt = 0; tt < 4; ++tt)
+        *reinterpret_cast<float*>(stage + (8 * g + 4 * h + tt) * WS_STP + rl * 4) = __builtin_ldexpf(acc[4 * g + tt], -(se[tt] + sw)) + bias;
     }
-}
-
-template <bool PAIR>
-__global__ __launch_bounds__(NT, PAIR ? 2 : 1) void pyramid_f32h_kernel(const float* __restrict__ feat, const bf16_t* __restrict__ Wv, int swv,
-                                                          const float* __restrict__ bv, const bf16_t* __restrict__ Wg, int swg,
-                                                          float* __restrict__ value, float* __restrict__ G, long rows, int ng) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* act = smem;                                             // 2 fp16 planes x RM rows
-  int* rs = reinterpret_cast<int*>(smem + 2 * HPLANE);          // s_row of the tile's rows
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long ntiles = (rows + RM - 1) / RM;
-  const int rot = (w * 3) & 15;
-  const bf16_t* wpv = frag_ptr(Wv, 0, w, 16, lane);
-  const bf16_t* wpg = frag_ptr(Wg, 0, w, 16, lane);
-  const bf16_t* wpg2 = frag_ptr(Wg, 0, w < 4 ? w : 4 + ((w - 4) >> 1), 16, lane);
-  const float bias_v = bv ? bv[32 * w + (lane & 31)] : 0.f;
-  const bool has_g = 32 * w < ng;
-  // PAIR: two workgroups per CU (2 x 68 KB of planes, <= 128 registers): no rows held across a tile's stages, fragment ring 2 deep --
-  // one workgroup's loads, splits, stores and barrier waits run under the other's matrix work
-  constexpr int RG = PAIR ? 2 : 4;
-  f32x4 x[8];
-  long tile = blockIdx.x;
-  if (!PAIR && tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * NT + tid;
-      x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
-    }
+    PWSTAMP(7);
+    prev = t;
+    ps ^= 1;
+    ++k;
+  };
+  auto step = [&](auto wp, auto hn, const long t) { tile_body(wp, hn, t); };
+  if (tile + G < ntiles) {
+    step(std::false_type{}, std::true_type{}, tile);
+    tile += G;
+#pragma unroll 1
+    for (; tile + G < ntiles; tile += G) step(std::true_type{}, std::true_type{}, tile);
+    step(std::true_type{}, std::false_type{}, tile);
+  } else {
+    step(std::false_type{}, std::false_type{}, tile);
   }
-  for (; tile < ntiles; tile += gridDim.x) {
-    const long r0 = tile * RM;
-    asm volatile("" : "+v"(wpv), "+v"(wpg), "+v"(wpg2));
-    if (PAIR) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid;
-        x[i] = *reinterpret_cast<const f32x4*>(feat + min(tile * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
-      }
-    }
-    __syncthreads();                               // the previous tile's stages have read the planes and the scale table
-    // chunk i of this thread is 4 columns of row 8 i + w: a wavefront holds one whole row per chunk -> its maximum by a butterfly
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float m = fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fmaxf(fabsf(x[i][2]), fabsf(x[i][3])));
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-      // s_row: the row maximum lands in [2^13, 2^14); rows of zeros / subnormals: capped (their scaled entries stay tiny, which is exact)
-      const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
-      const int sr = min(13 - e, 100);
-      const int row = 8 * i + w, col = lane * 4;
-      float xs[4], rr[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xs[t] = __builtin_ldexpf(x[i][t], sr);
-      const half2_t h0 = {(_Float16)xs[0], (_Float16)xs[1]}, h1 = {(_Float16)xs[2], (_Float16)xs[3]};
-      rr[0] = xs[0] - (float)h0[0]; rr[1] = xs[1] - (float)h0[1]; rr[2] = xs[2] - (float)h1[0]; rr[3] = xs[3] - (float)h1[1];
-      const half2_t l0 = {(_Float16)rr[0], (_Float16)rr[1]}, l1 = {(_Float16)rr[2], (_Float16)rr[3]};
-      *reinterpret_cast<uint2*>(act + row * PLP + col * 2) = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-      *reinterpret_cast<uint2*>(act + HPLANE + row * PLP + col * 2) = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
-      if (lane == 0) rs[row] = sr;
-    }
-    __syncthreads();
-    const long nxt = tile + gridDim.x;
-    f32x16 acc[2];
-    stage_swapped_h2<16, RG>(act, wpv, 65536, acc, rot, lane);
-    if (!PAIR && nxt < ntiles) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * NT + tid;
-        x[i] = *reinterpret_cast<const f32x4*>(feat + min(nxt * RM + (c >> 6), rows - 1) * 256 + (c & 63) * 4);
-      }
-    }
-    store_swapped_h2(value, 256, r0, rows, 32 * w + (lane & 31), acc, bias_v, rs, swv, lane);
-    if (ng == 192) {                               // balanced G stage, as in pyramid_f32s_kernel
-      if (w < 4) {
-        stage_swapped_h2<16, RG>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
-        store_swapped_h2(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, rs, swg, lane);
-      } else {
-        const int cbg = 4 + ((w - 4) >> 1), mtg = (w - 4) & 1;
-        f32x16 a1[1];
-        stage_swapped_h2<16, RG, 1>(act, wpg2, 65536, a1, (cbg * 3 + 7) & 15, lane, 32 * mtg);
-        store_swapped_h2<1>(G, ng, r0, rows, 32 * cbg + (lane & 31), a1, 0.f, rs, swg, lane, 32 * mtg);
-      }
-    } else if (has_g) {
-      stage_swapped_h2<16, RG>(act, wpg, 65536, acc, (rot + 7) & 15, lane);
-      store_swapped_h2(G, ng, r0, rows, 32 * w + (lane & 31), acc, 0.f, rs, swg, lane);
-    }
-  }
+  for (int i = 0; i < 4; ++i) { st_read(prev, i); st_store(prev, i); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -817,14 +881,37 @@ extern "C" int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv
   if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(G) |
        reinterpret_cast<uintptr_t>(Wv_planes) | reinterpret_cast<uintptr_t>(Wg_planes)) % 16 != 0)
     return MVG_E_BADARG;
-  const size_t lds = 2 * HPLANE + RM * sizeof(int);
-  static bool configured[MVG_MAX_DEVICES] = {};
-  const long ntiles = (rows + RM - 1) / RM;
-  // two persistent workgroups per CU (no row prefetch, fragment ring 2); the one-workgroup form with a row prefetch measured slower
-  if (int rc = configure_lds(&pyramid_f32h_kernel<true>, lds, configured)) return rc;
-  const int grid = (int)std::min<long>(ntiles, 2 * cu_count());
-  hipLaunchKernelGGL(pyramid_f32h_kernel<true>, dim3(grid), dim3(NT), lds, (hipStream_t)stream, feat, (const bf16_t*)Wv_planes, wv_scale,
-                     bv, (const bf16_t*)Wg_planes, wg_scale, value, G, (long)rows, n_g);
+  static bool configured_ws[MVG_MAX_DEVICES] = {};
+  if (int rc = configure_lds(&pyramid_ws_f32h_kernel, WS_LDS, configured_ws)) return rc;
+  {
+    PyrWsParams p = {};
+    p.feat = feat; p.rows = rows;
+    p.W[0] = (const bf16_t*)Wv_planes; p.W[1] = (const bf16_t*)Wg_planes;
+    p.bias[0] = bv; p.bias[1] = nullptr;
+    p.out[0] = value; p.out[1] = G;
+    p.sw[0] = wv_scale; p.sw[1] = wg_scale;
+    p.n[0] = 256; p.n[1] = n_g;
+    // one workgroup per CU, 32 per XCD, divided in proportion to the products' columns; never more than the tiles an XCD has
+    const long ntiles_ws = (rows + WS_RM - 1) / WS_RM;
+    int per_xcd = cu_count() / 8;
+    if (per_xcd > 32) per_xcd = 32;
+    if (per_xcd < 2) per_xcd = 2;
+    const long cap = (ntiles_ws + 7) / 8 * 2;
+    if (per_xcd > cap) per_xcd = (int)cap;
+    int s0 = (per_xcd * 256 + (256 + n_g) / 2) / (256 + n_g);
+    if (s0 < 1) s0 = 1;
+    if (s0 > per_xcd - 1) s0 = per_xcd - 1;
+    p.slots[0] = s0; p.slots[1] = per_xcd - s0;
+    int given[2] = {0, 0}, sidx = 0;
+    while (sidx < per_xcd)                       // interleave the two products over the slots
+      for (int j = 0; j < 2 && sidx < per_xcd; ++j)
+        if (given[j] < p.slots[j]) {
+          p.slot_job[sidx] = (unsigned char)j;
+          p.slot_idx[sidx] = (unsigned char)given[j]++;
+          ++sidx;
+        }
+    hipLaunchKernelGGL(pyramid_ws_f32h_kernel, dim3(8 * per_xcd), dim3(NT), WS_LDS, (hipStream_t)stream, p);
+  }
   MVG_LAUNCH_CHECK();
   return 0;
 }

@@ -19,7 +19,7 @@ __device__ __forceinline__ const bf16_t* frag_ptr(const bf16_t* __restrict__ Wf,
   return Wf + ((long)nb * 4 + (cb >> 1)) * kt_total * 1024 + (cb & 1) * 512 + lane * 8;
 }
 
-// ---- two-part fp16 operands ("f32h"): x 2^s = h + l, a * w = l*h + h*l + h*h as three fp16 MFMAs (see csrc/f32s.hip, pyramid_f32h_kernel)
+// ---- two-part fp16 operands ("f32h"): x 2^s = h + l, a * w = l*h + h*l + h*h as three fp16 MFMAs (see csrc/f32s.hip)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 

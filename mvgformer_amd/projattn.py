@@ -226,7 +226,7 @@ class ProjAttn(nn.Module):
                                                torch.empty((n_img * S, 192), dtype=dt, device=feat.device))
                 self._vp, self._G = cur
             if self.f32_fused_active() and Cc == 256 and feat.is_contiguous():
-                # two-part fp16 operands, three products (csrc/f32s.hip: pyramid_f32h_kernel)
+                # two-part fp16 operands, three products (csrc/f32s.hip: pyramid_ws_f32h_kernel)
                 (Wv_pl, sv), (Wg_pl, sg) = self.pyramid_planes_f32h()
                 ops.pyramid_f32h(feat, Wv_pl, sv, bv, Wg_pl, sg, 192, value=self._vp, G=self._G)   # projattn.py:169 + 180-181
             else:

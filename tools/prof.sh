@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --cpu-baseline 0 --graph 0 --profile-steps 0 --traffic off $*"
+ARGS="--steps 10 --warmup 3 --cpu-baseline 0 --graph 0 --profile-steps 0 --traffic off --secondary 0 $*"
 # per-kernel durations and counters are those of each kernel running alone (as bench.py's roofline pass times them):
 # the pyramid GEMMs are issued inline here; the overlapped schedule is traced separately at the end
 export MVG_OVERLAP_PYRAMID=0

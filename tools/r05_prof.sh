@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5: the committed records of the final build -- bench line, kernel stats + PMC summary, graph-replay timeline
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/r05_prof; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.err
+tools/prof.sh r05 > $O/prof.log 2>&1; tail -5 $O/prof.log
+cp gpurun_out/prof_r05/summary.txt $O/rocprofv3_summary.txt; cp gpurun_out/prof_r05/timeline_overlap.txt $O/ 2>/dev/null
+cp $(ls gpurun_out/prof_r05/trace/*/*kernel_stats.csv gpurun_out/prof_r05/trace/*kernel_stats.csv 2>/dev/null | head -1) $O/kernel_stats.csv
+tools/ktrace_graph.sh r05 --secondary 0 > /dev/null 2>&1; cp gpurun_out/ktg_r05/timeline.txt $O/timeline_graph.txt
+python bench.py --dtype fp32 --secondary 0 --cpu-baseline 0 > $O/bench_fp32.json 2>> $O/bench.err
+# keep the merge-back under its 64-MB limit: the raw traces stay on the box
+rm -rf gpurun_out/prof_r05/trace gpurun_out/prof_r05/pmc_* gpurun_out/prof_r05/overlap gpurun_out/ktg_r05/trace
+ls -la $O
