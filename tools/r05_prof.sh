@@ -9,5 +9,5 @@ cp $(ls gpurun_out/prof_r05/trace/*/*kernel_stats.csv gpurun_out/prof_r05/trace/
 tools/ktrace_graph.sh r05 --secondary 0 > /dev/null 2>&1; cp gpurun_out/ktg_r05/timeline.txt $O/timeline_graph.txt
 python bench.py --dtype fp32 --secondary 0 --cpu-baseline 0 > $O/bench_fp32.json 2>> $O/bench.err
 # keep the merge-back under its 64-MB limit: the raw traces stay on the box
-rm -rf gpurun_out/prof_r05/trace gpurun_out/prof_r05/pmc_* gpurun_out/prof_r05/overlap gpurun_out/ktg_r05/trace
+rm -rf gpurun_out/prof_r05/trace gpurun_out/prof_r05/pmc_[A-Z]* gpurun_out/prof_r05/overlap gpurun_out/ktg_r05/trace
 ls -la $O
