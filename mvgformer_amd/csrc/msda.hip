@@ -884,9 +884,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_pipe_kernel(const bf16_t* __res
   msda_gsamp_body<L, NT, 1>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
 }
 
-static int g_gsamp_pipe = 0;       // tuning knob "gsamp_pipe": 1 = double-buffered gathers in half batches (round 3: 93 VGPRs = 5 waves / SIMD,
-                                   // isolated launch with a warm Infinity Cache 105 -> 100 us, but 1.303 -> 1.314 ms per forward: the extra
-                                   // wavefronts thrash the L1s once the planes come from HBM; pinned to 4 waves / SIMD it equals the default)
+static int g_gsamp_pipe = 0;       // tuning knob "gsamp_pipe": gathers double-buffered in half batches (93 VGPRs) -- 0 = from 24 images per launch on, 1 = always, 2 = never
 int g_auto_small = 1;              // tuning knob "auto_small": small launches pick their own workgroup / tile sizes (see mvg_msda_gsamp)
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
@@ -1119,6 +1117,8 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   // workgroups and its time is a workgroup's latency -- smaller workgroups and single-block XCD chunks spread it over
   // more CUs (cfg-2 with 128 / 256 queries: 0.83 / 0.90 -> 0.80 / 0.88 ms per forward).  Results do not depend on either
   // (every (pair, head) is computed independently).
+  // double-buffered gathers: -1.1 % per forward at 31 views (cfg-5), +1 % at 5-10 images, noise at 20 (profiles/r05_experiments.txt)
+  const bool pipe = g_gsamp_pipe == 1 || (g_gsamp_pipe == 0 && N_img >= 24);
   int nthreads = g_gsamp_threads, map = g_gsamp_map;
   if (g_auto_small && Lq <= 8192) {
     nthreads = 128;
@@ -1128,7 +1128,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   {                                                                                                               \
     int npb = (int)((pairs + NT / 4 - 1) / (NT / 4));                                                             \
     if (map > 0) npb = (npb + 8 * map - 1) / (8 * map) * (8 * map);                                               \
-    if (g_gsamp_pipe == 1)                                                                                   \
+    if (pipe)                                                                                                 \
       hipLaunchKernelGGL((msda_gsamp_pipe_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,     \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
@@ -1172,7 +1172,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gsamp_map") && value >= 0 && value <= 4096) { g_gsamp_map = value; return 0; }
   if (!strcmp(key, "fwd_map") && (value >= 0 && value <= 2)) { g_fwd_map = value; return 0; }
   if (!strcmp(key, "gfused_chunk") && value >= 0 && value <= 4096) { g_gfused_chunk = value; return 0; }
-  if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 1) { g_gsamp_pipe = value; return 0; }
+  if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }
