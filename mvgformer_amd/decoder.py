@@ -187,6 +187,7 @@ class DQDecoderLayer(MvPDecoderLayer):
         self._geo_out = None   # set by DQDecoder.forward: this layer's slices of the stacked 3D / 2D outputs
         self._next_layer = None   # set by DQDecoder.forward: the layer that consumes this layer's output
         self._xw_in = None        # set by the previous layer: this layer's query term (B*Lq,192) f32
+        self._after_chain_b = None    # set by DQDecoder.launch_pyramid_projections (just-in-time schedule): issues the NEXT layer's pyramid products
         self._proj_in = None      # set by the previous layer's triangulation launch: (new_ref, (r, ref_lvl, inside)) of this layer
         # query-sharded runs (mvgformer_amd.dist): callable(any_valid int32[1]) that makes the
         # "no query valid anywhere -> force query (0,0)" rule (dq_decoder.py:620-623) global
@@ -627,6 +628,9 @@ class DQDecoderLayer(MvPDecoderLayer):
             o = ops.rowdot3(hcur, self._w("Wpe_last", (pose_layers[-1].weight,), f32),
                             self._w("bpe_last", (pose_layers[-1].bias,), f32))
 
+        hook, self._after_chain_b = self._after_chain_b, None
+        if hook is not None:
+            hook()      # just-in-time schedule: the next layer's pyramid products run next to this layer's triangulation + the binning
         return dict(r=r, o=o, valid=valid, any_valid=any_valid, tgt_update=tgt_update.view(B, Lq, C), prob=prob,
                     dims=(V, B, NQ, J))
 
@@ -693,6 +697,12 @@ class DQDecoder(MvPDecoder):
         # pack the pyramid on the side stream in front of its consumers: the first layer's query-side prologue (projection, pair
         # binning, query term) then runs next to the pack instead of behind it
         self.pack_on_side = os.environ.get("MVG_PACK_ON_SIDE", "1") != "0"
+        # bf16, one sample per forward: layer l+1's products (one launch, ONE workgroup per CU) are issued behind layer l's chain B, next
+        # to its triangulation and the next binning, instead of all up front -- the sampler then finds them in the 256-MB Infinity
+        # Cache (137 -> 128 us) and the first sampler has the chip to itself: -2.8 ... -3.1 % at cfg-2, -2 % at cfg-5, +2 % at two samples
+        # per forward (profiles/r05_experiments.txt section 10).  MVG_PYRAMID_JIT = 0 | 1 overrides the choice.
+        self.pyramid_jit = os.environ.get("MVG_PYRAMID_JIT", "auto")
+        self.pyramid_jit_slots = 32
         pool = {}
         for layer in self.layers:       # the inline fp32 pyramid products share one (value, G) pair per stream -- of THIS decoder
             layer.proj_attn._f32_pool = pool
@@ -725,11 +735,12 @@ class DQDecoder(MvPDecoder):
         self._side_stream.wait_stream(torch.cuda.current_stream())
         return self._side_stream
 
-    def launch_pyramid_projections(self, ctx, side=None, forked=False):
+    def launch_pyramid_projections(self, ctx, side=None, forked=False, jit=False):
         """Issue every layer's query-independent GEMMs (ProjAttn.project_pyramid) on the side stream, each followed
         by an event its consumer waits on.  Returns the side stream (pass it to join_pyramid_projections before
         the forward / the captured graph ends) or None when the projections run inline.  forked: `side` already waits for
-        whatever produced ctx.feat (pack_pyramid)."""
+        whatever produced ctx.feat (pack_pyramid).  jit: the caller runs the whole forward inside ONE fork / join of `side` (not the
+        segmented graphs of mvgformer_amd.dist) -- the just-in-time schedule may be used."""
         if side is None:
             side = self.fork_side_stream(ctx.feat.device)
             if side is None:
@@ -746,18 +757,31 @@ class DQDecoder(MvPDecoder):
                 # bf16 fast path: layer 0's value planes + G in one launch (the first sampler waits for nothing else), then the
                 # remaining layers' products in launches of `pyramid_group` layers: every launch reads the pyramid through the
                 # fabric once (ops.pyramid_group_ws); 8 reads of 103 MB per forward at cfg-2 become 2.  These launches fill every
-                # CU (2 x 239 registers per SIMD lane) and so does the sampler: next to each other they run one after the other,
+                # CU (2 x 246 registers per SIMD lane) and so does the sampler: next to each other they run one after the other,
                 # whatever the issue order -- issuing a group behind the sampler in front of it, or with half the workgroups,
-                # measured slower (profiles/r05_experiments.txt), so everything is issued here, up front.
-                for group in groups:
-                    jobs = []
-                    for layer in group:
-                        jobs += layer.proj_attn.pyramid_jobs(ctx.feat)
-                    ops.pyramid_group_ws(ctx.feat, jobs)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    for layer in group:
-                        layer.proj_attn._vp_event = ev
+                # measured slower (profiles/r05_experiments.txt section 2).  What does pay (section 10): one launch per layer with ONE
+                # workgroup per CU, issued behind the previous layer's chain B (use_jit below).
+                use_jit = jit and len(self.layers) > 1 and (self.pyramid_jit == "1" or (self.pyramid_jit == "auto" and ctx.B == 1))
+                if use_jit:
+                    groups = [[l] for l in self.layers]
+                for gi, group in enumerate(groups):
+                    def issue(group=group, slots=(self.pyramid_jit_slots if (use_jit and gi > 0) else 0)):
+                        jobs = []
+                        for layer in group:
+                            jobs += layer.proj_attn.pyramid_jobs(ctx.feat)
+                        ops.pyramid_group_ws(ctx.feat, jobs, slots=slots)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        for layer in group:
+                            layer.proj_attn._vp_event = ev
+                    if use_jit and gi > 0:
+                        def hook(issue=issue):
+                            side.wait_stream(torch.cuda.current_stream())     # behind the previous layer's chain B
+                            with torch.cuda.stream(side):
+                                issue()
+                        self.layers[gi - 1]._after_chain_b = hook
+                    else:
+                        issue()
         return side
 
     def pack_pyramid(self, ctx, src_views, side):
@@ -835,7 +859,7 @@ class DQDecoder(MvPDecoder):
             if deferred_pack is not None:
                 self.pack_pyramid(ctx, deferred_pack, side)
             if side is not None:
-                self.launch_pyramid_projections(ctx, side, forked=True)
+                self.launch_pyramid_projections(ctx, side, forked=True, jit=True)
             # the fused chain writes every layer's hidden state straight into its slice of the stacked output
             hs_buf = None
             if self.return_intermediate and not torch.is_grad_enabled() and tgt.is_cuda:
@@ -875,6 +899,7 @@ class DQDecoder(MvPDecoder):
                 layer._next_layer = None
                 layer._xw_in = None
                 layer._proj_in = None
+                layer._after_chain_b = None
             self.join_pyramid_projections(side)
         if self.return_intermediate:
             in_place = hs_buf is not None and all(t.data_ptr() == hs_buf[i].data_ptr() and t.shape == hs_buf[i].shape

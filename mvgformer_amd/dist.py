@@ -260,7 +260,7 @@ class SpeculativeShardedDecoder:
             side = dec.fork_side_stream(tgt.device) if hasattr(dec, "fork_side_stream") else None
             if side is not None:
                 dec.pack_pyramid(ctx, src_views, side)
-                dec.launch_pyramid_projections(ctx, side, forked=True)
+                dec.launch_pyramid_projections(ctx, side, forked=True, jit=True)
             else:
                 ctx.pack(src_views)
             outs = []
