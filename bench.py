@@ -662,16 +662,17 @@ def main():
             live_frac = float(torch.stack(live_fracs).mean()) if live_fracs else None
             exec_rows_a = [int(x) for x in exec_rows_a] if len(exec_rows_a) == Ly else None
             # the grouped pyramid products of the timed schedule (DQDecoder.launch_pyramid_projections), each launch alone
-            if rank == 0 and hasattr(dec, "_pyramid_groups") and ctx.feat is not None and ctx.feat.dtype == torch.bfloat16:
-                groups = dec._pyramid_groups(ctx)
-                if groups:
+            if rank == 0 and hasattr(dec, "pyramid_launches") and ctx.feat is not None and ctx.feat.dtype == torch.bfloat16:
+                launches = dec.pyramid_launches(ctx)
+                if launches:
                     ops.PROFILE = {}
                     for _ in range(args.profile_steps):
-                        for grp in groups:
+                        for grp, slots in launches:
                             jobs = []
                             for layer in grp:
                                 jobs += layer.proj_attn.pyramid_jobs(ctx.feat)
-                            ops.pyramid_group_ws(ctx.feat, jobs)
+                            ops.pyramid_group_ws(ctx.feat, jobs, slots=slots,
+                                                 label="pyramid_group_ws_%d%s" % (len(jobs), "_jit" if slots else ""))
                     torch.cuda.synchronize()
                     prof.update(ops.profile_summary())
                     ops.PROFILE = None
@@ -795,6 +796,7 @@ def main():
         add("value_proj", "value_proj_ws", fl["value"], Ly)
         add("feat_linear", "feat_linear_ws", fl["G"], Ly)
         add("pyramid_group_first_layer", "pyramid_group_ws_2", fl["value"] + fl["G"], 1)
+        add("pyramid_group_one_layer_just_in_time", "pyramid_group_ws_2_jit", fl["value"] + fl["G"], Ly - 1)
         for nj in (4, 6, 8):
             add("pyramid_group_%d_layers" % (nj // 2), "pyramid_group_ws_%d" % nj, (fl["value"] + fl["G"]) * (nj // 2), 1)
         roof_mfma = {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "flops_nominal": fl["nominal"], "flops_executed": fl["executed"],

@@ -761,11 +761,10 @@ class DQDecoder(MvPDecoder):
                 # whatever the issue order -- issuing a group behind the sampler in front of it, or with half the workgroups,
                 # measured slower (profiles/r05_experiments.txt section 2).  What does pay (section 10): one launch per layer with ONE
                 # workgroup per CU, issued behind the previous layer's chain B (use_jit below).
-                use_jit = jit and len(self.layers) > 1 and (self.pyramid_jit == "1" or (self.pyramid_jit == "auto" and ctx.B == 1))
-                if use_jit:
-                    groups = [[l] for l in self.layers]
-                for gi, group in enumerate(groups):
-                    def issue(group=group, slots=(self.pyramid_jit_slots if (use_jit and gi > 0) else 0)):
+                use_jit = self._pyramid_jit(ctx, jit)
+                launches = self.pyramid_launches(ctx, jit)
+                for gi, (group, slots) in enumerate(launches):
+                    def issue(group=group, slots=slots):
                         jobs = []
                         for layer in group:
                             jobs += layer.proj_attn.pyramid_jobs(ctx.feat)
@@ -795,6 +794,20 @@ class DQDecoder(MvPDecoder):
             ctx.pack(src_views)
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
+
+    def _pyramid_jit(self, ctx, jit=True):
+        """True when a forward of this context issues one product launch per layer, just in time (launch_pyramid_projections)"""
+        return bool(jit and len(self.layers) > 1 and (self.pyramid_jit == "1" or (self.pyramid_jit == "auto" and ctx.B == 1)))
+
+    def pyramid_launches(self, ctx, jit=True):
+        """[(layers, workgroups per XCD; 0 = the kernel's default)]: the product launches of one forward in issue order
+        (bf16 fast path; None otherwise)"""
+        groups = self._pyramid_groups(ctx)
+        if groups is None:
+            return None
+        if self._pyramid_jit(ctx, jit):
+            return [([l], self.pyramid_jit_slots if i else 0) for i, l in enumerate(self.layers)]
+        return [(g, 0) for g in groups]
 
     def _pyramid_groups(self, ctx):
         """layers whose pyramid products share one launch (bf16 fast path), or None for one launch pair per layer"""

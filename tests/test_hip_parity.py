@@ -1191,20 +1191,30 @@ def test_side_stream_pyramid_projections_change_nothing():
         dec.overlap_pyramid = True
         assert dec.fork_side_stream(torch.device(DEV)) is not None
         torch.cuda.synchronize()
-        for _ in range(3):
-            got = run()
+        # both issue orders of the side stream: everything up front (grouped launches), and one launch per layer issued
+        # just in time behind the previous layer's chain B with one workgroup per CU (the default at one sample per forward)
+        assert dec.pyramid_jit == "auto"
+        assert [(len(g), s) for g, s in dec.pyramid_launches(ctx)] == [(1, 0)] + [(1, dec.pyramid_jit_slots)] * (len(dec.layers) - 1)
+        for jit in ("auto", "0", "1"):
+            dec.pyramid_jit = jit
+            if jit == "0":
+                assert [(len(g), s) for g, s in dec.pyramid_launches(ctx)] == [(1, 0), (len(dec.layers) - 1, 0)]
+            for _ in range(3):
+                got = run()
+                torch.cuda.synchronize()
+                for x, y in zip(ref, got[:4]):
+                    assert torch.equal(x, y)
+            assert all(l.proj_attn._vp_event is None for l in dec.layers)          # every event consumed / dropped
+            assert all(l._after_chain_b is None for l in dec.layers)               # every hook fired / removed
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = run()
+            for _ in range(5):
+                g.replay()
             torch.cuda.synchronize()
-            for x, y in zip(ref, got[:4]):
+            for x, y in zip(ref, out[:4]):
                 assert torch.equal(x, y)
-        assert all(l.proj_attn._vp_event is None for l in dec.layers)          # every event consumed / dropped
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = run()
-        for _ in range(5):
-            g.replay()
-        torch.cuda.synchronize()
-        for x, y in zip(ref, out[:4]):
-            assert torch.equal(x, y)
+        dec.pyramid_jit = "auto"
         # a decoder that shares one layer (one set of vh / G buffers) must fall back to the inline schedule
         shared = build_decoder_for_case(case, DEV, dtype=torch.bfloat16)
         shared.layers = torch.nn.ModuleList([shared.layers[0]] * len(shared.layers))
