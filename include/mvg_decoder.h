@@ -247,11 +247,13 @@ int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, fl
  * order (rows) i32 or NULL: tile row i of the launch works on row order[i] (mvg_bin_pairs: masked rows last).
  * o_masked (3) f32 or NULL: o of a row with inside == 0 (the MLP of a zero row; obtain it by running this entry
  * point on one masked row).  When given, 64-row tiles without a single in-image row only write attn = 0 and
- * o = o_masked instead of running the chain. */
+ * o = o_masked instead of running the chain.
+ * rows_per_image (0 = unknown): rows of one image when `order` is mvg_bin_pairs' (image by image, each image's masked rows
+ * last); lets the launch dispatch every image's leading tiles first (a scheduling hint: results do not depend on it). */
 int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
                         const void* W0, const float* b0, const void* W1, const float* b1,
                         const float* W2, const float* b2, void* attn, float* o,
-                        const int32_t* order, const float* o_masked, int rows, void* stream);
+                        const int32_t* order, const float* o_masked, int rows, int rows_per_image, void* stream);
 
 /* ---- fp32 path as fused kernels (fp32 storage, fp32-accurate products on the fp16 matrix pipe; csrc/f32s.hip) ----------------
  * The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75 dispatches float / double only; the Linears of
@@ -300,14 +302,16 @@ int mvg_pyramid_f32h(const float* feat, const void* Wv_planes, int wv_scale, con
  * Optional tail (W_next != NULL): xw_next (B*NQ*J, n_next) f32 = (tgt' + query_pos) @ W_next^T + b_next, the query
  * term of the NEXT layer's offsets/logits Linear (the xw operand of mvg_msda_gsamp), computed while the rows are in
  * LDS.  W_next: (256,256) bf16 fragment order, rows >= n_next zero; b_next: 256 f32 (zero padded); query_pos
- * (B*NQ*J, 256) f32 or NULL; n_next <= 256, multiple of 4. */
+ * (B*NQ*J, 256) f32 or NULL; n_next <= 256, multiple of 4.
+ * attn_inside (V, B*NQ*J) u8 or NULL: the in-image flags mvg_chain_attn_pose was given.  Rows of attn with flag 0 are zero
+ * by construction; with the flags the view mean does not read them (same sums, a third fewer bytes at cfg-2). */
 int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,
                                const float* g2, const float* be2, const void* W1, const float* b1,
                                const void* W2, const float* b2, const float* g3, const float* be3,
                                const float* Wc, const float* bc, float threshold,
                                const uint8_t* forced_valid, float* tgt_out, float* prob, uint8_t* valid,
                                int* any_valid, const float* query_pos, const void* W_next, const float* b_next,
-                               float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, void* stream);
+                               float* xw_next, int n_next, int B, int NQ, int J, int has_ffn, const uint8_t* attn_inside, void* stream);
 
 /* A.6-A.8 (dq_decoder.py:659-717,399-461,119-246,1013-1029; multiview.py:170-269):
  * 2D refinement, view-softmax confidence, un-crop, 5-iteration undistortion, DLT rows,

@@ -22,6 +22,51 @@
 // "B" operand, the weight fragment the "A" operand, so a lane ends with 4 consecutive output
 // columns of one row and writes the next stage's input back to LDS with 8-byte stores.
 #include "common.h"
+#include <type_traits>
+
+// Probe build only (tools/probes/stamps_chain.py, -DCHAIN_STAMPS): every workgroup appends one record
+// [kernel id | blockIdx, start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID, up to 12 s_memtime phase stamps] (16 words) to a device buffer.
+#ifdef CHAIN_STAMPS
+__device__ unsigned long long chain_stamps[8192 * 16];
+__device__ unsigned int chain_stamp_count;
+#define CSTAMP_DECL unsigned long long cst_[16]; cst_[0] = 0
+#define CSTAMP_REAL(i) cst_[i] = __builtin_amdgcn_s_memrealtime()
+#define CSTAMP(i) cst_[i] = __builtin_amdgcn_s_memtime()
+#define CSTAMP_FLUSH(kernel_id, flag)                                                                                     \
+  do {                                                                                                                    \
+    if (threadIdx.x == 0) {                                                                                               \
+      const unsigned slot = atomicAdd(&chain_stamp_count, 1u);                                                            \
+      if (slot < 8192) {                                                                                                  \
+        unsigned hw, xcc;                                                                                                 \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                                  \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                                \
+        cst_[0] = ((unsigned long long)(kernel_id) << 48) | ((unsigned long long)(flag) << 32) | blockIdx.x;              \
+        cst_[3] = ((unsigned long long)xcc << 32) | hw;                                                                   \
+        for (int i_ = 0; i_ < 16; ++i_) chain_stamps[slot * 16 + i_] = cst_[i_];                                          \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  } while (0)
+extern "C" int mvg_chain_read_stamps(unsigned long long* host, int max_records, int reset) {
+  unsigned n = 0;
+  hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(chain_stamp_count), sizeof(n));
+  if (e != hipSuccess) return -(int)e;
+  if (n > 8192) n = 8192;
+  if ((int)n > max_records) n = max_records;
+  if (host && n) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(chain_stamps), sizeof(unsigned long long) * 16 * n);
+  if (e != hipSuccess) return -(int)e;
+  if (reset) {
+    const unsigned z = 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(chain_stamp_count), &z, sizeof(z));
+    if (e != hipSuccess) return -(int)e;
+  }
+  return (int)n;
+}
+#else
+#define CSTAMP_DECL
+#define CSTAMP_REAL(i)
+#define CSTAMP(i)
+#define CSTAMP_FLUSH(kernel_id, flag)
+#endif
 
 #include "chain_dev.h"
 
@@ -37,7 +82,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
                                                       const float* __restrict__ W2, const float* __restrict__ b2,
                                                       bf16_t* __restrict__ attn, float* __restrict__ o,
                                                       const int* __restrict__ order, const float* __restrict__ o_masked,
-                                                      int R) {
+                                                      int R, int tiles_per_image) {
   static_assert(JN == 2 || NT == 512, "column-split mapping needs 8 wavefronts");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
@@ -45,7 +90,20 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   float* w2s = reinterpret_cast<float*>(smem + RM * ACT_PITCH + RM * sizeof(int));   // last pose layer (3 x 256 f32)
   int* keepf = reinterpret_cast<int*>(w2s + 768);                                    // in-image flag of every tile row
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.x * RM;
+  // Dispatch order.  mvg_bin_pairs orders the pairs image by image, every image's masked pairs last: with workgroup b on tile b
+  // the tiles that only write zeros are spread over the launch, take their share of the 2 x 256 workgroup slots of the first wave
+  // of dispatches, and the last image's computing tiles start when those retire (s_memrealtime stamps, cfg-2: 40-48 of ~400
+  // computing tiles 7-8 us late, the launch 34 instead of 31 us).  Workgroup b takes tile (b mod n_img) * tiles_per_image +
+  // b / n_img instead: every image's leading (computing) tiles are dispatched first.  Rows are independent: same results.
+  int tile = blockIdx.x;
+  if (tiles_per_image > 0) {
+    const int n_img = gridDim.x / tiles_per_image;
+    tile = (blockIdx.x % n_img) * tiles_per_image + blockIdx.x / n_img;
+  }
+  const int r0 = tile * RM;
+  CSTAMP_DECL;
+  CSTAMP_REAL(1);
+  CSTAMP(4);
 
   // Tile row i works on global row order[r0 + i] (the sampler's processing order: rows whose reference point is
   // outside the image come last, mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
@@ -75,6 +133,8 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
       og[1] = m1;
       og[2] = m2;
     }
+    CSTAMP_REAL(2);
+    CSTAMP_FLUSH(1, 0);
     return;
   }
 
@@ -96,7 +156,15 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
       *reinterpret_cast<f32x4*>(act + row * ACT_PITCH + v16 * 16) = (rid[row] >= 0) ? x[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  CSTAMP(5);
+#ifdef CHAIN_STAMPS
+  chain_a_body<RM, NT, JN, true>(act, rid, w2s, inside, Wp, bp, W0, b0, W1, b1, b2, attn, o, pf1, keepf, cst_);
+#else
   chain_a_body<RM, NT, JN, true>(act, rid, w2s, inside, Wp, bp, W0, b0, W1, b1, b2, attn, o, pf1, keepf);
+#endif
+  CSTAMP(12);
+  CSTAMP_REAL(2);
+  CSTAMP_FLUSH(1, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -152,7 +220,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     const float* __restrict__ Wc, const float* __restrict__ bc, float threshold, const uint8_t* __restrict__ forced,
     float* __restrict__ tgt_out, float* __restrict__ prob, uint8_t* __restrict__ valid, int* __restrict__ any_valid,
     const float* __restrict__ qpos, const bf16_t* __restrict__ Wn, const float* __restrict__ bn,
-    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn) {
+    float* __restrict__ xw_next, int n_next, int rows, int J, int nq_total, int has_ffn, const uint8_t* __restrict__ inside) {
   constexpr int RM = RMT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                       // RM x 256 bf16 : GEMM operand (mean, then t1)
@@ -172,6 +240,9 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   const int rpt = qpt * J;                               // real rows per tile (60)
   const int q0 = blockIdx.x * qpt, r0 = q0 * J;
   const int nrow = min(rpt, rows - r0);
+  CSTAMP_DECL;
+  CSTAMP_REAL(1);
+  CSTAMP(4);
   // All tiles walk the SAME weights; in lock-step the 32 tiles of an XCD would hit the same L2 channel at the same time
   // (stage_gemm).  The k-step order is rotated per wavefront (= per column group) and, per TILE, by half a weight: tiles
   // (blockIdx >> 3) even / odd -- neighbours on one XCD, whose L2 they share -- start 8 k-steps apart.  The stage GEMMs
@@ -186,6 +257,17 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   // cross-lane latencies.  tgt is fetched here, long before its use.
   constexpr int RPASS = (RM + 8 * NW - 1) / (8 * NW);   // 1 with 8 wavefronts, 2 with 4; RM = 32: wavefronts 4..7 have no rows
   const int rgrp = lane >> 3, part = lane & 7;
+  // in-image flags of this wavefront's (row, view) pairs for the view mean below: requested FIRST, so that the wait for them leaves
+  // everything behind them in flight (vmcnt counts in order).  Lane j holds the flag of row slot j >> 3 (chunk (j >> 4), half
+  // wavefront (j >> 3) & 1) and view v0 + (j & 7).
+  constexpr int NCHUNK = RM * 32 / NT;
+  auto load_flag = [&](int v0) -> unsigned {
+    const int slot = lane >> 3, view = v0 + (lane & 7);
+    const int trow = (slot >> 1) * (NT / 32) + wave * 2 + (slot & 1);
+    if (slot < 2 * NCHUNK && view < V) return inside[(long)view * rows + r0 + min(trow, nrow - 1)];
+    return 0u;
+  };
+  unsigned flag = inside ? load_flag(0) : 1u;
   constexpr int NLN = 9 * 256, NLNP = (NLN + NT - 1) / NT;
   float lnv[NLNP];
 #pragma unroll
@@ -203,64 +285,79 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       tg[ps][i] = *reinterpret_cast<const f32x4*>(tgt + (long)(r0 + min(ps * 8 * NW + wave * 8 + rgrp, nrow - 1)) * 256 +
                                                   (part + 8 * i) * 4);
 
-  // ---- mean over views (dq_decoder.py:770) -> act (bf16); two 16-byte chunks per thread and pass, 16 loads in flight
+  // ---- mean over views (dq_decoder.py:770) -> act (bf16): all NCHUNK 16-byte chunks of a thread x 8 views in flight at once.
+  // The phase is a chip-wide read burst (every tile wants its 5 x 32 KB of attn + 64 KB of tgt at the same time: ~60 MB at
+  // 6-7 TB/s, 20 k cycles): what shortens it is bytes.  Rows of attn whose reference point is outside their image are zero by
+  // construction (chain A: dq_decoder.py:585-586) -- a third of them at cfg-2 -- and with `inside` given they are not read:
+  // the lane reads a cached dummy line instead and selects +0, the value the row holds (bit-identical sums).
   {
     const float inv = 1.f / (float)V;
-    constexpr int NCHUNK = RM * 32 / NT;
-    static_assert(NCHUNK % 2 == 0, "chunks are processed in pairs");
-#pragma unroll 1
-    for (int i = 0; i < NCHUNK; i += 2) {
-      float s[2][8];
+    float sacc[NCHUNK][8];
+    long off[NCHUNK];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NCHUNK; ++u) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s[u][t] = 0.f;
-      long off[2];
+      for (int t = 0; t < 8; ++t) sacc[u][t] = 0.f;
+      const int c = u * NT + tid;
+      off[u] = (long)(r0 + min(c >> 5, nrow - 1)) * 256 + (c & 31) * 8;
+    }
+    const uint4* dummy = reinterpret_cast<const uint4*>(bu);
+    // views in groups of KV, UC chunks of the thread in flight together (clamped / dummy address + select instead of a guard: a
+    // guarded load makes hipcc wait vmcnt(0) per element).  Up to 5 views: one group, all chunks (20 loads); more: groups of 8, two chunks.
+    auto group = [&](auto kv_tag, auto uc_tag, int v0, int u0, unsigned long long m) {
+      constexpr int KV = decltype(kv_tag)::value, UC = decltype(uc_tag)::value;
+      uint4 x[UC][KV];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = (i + u) * NT + tid;
-        off[u] = (long)(r0 + min(c >> 5, nrow - 1)) * 256 + (c & 31) * 8;
-      }
-      // views in groups of 8 (clamped index + zero weight instead of a guard: a guarded load makes hipcc wait
-      // vmcnt(0) per element)
-      for (int v0 = 0; v0 < V; v0 += 8) {
-        uint4 x[2][8];
+      for (int u = 0; u < UC; ++u)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            x[u][k] = *reinterpret_cast<const uint4*>(attn + (long)min(v0 + k, V - 1) * rows * 256 + off[u]);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float wv = (v0 + k < V) ? 1.f : 0.f;
-            const unsigned w4[4] = {x[u][k].x, x[u][k].y, x[u][k].z, x[u][k].w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              s[u][2 * t] = fmaf(wv, __uint_as_float(w4[t] << 16), s[u][2 * t]);
-              s[u][2 * t + 1] = fmaf(wv, __uint_as_float(w4[t] & 0xffff0000u), s[u][2 * t + 1]);
-            }
-          }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = (i + u) * NT + tid, row = c >> 5, v16 = c & 31;
-        uint4 o;
-        unsigned* op = reinterpret_cast<unsigned*>(&o);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float a = row < nrow ? s[u][2 * t] * inv : 0.f, b = row < nrow ? s[u][2 * t + 1] * inv : 0.f;
-          op[t] = pack_bf16(a, b);
+        for (int k = 0; k < KV; ++k) {
+          const bool live = (v0 + k < V) && ((m >> (((u0 + u) * 2 + (lane >> 5)) * 8 + k)) & 1ull);
+          const uint4* src = reinterpret_cast<const uint4*>(attn + (long)min(v0 + k, V - 1) * rows * 256 + off[u0 + u]);
+          x[u][k] = *(live ? src : dummy);
         }
-        *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = o;
+#pragma unroll
+      for (int u = 0; u < UC; ++u)
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+          const bool live = (v0 + k < V) && ((m >> (((u0 + u) * 2 + (lane >> 5)) * 8 + k)) & 1ull);
+          const unsigned w4[4] = {x[u][k].x, x[u][k].y, x[u][k].z, x[u][k].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const unsigned w = live ? w4[t] : 0u;
+            sacc[u0 + u][2 * t] += __uint_as_float(w << 16);
+            sacc[u0 + u][2 * t + 1] += __uint_as_float(w & 0xffff0000u);
+          }
+        }
+    };
+    if (V <= 5) {
+      const unsigned long long m = inside ? __ballot(flag != 0) : ~0ull;
+      group(std::integral_constant<int, 5>{}, std::integral_constant<int, NCHUNK>{}, 0, 0, m);
+    } else {
+      for (int v0 = 0; v0 < V; v0 += 8) {
+        const unsigned long long m = inside ? __ballot(flag != 0) : ~0ull;
+        if (inside && v0 + 8 < V) flag = load_flag(v0 + 8);        // the next group's flags, in flight under this group's rows
+#pragma unroll
+        for (int u0 = 0; u0 < NCHUNK; u0 += 2) group(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, v0, u0, m);
       }
+    }
+#pragma unroll
+    for (int u = 0; u < NCHUNK; ++u) {
+      const int c = u * NT + tid, row = c >> 5, v16 = c & 31;
+      uint4 o;
+      unsigned* op = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a = row < nrow ? sacc[u][2 * t] * inv : 0.f, b = row < nrow ? sacc[u][2 * t + 1] * inv : 0.f;
+        op[t] = pack_bf16(a, b);
+      }
+      *reinterpret_cast<uint4*>(act + row * ACT_PITCH + v16 * 16) = o;
     }
   }
 #pragma unroll
   for (int i = 0; i < NLNP; ++i)
     if (i * NT + tid < NLN) lnp[i * NT + tid] = lnv[i];
   __syncthreads();
+  CSTAMP(5);
 
   // ---- u = feature_update_mlp(mean) ; x = u + bu ; t1 = LN2(tgt + x)   (dq_decoder.py:773-778)
   f32x16 acc[MT][JN], acc2[MT][JN];
@@ -270,6 +367,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   merge_acc<MT, JN>(acc, acc2);
   acc_to_x<MT, JN>(xb, acc, lnp + 1536, false, tid);
   __syncthreads();
+  CSTAMP(6);
 #pragma unroll
   for (int ps = 0; ps < RPASS; ++ps) {
     if (ps * 8 * NW + wave * 8 >= RM) continue;        // wavefront without rows (RM = 32)
@@ -303,16 +401,22 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   }
   __syncthreads();
 
-  // query_pos of the last row phase, fetched before the FFN hides the latency
+  // query_pos of the last row phase: requested behind the FFN's last weight fragment (vmcnt is in order: requested in front of the
+  // FFN, its first stage waited for these 64 KB per tile -- update + LN2 + FFN 51.7 k cycles against 46.3 k in the last layer,
+  // which has no next layer and loads no query_pos), consumed after the LN3 statistics
   f32x4 qp[RPASS][8];
+  auto load_qp = [&]() {
 #pragma unroll
-  for (int ps = 0; ps < RPASS; ++ps)
+    for (int ps = 0; ps < RPASS; ++ps)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      qp[ps][i] = (Wn && qpos)
-                      ? *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(ps * 8 * NW + wave * 8 + rgrp, nrow - 1)) * 256 +
-                                                        (part + 8 * i) * 4)
-                      : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 8; ++i)
+        qp[ps][i] = (Wn && qpos)
+                        ? *reinterpret_cast<const f32x4*>(qpos + (long)(r0 + min(ps * 8 * NW + wave * 8 + rgrp, nrow - 1)) * 256 +
+                                                          (part + 8 * i) * 4)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  if (!has_ffn) load_qp();
+  CSTAMP(7);
   const float bc0 = bc[0], bc1 = bc[1];
 
   if (has_ffn) {
@@ -336,13 +440,25 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
       stage_gemm<MT, 16, BRING, JN, true, true>(hbuf, W2 + (long)c * 16 * 1024, accy, tid, c == 0, rot + 3 * c + 1, 64 * 1024, pf, accy2);
       if (c < 3) ring_prefetch<16, BRING, JN, MT>(W1 + (long)(c + 1) * 256 * 256, pf, tid, rot + 3 * (c + 1));
       __syncthreads();                                                               // hbuf free for the next chunk
+      if (c == 0) CSTAMP(8);
+      if (c == 1) CSTAMP(9);
+      if (c == 2) CSTAMP(10);
+      if (c == 3) CSTAMP(11);
     }
+    load_qp();
+    if (Wn) ring_prefetch<16, BRING, JN, MT>(Wn, pf, tid, rot + 7);
     merge_acc<MT, JN>(accy, accy2);
     acc_to_x<MT, JN>(xb, accy, lnp + 1792, true, tid);                                   // x = t1 + Y + b2
     __syncthreads();
   }
+  CSTAMP(12);
 
   // ---- tgt' = LN3(x) (or t1 when the FFN is off) ; class head per row (dq_decoder.py:889-893)
+  // With a next layer (Wn) the tgt' rows stay in registers and are stored AFTER the query-term GEMM: vmcnt counts loads and
+  // stores in order, so every weight fragment that GEMM requests behind the 64-KB store burst of a tile waits for the burst
+  // (s_memrealtime stamps: LN3 + class head 5.9 k cycles without the GEMM, 17 k with it).  Its first fragments are requested here.
+  f32x4 ykeep[RPASS][8];
+  if (Wn && !has_ffn) ring_prefetch<16, BRING, JN, MT>(Wn, pf, tid, rot + 7);
 #pragma unroll
   for (int ps = 0; ps < RPASS; ++ps) {
     if (ps * 8 * NW + wave * 8 >= RM) continue;
@@ -373,7 +489,8 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c4 = part + 8 * i;
-      if (row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + c4 * 4) = y[i];
+      ykeep[ps][i] = y[i];
+      if (!Wn && row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + c4 * 4) = y[i];
       if (Wn) {   // operand of the next layer's query-term GEMM: tgt' + query_pos (bf16), into the now free act tile
         const f32x4 x = y[i] + qp[ps][i];
         uint2 pk;
@@ -393,6 +510,30 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     }
   }
   __syncthreads();
+  CSTAMP(13);
+  if (Wn) {
+    // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets/logits Linear
+    //      (projattn.py:180-181), computed while the rows are still in LDS (saves a 15 360-row GEMM launch and the
+    //      elementwise add per layer).  The barrier above ordered the act writes and the last xb reads.
+    stage_gemm<MT, 16, BRING, JN, true, true>(act, Wn, acc, tid, true, rot + 7, 16 * 1024, pf, acc2);
+#pragma unroll
+    for (int ps = 0; ps < RPASS; ++ps) {
+      if (ps * 8 * NW + wave * 8 >= RM) continue;
+      const int row = ps * 8 * NW + wave * 8 + rgrp;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (row < nrow) *reinterpret_cast<f32x4*>(tgt_out + (long)(r0 + row) * 256 + (part + 8 * i) * 4) = ykeep[ps][i];
+    }
+    merge_acc<MT, JN>(acc, acc2);
+    acc_to_x<MT, JN>(xb, acc, lnp + 2048, false, tid);
+    __syncthreads();
+    for (int row = wave; row < nrow; row += NW)
+      if (lane * 4 < n_next)
+        *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + row) * n_next + lane * 4) =
+            *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
+  }
+  CSTAMP(14);
+  // per-query probabilities and validity (after the query-term GEMM: no load of the kernel waits behind these stores)
   if (tid < qpt && q0 + tid < nq_total) {
     float p0 = 0.f, p1 = 0.f;
     for (int j = 0; j < J; ++j) {
@@ -408,19 +549,9 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
     valid[qi] = ok ? 1 : 0;
     if (ok) atomicOr(any_valid, 1);
   }
-  if (Wn) {
-    // ---- xw = (tgt' + query_pos) W_next^T + b_next: the query term of the NEXT layer's offsets/logits Linear
-    //      (projattn.py:180-181), computed while the rows are still in LDS (saves a 15 360-row GEMM launch and the
-    //      elementwise add per layer).  The barrier above ordered the act writes and the last xb reads.
-    stage_gemm<MT, 16, BRING, JN, false, true>(act, Wn, acc, tid, true, rot + 7, 16 * 1024, nullptr, acc2);
-    merge_acc<MT, JN>(acc, acc2);
-    acc_to_x<MT, JN>(xb, acc, lnp + 2048, false, tid);
-    __syncthreads();
-    for (int row = wave; row < nrow; row += NW)
-      if (lane * 4 < n_next)
-        *reinterpret_cast<f32x4*>(xw_next + (long)(r0 + row) * n_next + lane * 4) =
-            *reinterpret_cast<const f32x4*>(xb + row * XP + lane * 16);
-  }
+  CSTAMP(15);
+  CSTAMP_REAL(2);
+  CSTAMP_FLUSH(2, 1);
 }
 
 }  // namespace
@@ -433,8 +564,12 @@ int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A 
 template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
-                          float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
+                          float* o, const int* order, const float* o_masked, int rows, hipStream_t st, int rows_per_image = 0) {
   const size_t lds = RM * ACT_PITCH + 2 * RM * sizeof(int) + 768 * sizeof(float);
+  // image-interleaved dispatch (chain_a_kernel) when every image is a whole number of tiles
+  int tpi = 0;
+  if (order && rows_per_image > 0 && rows_per_image % RM == 0 && rows % rows_per_image == 0 && rows / rows_per_image > 1)
+    tpi = rows_per_image / RM;
   // the attribute is per DEVICE: a process that drives several GPUs configures the > 64-KB LDS kernels on each of them
   static bool configured[MVG_MAX_DEVICES] = {};
   int dev = 0;
@@ -447,7 +582,7 @@ static int launch_chain_a(const void* samp, const uint8_t* inside, const void* W
   }
   hipLaunchKernelGGL((chain_a_kernel<RM, NT, JN>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
                      (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, order,
-                     o_masked, rows);
+                     o_masked, rows, tpi);
   MVG_LAUNCH_CHECK();
   return 0;
 }
@@ -455,8 +590,9 @@ static int launch_chain_a(const void* samp, const uint8_t* inside, const void* W
 extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
                                    const void* W0, const float* b0, const void* W1, const float* b1, const float* W2,
                                    const float* b2, void* attn, float* o, const int32_t* order, const float* o_masked,
-                                   int rows, void* stream) {
-  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
+                                   int rows, int rows_per_image, void* stream) {
+  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0 || rows_per_image < 0)
+    return MVG_E_BADARG;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // Every variant computes a row bit-identically (stage GEMMs: the k-step order depends on the column group only; last pose layer:
@@ -465,10 +601,10 @@ extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, cons
   // workgroups on the chip (measured at cfg-2 with 128 / 256 / 512 queries: -2.6 / -0.6 / -1.4 % of the forward; the full 1024
   // queries are 1.4 % faster with 128-row tiles).
   if (g_auto_small && g_chain_rm == 128 && rows <= 320 * 128)
-    return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  if (g_chain_rm == 128) return launch_chain_a<128, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
-  return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+    return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
+  if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
+  if (g_chain_rm == 128) return launch_chain_a<128, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
+  return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
 }
 
 extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,
@@ -478,7 +614,7 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
                                           float* tgt_out, float* prob, uint8_t* valid, int* any_valid,
                                           const float* query_pos, const void* W_next, const float* b_next,
                                           float* xw_next, int n_next, int B, int NQ, int J, int has_ffn,
-                                          void* stream) {
+                                          const uint8_t* attn_inside, void* stream) {
   if (!attn || !tgt || !Wu || !bu || !g2 || !be2 || !Wc || !bc || !tgt_out || !prob || !valid || !any_valid) return MVG_E_BADARG;
   if (has_ffn && (!W1 || !b1 || !W2 || !b2 || !g3 || !be3)) return MVG_E_BADARG;
   if (V <= 0 || J <= 0 || J > 64 || B < 0 || NQ < 0) return MVG_E_BADARG;
@@ -507,7 +643,7 @@ extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* 
   hipLaunchKernelGGL((chain_b_kernel<R, NTH, JNN, ##__VA_ARGS__>), grid, dim3(NTH), lds, (hipStream_t)stream, (const bf16_t*)attn, V, tgt,  \
                      (const bf16_t*)Wu, bu, g2, be2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, g3, be3, Wc, bc,     \
                      threshold, forced_valid, tgt_out, prob, valid, any_valid, query_pos, (const bf16_t*)W_next, b_next, xw_next,  \
-                     n_next, rows, J, nq_total, has_ffn)
+                     n_next, rows, J, nq_total, has_ffn, attn_inside)
   if (small) MVG_CB(4, 512, 1, 32);
   else MVG_CB(4, 512, 1);
 #undef MVG_CB

@@ -2,6 +2,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef CSTAMP
+#define CSTAMP(i)
+#endif
+
 namespace {
 
 
@@ -231,7 +235,8 @@ __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* 
                                              const float* __restrict__ b0, const bf16_t* __restrict__ W1,
                                              const float* __restrict__ b1, const float* __restrict__ b2,
                                              bf16_t* __restrict__ attn, float* __restrict__ o,
-                                             f32x4 (*pf1)[JN] = nullptr, const int* __restrict__ keep_lds = nullptr) {
+                                             f32x4 (*pf1)[JN] = nullptr, const int* __restrict__ keep_lds = nullptr,
+                                             unsigned long long* cst_ = nullptr) {   // cst_: probe build only (CSTAMP)
   constexpr int MT = (JN == 1) ? RM / 32 : RM / 32 / (NT / 256);                  // row tiles per wave
   const int tid = threadIdx.x, lane = tid & 63, rl = lane & 31;
   const int row0 = (JN == 1) ? 0 : (tid >> 8) * MT * 32;
@@ -254,6 +259,7 @@ __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* 
   // before the barrier + epilogue that follow its k-loop (ring_prefetch).
   f32x4 pf[4][JN], bvr[JN][4];
   stage_gemm<MT, 16, 4, JN, PRE1>(act, Wp, acc, tid, true, rot, 16 * 1024, pf1);
+  CSTAMP(6);
   load_bias<JN>(bp, bvr, tid, MT * 32);
   ring_prefetch<16, 4, JN, MT>(W0, pf, tid, rot + 5);
   __builtin_amdgcn_sched_barrier(0);
@@ -268,18 +274,23 @@ __device__ __forceinline__ void chain_a_body(char* __restrict__ act, const int* 
       *reinterpret_cast<f32x4*>(attn + (long)g * 256 + v16 * 8) =
           *reinterpret_cast<const f32x4*>(act + row * ACT_PITCH + v16 * 16);
   }
+  CSTAMP(7);
   // pose_embed MLP layers 0, 1 (ReLU)
   stage_gemm<MT, 16, 4, JN, true>(act, W0, acc, tid, true, rot + 5, 16 * 1024, pf);
+  CSTAMP(8);
   load_bias<JN>(b0, bvr, tid, MT * 32);
   ring_prefetch<16, 4, JN, MT>(W1, pf, tid, rot + 10);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   write_act_pre<MT, JN>(act, acc, bvr, true, all, tid);
   __syncthreads();
+  CSTAMP(9);
   stage_gemm<MT, 16, 4, JN, true>(act, W1, acc, tid, true, rot + 10, 16 * 1024, pf);
   __syncthreads();
+  CSTAMP(10);
   write_act<MT, JN>(act, acc, b1, true, all, tid);
   __syncthreads();
+  CSTAMP(11);
   // last layer (3 outputs): TPR = 2 | 4 | 8 threads per row (RM = 128 | 64 | 32 rows on 256 threads, ...).  The 256-term dot
   // products are summed in an order that does NOT depend on TPR: eight 32-column chunk sums c0..c7 (each accumulated in column
   // order), then the balanced tree ((c0+c1)+(c2+c3)) + ((c4+c5)+(c6+c7)) -- inside a lane while it owns several chunks, across

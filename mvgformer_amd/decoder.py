@@ -537,7 +537,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
                                                 order=order, xw=xw_in)
             wts, o_masked = self._chain_a_weights(dt)
-            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
+            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked, rows_per_image=Lq)
         elif self._fuses_chains_f32(dt, Lq, ctx.levels)[0] and C == 256:
             # fp32, fused: G-sampling kernel + chain A on pre-split operands (csrc/f32s.hip); pairs in processing order, masked
             # pairs last (zero-filled by the sampler, all-masked tiles skipped by the chain)
@@ -595,7 +595,8 @@ class DQDecoderLayer(MvPDecoderLayer):
                 next_proj = (qp, Wn, bn, n_next)
             res = ops.chain_update_ffn_class(
                 attn, V, tgt32, *self._chain_b_weights(dt), threshold, B, NQ, J, forced, ffn, tgt_out=self._tgt_out,
-                any_valid=self._flag, next_query_proj=next_proj)
+                any_valid=self._flag, next_query_proj=next_proj,
+                attn_inside=inside.view(-1) if fuse_a else None)      # chain A wrote zeros for the pairs outside their image
             tgt_update, prob, valid, any_valid = res[:4]
             if next_proj is not None:
                 nxt._xw_in = res[4]

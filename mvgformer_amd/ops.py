@@ -589,10 +589,11 @@ def chain_update_ffn_class_f32h(attn, V, tgt, Wu, su, bu, g2, be2, W1, s1, b1, W
     return tgt_out, prob, valid, any_valid
 
 
-def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
+def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None, rows_per_image=0):
     """fused output_proj (* in-image mask) + 3-layer pose MLP; Wp/W0/W1 in swizzle_weight order.
     order (rows) i32: row processing order (bin_pairs: masked rows last); o_masked (3) f32 from
-    chain_masked_row_output: lets all-masked 64-row tiles skip the chain.
+    chain_masked_row_output: lets all-masked 64-row tiles skip the chain.  rows_per_image: rows of one image of bin_pairs'
+    order (dispatch hint: every image's computing tiles first; 0 = unknown).
     Returns (attn bf16 (rows,256), o f32 (rows,3))."""
     rows = samp.shape[0]
     attn = torch.empty((rows, 256), dtype=torch.bfloat16, device=samp.device)
@@ -603,7 +604,7 @@ def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_
       L.check(L.load().mvg_chain_attn_pose(L.ptr(samp), L.ptr(inside), L.ptr(Wp), L.ptr(bp), L.ptr(W0), L.ptr(b0), L.ptr(W1),
                                            L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
                                            None if order is None else L.ptr(order),
-                                           None if o_masked is None else L.ptr(o_masked), rows, L.stream_ptr()),
+                                           None if o_masked is None else L.ptr(o_masked), rows, int(rows_per_image), L.stream_ptr()),
               "mvg_chain_attn_pose")
     return attn, o
 
@@ -623,8 +624,9 @@ def chain_masked_row_output(Wp, bp, W0, b0, W1, b1, W2, b2):
 
 
 def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be3, Wc, bc, threshold, B, NQ, J,
-                           forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None):
+                           forced_valid=None, has_ffn=True, tgt_out=None, any_valid=None, next_query_proj=None, attn_inside=None):
     """fused view-mean + update MLP + LN2 + FFN + LN3 + class head (weights in swizzle_weight order).
+    attn_inside (V * rows) u8: chain A's in-image flags -- attn rows with flag 0 are zero and are not read.
     Returns (tgt_update f32 (B*NQ*J,256), prob (B,NQ,2), valid (B,NQ) u8, any_valid int32[1])."""
     dev = attn.device
     rows = B * NQ * J
@@ -647,12 +649,14 @@ def chain_update_ffn_class(attn, V, tgt, Wu, bu, g2, be2, W1, b1, W2, b2, g3, be
         xw_next = torch.empty((rows, n_next), dtype=torch.float32, device=dev)
     if any_valid is None:       # else: a caller-owned int32[1] that is already zero
         any_valid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    if attn_inside is not None:
+        assert attn_inside.dtype == torch.uint8 and attn_inside.numel() == V * rows and attn_inside.is_contiguous()
     with _timed("chain_update_ffn_class"):
       L.check(L.load().mvg_chain_update_ffn_class(
           L.ptr(attn), V, L.ptr(tgt), L.ptr(Wu), L.ptr(bu), L.ptr(g2), L.ptr(be2), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
           L.ptr(g3), L.ptr(be3), L.ptr(Wc), L.ptr(bc), float(threshold), L.ptr(forced_valid), L.ptr(tgt_out), L.ptr(prob),
           L.ptr(valid), L.ptr(any_valid), L.ptr(qpos), L.ptr(Wn), L.ptr(bn), L.ptr(xw_next), n_next, B, NQ, J,
-          1 if has_ffn else 0, L.stream_ptr()), "mvg_chain_update_ffn_class")
+          1 if has_ffn else 0, L.ptr(attn_inside), L.stream_ptr()), "mvg_chain_update_ffn_class")
     if next_query_proj is not None:
         return tgt_out, prob, valid, any_valid, xw_next
     return tgt_out, prob, valid, any_valid

@@ -950,6 +950,17 @@ def test_chain_a_row_order_and_masked_tile_skip():
         assert torch.equal(o1[inside != 0], o0[inside != 0])
         assert torch.equal(attn1[inside == 0], torch.zeros_like(attn1[inside == 0]))
         assert float((o1[inside == 0] - o_masked).abs().max()) <= 2e-3 * float(o0.abs().max())
+    # rows_per_image: the image-interleaved dispatch (workgroup b on tile (b mod n_img) * tiles_per_image + b / n_img) is a
+    # scheduling hint -- 4 "images" of 3 x 128 rows, per-image order with each image's masked rows last, as mvg_bin_pairs gives it
+    rpi, n_img = 384, 4
+    rows = rpi * n_img
+    samp = torch.randn(rows, 256, device=DEV).to(torch.bfloat16)
+    inside = (torch.rand(rows, device=DEV) < 0.6).to(torch.uint8)
+    order = torch.cat([n * rpi + torch.argsort(1 - inside[n * rpi:(n + 1) * rpi].int(), stable=True) for n in range(n_img)]).to(torch.int32)
+    ref = ops.chain_attn_pose(samp, inside, *wts, order=order, o_masked=o_masked)
+    for hint in (rpi, 2 * rpi, 100, rows):            # whole tiles per image: interleaved; otherwise the plain dispatch
+        got = ops.chain_attn_pose(samp, inside, *wts, order=order, o_masked=o_masked, rows_per_image=hint)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
 
 
 def test_pyramid_producer_handoff_layouts():
