@@ -353,7 +353,10 @@ extern "C" int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njob
     if (planes[j] ? (N[j] != 256 || !bias[j]) : N[j] != 192) return MVG_E_BADARG;     // the two shapes the decoder has
     gp.job[j].Wf = (const bf16_t*)Wf[j]; gp.job[j].bias = bias[j]; gp.job[j].out = out[j];
     gp.job[j].N = N[j]; gp.job[j].rowmajor = planes[j] ? 0 : 1;
-    weight[j] = planes[j] ? 400 : g_wreg_gweight;
+    // A launch with at most one workgroup per CU (the just-in-time launches) is bound by a workgroup's own tile loop, not by HBM: every
+    // workgroup then needs the same number of tiles, whatever its job's columns (s_memtime stamps in the forward: 2 430 cycles per
+    // tile for both jobs; at 18 : 13 slots the G workgroups ran 56 tiles against 44 and finished 9 us late; 16 : 16: forward -2.2 %).
+    weight[j] = planes[j] ? 400 : (slots_per_xcd > 0 && slots_per_xcd <= 32 ? 400 : g_wreg_gweight);
     total += weight[j];
   }
   // slots per XCD in proportion to the jobs' work; never more than the 64 resident workgroups of an XCD

@@ -703,7 +703,7 @@ class DQDecoder(MvPDecoder):
         # Cache (137 -> 128 us) and the first sampler has the chip to itself: -2.8 ... -3.1 % at cfg-2, -2 % at cfg-5, +2 % at two samples
         # per forward (profiles/r05_experiments.txt section 10).  MVG_PYRAMID_JIT = 0 | 1 overrides the choice.
         self.pyramid_jit = os.environ.get("MVG_PYRAMID_JIT", "auto")
-        self.pyramid_jit_slots = 32
+        self.pyramid_jit_slots = int(os.environ.get("MVG_PYRAMID_JIT_SLOTS", "32"))
         pool = {}
         for layer in self.layers:       # the inline fp32 pyramid products share one (value, G) pair per stream -- of THIS decoder
             layer.proj_attn._f32_pool = pool

@@ -31,7 +31,7 @@ with torch.no_grad():
     for _ in range(200):
         graph.replay()
     torch.cuda.synchronize()
-nb = 512
+nb = 256
 buf = (C.c_ulonglong * (64 * nb))()
 lib.mvg_wreg_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mvg_wreg_read_stamps(buf, nb) == 0
@@ -39,7 +39,13 @@ t = np.frombuffer(buf, dtype=np.uint64).reshape(nb * 4, 16).astype(np.int64)
 live = t[(t[:, 12] > 0) & (t[:, 14] > t[:, 13])]
 real_ns = (live[:, 14] - live[:, 13]) * 10.0
 ticks = live[:, 11] - live[:, 8]
-print("last grouped launch of the forward (layers 1-3): %d wavefronts, %.1f tiles each; lifetime %d ticks = %.1f us -> %.3f GHz; span %.1f us" % (
+print("last product launch of the forward (just-in-time schedule: one layer, one workgroup per CU; records of earlier launches with more workgroups may be mixed in): %d wavefronts, %.1f tiles each; lifetime %d ticks = %.1f us -> %.3f GHz; span %.1f us" % (
     len(live), np.median(live[:, 12]), np.median(ticks), np.median(real_ns) / 1e3, np.median(ticks / real_ns),
     (live[:, 14].max() - live[:, 13].min()) / 100.0))
 print("per tile: %d ticks" % np.median((live[:, 10] - live[:, 9]) / live[:, 12]))
+t = t[: nb * 4]
+w = t[(t[:, 6] > 0) & (t[:, 12] > 0)]
+d = np.diff(w[:, [0, 1, 2, 5, 6]], axis=1)
+for i, nm in enumerate(("vmcnt wait", "barrier", "k loop", "epilogue")):
+    print("  %-12s %6.0f (%6.0f .. %6.0f)" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+print("  tiles per wavefront: %s" % dict(zip(*np.unique(live[:, 12], return_counts=True))))
