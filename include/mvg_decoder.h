@@ -212,9 +212,13 @@ int mvg_msda_gsamp(const void* vh, const void* G, const float* xw, const float* 
 
 /* Processing order for mvg_msda_gsamp: per image, the Lq (image, query) pairs counting-sorted by the Morton code of
  * the level-0 cell block of their reference point, pairs with inside == 0 last.  order (N_img*Lq) int32 holds
- * global pair indices (n*Lq + q); it changes where a pair is computed, never its result.  inside may be NULL.
+ * global pair indices (n*Lq + q), a permutation of all of them; it changes where a pair is computed, never its result.
+ * inside may be NULL.
  * workspace: device scratch of at least mvg_bin_pairs_workspace(N_img, Lq) bytes (0 for small Lq), or NULL: with it,
- * images with many pairs are sorted by 8 workgroups each (two kernels) instead of one. */
+ * images with many pairs are sorted by 8 workgroups each (two kernels) instead of one.
+ * Layout: with the workspace (>= 8192 pairs per image) the in-image pairs of ALL images come first, image by image, then the
+ * pairs with inside == 0, image by image -- consumers that skip the latter then find them in one run at the end of their launch
+ * instead of one run per image; without it every image's Lq entries are [its in-image pairs | its other pairs]. */
 size_t mvg_bin_pairs_workspace(int N_img, int Lq);
 int mvg_bin_pairs(const float* ref_lvl, const uint8_t* inside, const int64_t* shapes_host, int L, int32_t* order,
                   int N_img, int Lq, void* workspace, size_t workspace_bytes, void* stream);
@@ -247,13 +251,11 @@ int mvg_rowdot3(const void* h, int h_dtype, const float* W3, const float* b3, fl
  * order (rows) i32 or NULL: tile row i of the launch works on row order[i] (mvg_bin_pairs: masked rows last).
  * o_masked (3) f32 or NULL: o of a row with inside == 0 (the MLP of a zero row; obtain it by running this entry
  * point on one masked row).  When given, 64-row tiles without a single in-image row only write attn = 0 and
- * o = o_masked instead of running the chain.
- * rows_per_image (0 = unknown): rows of one image when `order` is mvg_bin_pairs' (image by image, each image's masked rows
- * last); lets the launch dispatch every image's leading tiles first (a scheduling hint: results do not depend on it). */
+ * o = o_masked instead of running the chain. */
 int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
                         const void* W0, const float* b0, const void* W1, const float* b1,
                         const float* W2, const float* b2, void* attn, float* o,
-                        const int32_t* order, const float* o_masked, int rows, int rows_per_image, void* stream);
+                        const int32_t* order, const float* o_masked, int rows, void* stream);
 
 /* ---- fp32 path as fused kernels (fp32 storage, fp32-accurate products on the fp16 matrix pipe; csrc/f32s.hip) ----------------
  * The reference's arithmetic is fp32 (lib/models/ops/src/cuda/deform_cuda.cu:75 dispatches float / double only; the Linears of

@@ -41,7 +41,7 @@ SIGNATURES = {
     "mvg_linear_sum": [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "mvg_msda_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvg_msda_gfused_f32": [_vp] * 9 + [_i] * 5 + [_vp],
-    "mvg_chain_attn_pose": [_vp] * 14 + [_i, _i, _vp],
+    "mvg_chain_attn_pose": [_vp] * 14 + [_i, _vp],
     "mvg_chain_update_ffn_class": [_vp, _i] + [_vp] * 13 + [_f] + [_vp] * 9 + [_i] * 5 + [_vp, _vp],
     "mvg_chain_update_ffn_class_f32h": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],

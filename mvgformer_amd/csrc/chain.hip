@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
                                                       const float* __restrict__ W2, const float* __restrict__ b2,
                                                       bf16_t* __restrict__ attn, float* __restrict__ o,
                                                       const int* __restrict__ order, const float* __restrict__ o_masked,
-                                                      int R, int tiles_per_image) {
+                                                      int R) {
   static_assert(JN == 2 || NT == 512, "column-split mapping needs 8 wavefronts");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
@@ -90,23 +90,13 @@ __global__ __launch_bounds__(NT, 2) void chain_a_kernel(const bf16_t* __restrict
   float* w2s = reinterpret_cast<float*>(smem + RM * ACT_PITCH + RM * sizeof(int));   // last pose layer (3 x 256 f32)
   int* keepf = reinterpret_cast<int*>(w2s + 768);                                    // in-image flag of every tile row
   const int tid = threadIdx.x;
-  // Dispatch order.  mvg_bin_pairs orders the pairs image by image, every image's masked pairs last: with workgroup b on tile b
-  // the tiles that only write zeros are spread over the launch, take their share of the 2 x 256 workgroup slots of the first wave
-  // of dispatches, and the last image's computing tiles start when those retire (s_memrealtime stamps, cfg-2: 40-48 of ~400
-  // computing tiles 7-8 us late, the launch 34 instead of 31 us).  Workgroup b takes tile (b mod n_img) * tiles_per_image +
-  // b / n_img instead: every image's leading (computing) tiles are dispatched first.  Rows are independent: same results.
-  int tile = blockIdx.x;
-  if (tiles_per_image > 0) {
-    const int n_img = gridDim.x / tiles_per_image;
-    tile = (blockIdx.x % n_img) * tiles_per_image + blockIdx.x / n_img;
-  }
-  const int r0 = tile * RM;
+  const int r0 = blockIdx.x * RM;
   CSTAMP_DECL;
   CSTAMP_REAL(1);
   CSTAMP(4);
 
-  // Tile row i works on global row order[r0 + i] (the sampler's processing order: rows whose reference point is
-  // outside the image come last, mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
+  // Tile row i works on global row order[r0 + i] (the sampler's processing order: the rows whose reference point is outside
+  // their image come last, behind the in-image rows of ALL images -- the computing tiles lead the launch; mvg_bin_pairs) or r0 + i.  A tile without a single in-image row has attn = 0
   // and o = the MLP of a zero row for all of its rows: o_masked holds that row's result (computed by this very
   // kernel on one masked row), so such tiles only write their outputs.
   for (int i = tid; i < 768; i += NT) w2s[i] = W2[i];      // read by every thread in the last stage: LDS, not 96 global loads each
@@ -564,12 +554,8 @@ int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A 
 template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
-                          float* o, const int* order, const float* o_masked, int rows, hipStream_t st, int rows_per_image = 0) {
+                          float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
   const size_t lds = RM * ACT_PITCH + 2 * RM * sizeof(int) + 768 * sizeof(float);
-  // image-interleaved dispatch (chain_a_kernel) when every image is a whole number of tiles
-  int tpi = 0;
-  if (order && rows_per_image > 0 && rows_per_image % RM == 0 && rows % rows_per_image == 0 && rows / rows_per_image > 1)
-    tpi = rows_per_image / RM;
   // the attribute is per DEVICE: a process that drives several GPUs configures the > 64-KB LDS kernels on each of them
   static bool configured[MVG_MAX_DEVICES] = {};
   int dev = 0;
@@ -582,7 +568,7 @@ static int launch_chain_a(const void* samp, const uint8_t* inside, const void* W
   }
   hipLaunchKernelGGL((chain_a_kernel<RM, NT, JN>), dim3((rows + RM - 1) / RM), dim3(NT), lds, st, (const bf16_t*)samp, inside,
                      (const bf16_t*)Wp, bp, (const bf16_t*)W0, b0, (const bf16_t*)W1, b1, W2, b2, (bf16_t*)attn, o, order,
-                     o_masked, rows, tpi);
+                     o_masked, rows);
   MVG_LAUNCH_CHECK();
   return 0;
 }
@@ -590,9 +576,8 @@ static int launch_chain_a(const void* samp, const uint8_t* inside, const void* W
 extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, const void* Wp, const float* bp,
                                    const void* W0, const float* b0, const void* W1, const float* b1, const float* W2,
                                    const float* b2, void* attn, float* o, const int32_t* order, const float* o_masked,
-                                   int rows, int rows_per_image, void* stream) {
-  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0 || rows_per_image < 0)
-    return MVG_E_BADARG;
+                                   int rows, void* stream) {
+  if (!samp || !inside || !Wp || !bp || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !attn || !o || rows < 0) return MVG_E_BADARG;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   // Every variant computes a row bit-identically (stage GEMMs: the k-step order depends on the column group only; last pose layer:
@@ -601,10 +586,10 @@ extern "C" int mvg_chain_attn_pose(const void* samp, const uint8_t* inside, cons
   // workgroups on the chip (measured at cfg-2 with 128 / 256 / 512 queries: -2.6 / -0.6 / -1.4 % of the forward; the full 1024
   // queries are 1.4 % faster with 128-row tiles).
   if (g_auto_small && g_chain_rm == 128 && rows <= 320 * 128)
-    return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
-  if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
-  if (g_chain_rm == 128) return launch_chain_a<128, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
-  return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st, rows_per_image);
+    return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 256) return launch_chain_a<256, 512, 1>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  if (g_chain_rm == 128) return launch_chain_a<128, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
+  return launch_chain_a<64, 256, 2>(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, attn, o, order, o_masked, rows, st);
 }
 
 extern "C" int mvg_chain_update_ffn_class(const void* attn, int V, const float* tgt, const void* Wu, const float* bu,

@@ -865,13 +865,40 @@ __global__ __launch_bounds__(1024) void bin_count_kernel(const float* __restrict
   if (tid == 0) *reinterpret_cast<uint4*>(dst + BIN_KEYS) = *reinterpret_cast<const uint4*>(&hist[BIN_KEYS]);
 }
 
+// Layout of `order` (this variant): the in-image pairs of ALL images first (image by image, Morton order inside an image), then
+// the pairs outside their image (image by image).  With every image's outside pairs behind its own in-image pairs, a consumer that
+// walks the order in workgroups of 64 slots met a run of do-nothing workgroups per image: they took their share of the dispatch
+// slots and the chip ran 30-40 % under-occupied for ~10 us five times per sampler launch (s_memrealtime stamps per workgroup,
+// tools/probes/stamps_gsamp.py: sampler 127 -> 116 us); chain A's computing tiles now lead its launch by themselves.  The offsets
+// of the other images come from their parts' "outside" counters (N_img x BIN_PARTS words, one per thread).
 template <int KPT>
 __global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __restrict__ cnt,
                                                            const unsigned short* __restrict__ keys_in,
                                                            int* __restrict__ order, int Lq, int Lp) {
   __shared__ int hist[BIN_KEYS + 4];
   __shared__ int wave_tot[16];
+  __shared__ int out_sums[2];           // outside pairs of the images before this one | of all images
   const int n = blockIdx.x / BIN_PARTS, part = blockIdx.x % BIN_PARTS, tid = threadIdx.x;
+  const int n_img = gridDim.x / BIN_PARTS;
+  if (tid < 2) out_sums[tid] = 0;
+  __syncthreads();
+  {
+    int before = 0, all = 0;
+    for (int i = tid; i < n_img * BIN_PARTS; i += 1024) {
+      const int v = (int)cnt[(long)i * BIN_CNT_STRIDE + BIN_KEYS];
+      all += v;
+      before += (i / BIN_PARTS < n) ? v : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      before += __shfl_xor(before, off, 64);
+      all += __shfl_xor(all, off, 64);
+    }
+    if ((tid & 63) == 0 && all) {
+      atomicAdd(&out_sums[0], before);
+      atomicAdd(&out_sums[1], all);
+    }
+  }
   const int q0 = part * Lp, nq = max(0, min(Lp, Lq - q0));
   int key[KPT];
 #pragma unroll
@@ -914,6 +941,11 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __res
   hist[4 * tid + 3] = ex + tot[0] + tot[1] + tot[2] + before[3];
   if (tid == 0) hist[BIN_KEYS] = total + out_before;          // the "outside" pairs go last
   __syncthreads();
+  // image-local position -> position in the launch-wide order: in-image pairs behind those of the images before, outside pairs
+  // behind ALL in-image pairs and the outside pairs of the images before
+  const int out_prev = out_sums[0], out_all = out_sums[1];
+  const long in_base = (long)n * Lq - out_prev;                              // in-image pairs of images < n
+  const long out_base = (long)n_img * Lq - out_all + out_prev - total;       // (+ local position, which starts at `total`)
 #pragma unroll
   for (int k = 0; k < KPT; ++k) {
     const bool live = tid + 1024 * k < nq;
@@ -925,7 +957,7 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __res
     if (outm && (tid & 63) == 0) obase = atomicAdd(&hist[BIN_KEYS], __popcll(outm));
     obase = __shfl(obase, 0, 64);
     if (out) pos = obase + __popcll(outm & ((1ull << (tid & 63)) - 1ull));
-    if (live) order[(long)n * Lq + pos] = n * Lq + q0 + tid + 1024 * k;
+    if (live) order[(out ? out_base : in_base) + pos] = n * Lq + q0 + tid + 1024 * k;
   }
 }
 

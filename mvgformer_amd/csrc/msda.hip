@@ -818,6 +818,28 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
 //     are issued back to back (sched_barrier: hipcc otherwise sinks them to their uses); the blend is 64
 //     v_dot2c_f32_bf16 per batch, fp32 accumulation, no bf16->fp32 unpacking.  (The bilinear x attention
 //     weights are rounded to bf16; products and sums are fp32.)
+// Probe build only (-DGSAMP_STAMPS, tools/probes/stamps_gsamp.py): wavefront 0 of every workgroup appends [blockIdx, start, end
+// (s_memrealtime), HW_ID | XCC_ID << 32, lanes that sampled] to a device buffer.
+#ifdef GSAMP_STAMPS
+__device__ unsigned long long gsamp_stamps[65536 * 4];
+__device__ unsigned int gsamp_stamp_count;
+extern "C" int mvg_gsamp_read_stamps(unsigned long long* host, int max_records, int reset) {
+  unsigned n = 0;
+  hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(gsamp_stamp_count), sizeof(n));
+  if (e != hipSuccess) return -(int)e;
+  if (n > 65536) n = 65536;
+  if ((int)n > max_records) n = max_records;
+  if (host && n) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(gsamp_stamps), sizeof(unsigned long long) * 4 * n);
+  if (e != hipSuccess) return -(int)e;
+  if (reset) {
+    const unsigned z = 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(gsamp_stamp_count), &z, sizeof(z));
+    if (e != hipSuccess) return -(int)e;
+  }
+  return (int)n;
+}
+#endif
+
 template <int L, int NT, int PIPE = 0>   // NT threads per workgroup = NT/4 consecutive slots of the processing order, one head
 __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                                 const float* __restrict__ xw, const float* __restrict__ r,
@@ -847,6 +869,26 @@ __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, c
   // leave early (no workgroup barrier below): slots past the end, and pairs the caller masks out (reference
   // points outside the image: the consumer multiplies their rows by 0, dq_decoder.py:585-586) -- zero-filled.
   const int slot = pblk * (NT / 4) + wave * 16 + pl;
+#ifdef GSAMP_STAMPS
+  const unsigned long long gs_t0 = __builtin_amdgcn_s_memrealtime();
+  auto gs_flush = [&](bool sampled) {
+    const unsigned long long act = __ballot(sampled);
+    // (lane 0 may have left: the first lane still here writes)
+    const int first = __ffsll((unsigned long long)__ballot(true)) - 1;
+    if (wave == 0 && lane == first) {
+      const unsigned s_ = atomicAdd(&gsamp_stamp_count, 1u);
+      if (s_ < 65536) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        gsamp_stamps[s_ * 4] = blockIdx.x | ((unsigned long long)__popcll(act) << 32);
+        gsamp_stamps[s_ * 4 + 1] = gs_t0;
+        gsamp_stamps[s_ * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        gsamp_stamps[s_ * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+      }
+    }
+  };
+#endif
   if (slot >= n_pairs) return;
   const int pair = order ? order[slot] : slot;
   // the pair's reference points are requested WITH its mask byte, not after it (one round trip less in front of phase A;
@@ -861,6 +903,9 @@ __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, c
   float acc[8];
   gsamp_unit<L, PIPE>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc, rpre);
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
+#ifdef GSAMP_STAMPS
+  gs_flush(true);
+#endif
 }
 
 // (hipcc's own allocation is 101 VGPRs = 4 wavefronts per SIMD; a build pinned to 5 per SIMD -- 96 VGPRs, 5 dwords of scratch

@@ -537,7 +537,7 @@ class DQDecoderLayer(MvPDecoderLayer):
             samp = self.proj_attn.native_sample(x, ref_lvl, ctx.feat, ctx.levels, V, B, pair_mask=inside.view(-1),
                                                 order=order, xw=xw_in)
             wts, o_masked = self._chain_a_weights(dt)
-            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked, rows_per_image=Lq)
+            attn, o = ops.chain_attn_pose(samp, inside.view(-1), *wts, order=order, o_masked=o_masked)
         elif self._fuses_chains_f32(dt, Lq, ctx.levels)[0] and C == 256:
             # fp32, fused: G-sampling kernel + chain A on pre-split operands (csrc/f32s.hip); pairs in processing order, masked
             # pairs last (zero-filled by the sampler, all-masked tiles skipped by the chain)

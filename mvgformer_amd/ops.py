@@ -589,11 +589,10 @@ def chain_update_ffn_class_f32h(attn, V, tgt, Wu, su, bu, g2, be2, W1, s1, b1, W
     return tgt_out, prob, valid, any_valid
 
 
-def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None, rows_per_image=0):
+def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_masked=None):
     """fused output_proj (* in-image mask) + 3-layer pose MLP; Wp/W0/W1 in swizzle_weight order.
     order (rows) i32: row processing order (bin_pairs: masked rows last); o_masked (3) f32 from
-    chain_masked_row_output: lets all-masked 64-row tiles skip the chain.  rows_per_image: rows of one image of bin_pairs'
-    order (dispatch hint: every image's computing tiles first; 0 = unknown).
+    chain_masked_row_output: lets all-masked 64-row tiles skip the chain.
     Returns (attn bf16 (rows,256), o f32 (rows,3))."""
     rows = samp.shape[0]
     attn = torch.empty((rows, 256), dtype=torch.bfloat16, device=samp.device)
@@ -604,7 +603,7 @@ def chain_attn_pose(samp, inside, Wp, bp, W0, b0, W1, b1, W2, b2, order=None, o_
       L.check(L.load().mvg_chain_attn_pose(L.ptr(samp), L.ptr(inside), L.ptr(Wp), L.ptr(bp), L.ptr(W0), L.ptr(b0), L.ptr(W1),
                                            L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(attn), L.ptr(o),
                                            None if order is None else L.ptr(order),
-                                           None if o_masked is None else L.ptr(o_masked), rows, int(rows_per_image), L.stream_ptr()),
+                                           None if o_masked is None else L.ptr(o_masked), rows, L.stream_ptr()),
               "mvg_chain_attn_pose")
     return attn, o
 

@@ -870,6 +870,30 @@ def test_bf16_fast_path_matches_generic_kernels():
     assert float((a - b).abs().mean()) < 4e-3 * float(a.abs().max())
 
 
+def _per_image_order(order, inside):
+    """mvg_bin_pairs' order as (n_img, Lq) rows "image n's pairs: in-image ones in processing order, then the others", whichever of the
+    two layouts the call produced: per image [in-image | outside] (single-workgroup variant), or launch-wide [in-image pairs of all
+    images, image by image | outside pairs of all images, image by image] (multi-workgroup variant).  Checks the layout on the way."""
+    n_img, Lq = inside.shape
+    order = order.view(-1).long()
+    assert torch.equal(torch.sort(order).values, torch.arange(n_img * Lq, device=order.device))          # a permutation of all pairs
+    img = order // Lq
+    fl = inside.view(-1)[order].bool()
+    per_image = bool((img.view(n_img, Lq) == torch.arange(n_img, device=order.device)[:, None]).all())
+    if not per_image:
+        n_in = int(fl.sum())
+        assert bool(fl[:n_in].all()) and not bool(fl[n_in:].any())                                       # in-image pairs of ALL images first
+        assert bool((img[:n_in][1:] >= img[:n_in][:-1]).all()) and bool((img[n_in:][1:] >= img[n_in:][:-1]).all())   # image by image
+    rows = []
+    for n in range(n_img):
+        mine = order[img == n]
+        f = inside.view(-1)[mine].bool()
+        k = int(f.sum())
+        assert bool(f[:k].all()) and not bool(f[k:].any())
+        rows.append(mine)
+    return torch.stack(rows)
+
+
 def test_pair_binning_and_masked_sampling_are_exact():
     """mvg_bin_pairs: a permutation per image, in-image pairs first in nondecreasing Morton key of the level-0
     4x4-cell block, masked pairs last.  mvg_msda_gsamp with (pair_mask, order): bit-identical rows for the kept
@@ -889,7 +913,7 @@ def test_pair_binning_and_masked_sampling_are_exact():
         inside[:, 1::3] = 0                                       # make sure both classes occur in every image
         n_img, Lq = inside.shape
         order = ops.bin_pairs(ref_lvl, inside.view(-1), ctx.levels)
-        o = order.view(n_img, Lq).long().cpu()
+        o = _per_image_order(order, inside).cpu()
         H0, W0 = [int(v) for v in ctx.levels.shapes[0]]
 
         def morton(cx, cy):
@@ -950,17 +974,6 @@ def test_chain_a_row_order_and_masked_tile_skip():
         assert torch.equal(o1[inside != 0], o0[inside != 0])
         assert torch.equal(attn1[inside == 0], torch.zeros_like(attn1[inside == 0]))
         assert float((o1[inside == 0] - o_masked).abs().max()) <= 2e-3 * float(o0.abs().max())
-    # rows_per_image: the image-interleaved dispatch (workgroup b on tile (b mod n_img) * tiles_per_image + b / n_img) is a
-    # scheduling hint -- 4 "images" of 3 x 128 rows, per-image order with each image's masked rows last, as mvg_bin_pairs gives it
-    rpi, n_img = 384, 4
-    rows = rpi * n_img
-    samp = torch.randn(rows, 256, device=DEV).to(torch.bfloat16)
-    inside = (torch.rand(rows, device=DEV) < 0.6).to(torch.uint8)
-    order = torch.cat([n * rpi + torch.argsort(1 - inside[n * rpi:(n + 1) * rpi].int(), stable=True) for n in range(n_img)]).to(torch.int32)
-    ref = ops.chain_attn_pose(samp, inside, *wts, order=order, o_masked=o_masked)
-    for hint in (rpi, 2 * rpi, 100, rows):            # whole tiles per image: interleaved; otherwise the plain dispatch
-        got = ops.chain_attn_pose(samp, inside, *wts, order=order, o_masked=o_masked, rows_per_image=hint)
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
 
 
 def test_pyramid_producer_handoff_layouts():
@@ -1286,11 +1299,8 @@ def test_pyramid_gemms_and_binning_full_size():
     inside = (torch.rand(n_img, Lq, device=DEV) < 0.6).to(torch.uint8)
     order = ops.bin_pairs(r, inside.view(-1), levels).view(n_img, Lq).long()
     base = (torch.arange(n_img, device=DEV) * Lq)[:, None]
+    order = _per_image_order(order, inside)         # (checks the layout: in-image pairs first, per image or launch-wide)
     assert torch.equal(torch.sort(order, 1).values, base + torch.arange(Lq, device=DEV)[None])
-    flags = inside.view(-1)[order.view(-1)].view(n_img, Lq)
-    n_in = inside.sum(1)
-    for n in range(n_img):
-        assert int(flags[n, :int(n_in[n])].sum()) == int(n_in[n]) and int(flags[n, int(n_in[n]):].sum()) == 0
 
 
 @pytest.mark.parametrize("n_img,S,n_layers", [(5, 40320, 1), (5, 40320, 3), (3, 1237, 4), (1, 5, 2), (2, 40, 1)])
@@ -1576,7 +1586,7 @@ def test_bin_pairs_all_variants_against_a_stable_sort(n_img, Lq):
     for multi in (0, 1):
         lib.mvg_set_tuning(b"bin_multi", multi)
         try:
-            order = ops.bin_pairs(ref, inside.view(-1), levels).view(n_img, Lq).long()
+            order = _per_image_order(ops.bin_pairs(ref, inside.view(-1), levels), inside)
         finally:
             lib.mvg_set_tuning(b"bin_multi", 1)
         base = torch.arange(n_img, device=DEV).view(-1, 1) * Lq
