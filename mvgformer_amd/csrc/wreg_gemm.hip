@@ -340,8 +340,6 @@ int wreg2_configure() {
 
 
 
-static const int g_wreg_gweight = 300;   // share of an XCD's workgroups a 192-column job gets, x100 (a 256-column job: 400); 300-400 measured alike
-
 extern "C" int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njobs, const void* const* Wf, const float* const* bias,
                                     void* const* out, const int* N, const int* planes, int slots_per_xcd, void* stream) {
   if (!feat || !Wf || !bias || !out || !N || !planes || n_img <= 0 || S <= 0 || njobs < 1 || njobs > WREG_MAX_JOBS) return MVG_E_BADARG;
@@ -353,10 +351,12 @@ extern "C" int mvg_pyramid_group_ws(const void* feat, int n_img, int S, int njob
     if (planes[j] ? (N[j] != 256 || !bias[j]) : N[j] != 192) return MVG_E_BADARG;     // the two shapes the decoder has
     gp.job[j].Wf = (const bf16_t*)Wf[j]; gp.job[j].bias = bias[j]; gp.job[j].out = out[j];
     gp.job[j].N = N[j]; gp.job[j].rowmajor = planes[j] ? 0 : 1;
-    // A launch with at most one workgroup per CU (the just-in-time launches) is bound by a workgroup's own tile loop, not by HBM: every
-    // workgroup then needs the same number of tiles, whatever its job's columns (s_memtime stamps in the forward: 2 430 cycles per
-    // tile for both jobs; at 18 : 13 slots the G workgroups ran 56 tiles against 44 and finished 9 us late; 16 : 16: forward -2.2 %).
-    weight[j] = planes[j] ? 400 : (slots_per_xcd > 0 && slots_per_xcd <= 32 ? 400 : g_wreg_gweight);
+    // Equal shares: every workgroup gets the same number of tiles, whatever its job's column count.  A workgroup's time per tile is the
+    // same for a 256- and a 192-column job (s_memtime stamps in the forward: 2 430 cycles), and a launch with one workgroup per CU
+    // (the just-in-time launches) is bound by that tile loop, not by HBM: with the slots split by columns (18 : 13 of 32) the G
+    // workgroups ran 56 tiles against 44 and finished 9 us late (forward -2.2 % with 16 : 16); the two-workgroups-per-CU launches are
+    // HBM-bound and indifferent (2 / 4 samples per forward: -0.6 / -0.7 %).
+    weight[j] = 1;
     total += weight[j];
   }
   // slots per XCD in proportion to the jobs' work; never more than the 64 resident workgroups of an XCD
