@@ -796,7 +796,7 @@ def main():
         add("value_proj", "value_proj_ws", fl["value"], Ly)
         add("feat_linear", "feat_linear_ws", fl["G"], Ly)
         add("pyramid_group_first_layer", "pyramid_group_ws_2", fl["value"] + fl["G"], 1)
-        add("pyramid_group_one_layer_just_in_time", "pyramid_group_ws_2_jit", fl["value"] + fl["G"], Ly - 1)
+        add("pyramid_group_one_layer_just_in_time", "pyramid_group_ws_2_jit", fl["value"] + fl["G"], Ly)
         for nj in (4, 6, 8):
             add("pyramid_group_%d_layers" % (nj // 2), "pyramid_group_ws_%d" % nj, (fl["value"] + fl["G"]) * (nj // 2), 1)
         roof_mfma = {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "flops_nominal": fl["nominal"], "flops_executed": fl["executed"],

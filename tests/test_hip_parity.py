@@ -1218,7 +1218,7 @@ def test_side_stream_pyramid_projections_change_nothing():
         # both issue orders of the side stream: everything up front (grouped launches), and one launch per layer issued
         # just in time behind the previous layer's chain B with one workgroup per CU (the default at one sample per forward)
         assert dec.pyramid_jit == "auto"
-        assert [(len(g), s) for g, s in dec.pyramid_launches(ctx)] == [(1, 0)] + [(1, dec.pyramid_jit_slots)] * (len(dec.layers) - 1)
+        assert [(len(g), s) for g, s in dec.pyramid_launches(ctx)] == [(1, dec.pyramid_jit_slots)] * len(dec.layers)
         for jit in ("auto", "0", "1"):
             dec.pyramid_jit = jit
             if jit == "0":
