@@ -929,7 +929,7 @@ __global__ __launch_bounds__(NT) void msda_gsamp_pipe_kernel(const bf16_t* __res
   msda_gsamp_body<L, NT, 1>(vp, G, xw, r, lv, samp, pair_mask, order, n_pairs, Lq, S, B, map_ch);
 }
 
-static int g_gsamp_pipe = 0;       // tuning knob "gsamp_pipe": gathers double-buffered in half batches (93 VGPRs) -- 0 = from 24 images per launch on, 1 = always, 2 = never
+static int g_gsamp_pipe = 0;       // tuning knob "gsamp_pipe": gathers double-buffered in half batches (93 VGPRs) -- 0 = from 32 768 pairs per launch on, 1 = always, 2 = never
 int g_auto_small = 1;              // tuning knob "auto_small": small launches pick their own workgroup / tile sizes (see mvg_msda_gsamp)
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
@@ -1162,8 +1162,11 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
   // workgroups and its time is a workgroup's latency -- smaller workgroups and single-block XCD chunks spread it over
   // more CUs (cfg-2 with 128 / 256 queries: 0.83 / 0.90 -> 0.80 / 0.88 ms per forward).  Results do not depend on either
   // (every (pair, head) is computed independently).
-  // double-buffered gathers: -1.1 % per forward at 31 views (cfg-5), +1 % at 5-10 images, noise at 20 (profiles/r05_experiments.txt)
-  const bool pipe = g_gsamp_pipe == 1 || (g_gsamp_pipe == 0 && N_img >= 24);
+  // double-buffered gathers: from 32 768 pairs per launch on.  With the planes written just before the launch (just-in-time products:
+  // Infinity-Cache hits) the half batches pay at full size -- cfg-2 -0.8 %, all pairs inside -1.6 %, cfg-5 -1.4 % per forward -- and cost
+  // a rank's shard +1 % (128 queries); 2 samples per forward +-0.4 % (profiles/r05_experiments.txt section 13; before that schedule:
+  // -1.1 % at 31 views, +1 % at 5-10 images)
+  const bool pipe = g_gsamp_pipe == 1 || (g_gsamp_pipe == 0 && (long)N_img * Lq >= 32768);
   int nthreads = g_gsamp_threads, map = g_gsamp_map;
   if (g_auto_small && Lq <= 8192) {
     nthreads = 128;
