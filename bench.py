@@ -111,6 +111,17 @@ def measure_traffic_live(argv_tail, kernel_prefix):
 SAMPLER_KERNELS = {"msda_gsamp": "msda_gsamp_kernel",
                    "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
 
+
+def sampler_kernel_name(key, n_pairs):
+    """the kernel a profile label of the sampling step stands for: the bf16 G-sampling launch runs its double-buffered build from
+    32 768 pairs per launch on (csrc/msda.hip: mvg_msda_gsamp), unless a tuning knob says otherwise"""
+    if key == "msda_gsamp":
+        from mvgformer_amd import _lib
+        pipe = _lib.TUNING.get("gsamp_pipe", 0)
+        if pipe == 1 or (pipe == 0 and n_pairs >= 32768):
+            return "msda_gsamp_pipe_kernel"
+    return SAMPLER_KERNELS[key]
+
 # the workloads measured next to the headline in the driver's one command (VERDICT r3 item 2): (name, config, dtype, inside, batch)
 SECONDARY = (("cfg2_fp32", "cfg2", "fp32", "grid", 1), ("cfg4_fp32", "cfg4", "fp32", "grid", 1),
              ("cfg2_bf16_inside_all", "cfg2", "bf16", "all", 1), ("cfg5_bf16", "cfg5", "bf16", "grid", 1),
@@ -237,7 +248,7 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3
         rec["fp32_form"] = FP32_FORM
     if key is not None:
         us = prof[key][1] * 1e3
-        rec.update({"sampler_kernel": SAMPLER_KERNELS[key], "sampler_us": round(us, 2),
+        rec.update({"sampler_kernel": sampler_kernel_name(key, batch * case.V * case.NQ * 15), "sampler_us": round(us, 2),
                     "frac": round(bytes_launch / (us * 1e-6) / 8e12, 4), "algorithmic_bytes_per_launch": bytes_launch})
     rec["kernels_us"] = {k: round(ms * 1e3, 1) for k, (n, ms) in sorted(prof.items())}
     del graph, out, dec, g, ctx, case
@@ -719,7 +730,7 @@ def main():
     kernel_names = {"msda_gsamp": "msda_gsamp_kernel",
                     "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
     samp_key = next((k for k in kernel_names if k in prof), "msda_fused")
-    samp_name = kernel_names[samp_key]
+    samp_name = sampler_kernel_name(samp_key, args.batch * V * NQ * J)
     if world == 1 and args.traffic != "off" and args.inflight == 1:
         src_hash = sampler_source_hash()
         want = {"config": args.config, "dtype": args.dtype, "queries": NQ, "valid_fraction": args.valid_fraction,

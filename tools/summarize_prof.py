@@ -61,7 +61,7 @@ for k in sorted(acc, key=lambda k: -dur.get(k, 0)):
 # ---- machine-readable HBM-side traffic of the dominant kernel (read by bench.py -> roofline.traffic)
 import json
 for k in acc:
-    if (k.startswith("samp_chain_kernel") or k.startswith("msda_gsamp_kernel")) and "FETCH_SIZE" in acc[k]:
+    if (k.startswith("msda_gsamp_pipe_kernel") or k.startswith("msda_gsamp_kernel")) and "FETCH_SIZE" in acc[k]:
         fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
         write_kb = sum(acc[k].get("WRITE_SIZE", [0])) / max(len(acc[k].get("WRITE_SIZE", [0])), 1)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
