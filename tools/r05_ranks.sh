@@ -15,3 +15,6 @@ for f in sorted(glob.glob("gpurun_out/r05_ranks/bench_*.json")):
     d = json.loads(open(f).read().strip().splitlines()[-1])
     print(f.split("/")[-1], d["ms_per_step"], d["rank_time_split"], d["config"].get("emulated_rank"), d["config"].get("touched_pyramid_share", {}).get("per_layer") if d["config"].get("touched_pyramid_share") else None, d["roofline"]["in_image_pair_fraction"])
 PY
+python bench.py --cpu-baseline 0 --traffic off --secondary 0 --steps 100 > $O/bench_full.json 2> $O/err_full.txt
+python -c "
+import json; d=json.loads(open('gpurun_out/r05_ranks/bench_full.json').read().strip().splitlines()[-1]); print('full', d['ms_per_step'])"
