@@ -108,6 +108,45 @@ def measure_traffic_live(argv_tail, kernel_prefix):
                         "fetch_correction": 2.0}
 
 
+def measure_sampler_in_forward(argv_tail, kernel_prefix, launches_per_forward, replays=8):
+    """Duration of the sampling kernel INSIDE the graph-replayed forward (what the timed region runs): one rocprofv3 --kernel-trace
+    child pass over `replays` replays of this configuration, the kernel's launches of those replays taken from the end of the trace.
+    (The eager profile pass times every kernel alone; in the forward the sampler finds its planes written just before it.)
+    Returns (mean us, n launches) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="mvg_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "-d", tmp, "-o", "kt", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", str(replays), "--warmup", "2", "--secondary", "0", "--traffic", "off", "--profile-steps", "0"] + argv_tail
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        rows = []
+        for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if kernel_prefix in r["Kernel_Name"]:
+                        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        need = launches_per_forward * replays
+        if len(rows) < need:
+            return None, "%d launches of %s in the trace, %d expected (rc %d: %s)" % (len(rows), kernel_prefix, need, p.returncode, p.stderr[-300:])
+        rows.sort()
+        last = rows[-need:]
+        return sum(e - s for s, e in last) / len(last) * 1e-3, len(last)
+    except Exception as e:      # profiler trouble must never cost the bench line
+        return None, "kernel-trace pass failed: %s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 SAMPLER_KERNELS = {"msda_gsamp": "msda_gsamp_kernel",
                    "msda_gfused_f32": "msda_gfused_f32_hp_kernel", "msda_fused": "msda_fused_kernel"}
 
@@ -725,6 +764,7 @@ def main():
     # measured by this run (two rocprofv3 child passes of the same command) or the committed figure of tools/prof.sh --
     # quoted only for the kernel sources (hash) and configuration it was measured on; the line says which.
     traffic, traffic_source = None, None
+    in_forward = None
     # the dominant kernel: the G-sampling kernel (bf16), its fp32 twin or the generic fused sampling kernel; its algorithmic
     # bytes are SURVEY 8(d)'s sampling figure in all three cases
     kernel_names = {"msda_gsamp": "msda_gsamp_kernel",
@@ -756,6 +796,7 @@ def main():
             if args.valid_fraction is not None:
                 tail += ["--valid-fraction", str(args.valid_fraction)]
             traffic, detail = measure_traffic_live(tail, samp_name)
+            in_forward = measure_sampler_in_forward(tail, samp_name, Ly) if args.batch == 1 else None
             traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, %s" % json.dumps(detail)
                               if traffic is not None else "unavailable: %s" % detail)
         elif traffic is None:
@@ -773,6 +814,17 @@ def main():
                 "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n, "algorithmic_bytes_per_launch": bytes_launch,
                 # SURVEY 8(d) optional: value read once + output written once (locations / weights never hit HBM here)
                 "fused_minimum_bytes_per_launch": args.batch * V * (S * 256 + Lq_loc * 256) * elem}
+        if in_forward is not None:
+            # the same kernel inside the graph-replayed forward (rocprofv3 --kernel-trace child pass): there its value planes and G
+            # were written just before it (Infinity-Cache hits) and it runs shorter than alone; `achieved` / `frac` above keep the
+            # kernel-alone duration that profiles/*_kernel_stats.csv reports
+            if in_forward[0] is not None:
+                roof["in_forward"] = {"avg_launch_us": round(in_forward[0], 2), "launches": in_forward[1],
+                                      "achieved": round(bytes_launch / (in_forward[0] * 1e-6) / 1e9, 1),
+                                      "frac": round(bytes_launch / (in_forward[0] * 1e-6) / 1e9 / 8000.0, 4),
+                                      "source": "rocprofv3 --kernel-trace child pass over 8 graph replays of this configuration"}
+            else:
+                roof["in_forward"] = {"unavailable": in_forward[1]}
         if samp_key == "msda_gsamp":
             # The roof this kernel actually runs against: its gathers are served by the L1s, which deliver
             # 55-57 B/clk/CU = ~35 TB/s to loads of this shape (tools/probes/l1_gather_probe).  Bytes delivered to the lanes per

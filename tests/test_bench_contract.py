@@ -46,6 +46,11 @@ def test_bench_line_has_the_contract_fields():
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["hip_graph"] is True
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "msda_gsamp_pipe_kernel"    # (the double-buffered build: 76 800 pairs per launch)
+    # the same kernel inside the replayed forward (kernel-trace child pass): 4 launches per forward x 8 replays, priced by the same bytes
+    f = r["in_forward"]
+    assert "unavailable" not in f, f
+    assert f["launches"] == 32 and 0.5 * r["avg_launch_us"] < f["avg_launch_us"] < 1.5 * r["avg_launch_us"]
+    assert abs(f["frac"] - r["algorithmic_bytes_per_launch"] / (f["avg_launch_us"] * 1e-6) / 8e12) < 1e-3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # 5 views x 46.20 MB (bf16) per launch
     assert r["algorithmic_bytes_per_launch"] == 231014400
