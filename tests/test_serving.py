@@ -82,3 +82,34 @@ def test_graph_survives_an_eager_call_with_other_shapes_on_the_same_decoder():
     again = [t.clone() for t in run.replay()[:4]]
     del junk
     assert all(torch.equal(x, y) for x, y in zip(first, again))
+
+
+def test_product_launch_schedule_description(monkeypatch):
+    """DQDecoder.pyramid_launches: which pyramid-product launches a bf16 forward issues (host logic only, no kernels).  One sample per
+    forward: one launch per layer with one workgroup per CU (32 per XCD), layer l + 1's behind layer l's chain B; more samples per
+    forward, or MVG_PYRAMID_JIT = 0: layer 0's launch + the remaining layers grouped; no side stream -> the same description (the
+    launches then run inline)."""
+    import types
+    import torch
+    from mvgformer_amd.factory import build_decoder_for_case
+    from mvgformer_amd.synthetic import build_case
+    case = build_case("cfg2", NQ=8, with_features=False)
+    dec = build_decoder_for_case(case, "cpu", dtype=torch.bfloat16)
+    ctx = lambda B: types.SimpleNamespace(B=B, feat=torch.zeros((case.V * B, 8, 256), dtype=torch.bfloat16))
+    shape = lambda launches: [(len(g), s) for g, s in launches]
+    n = len(dec.layers)
+    assert n == 4 and dec.pyramid_jit == "auto" and dec.pyramid_jit_slots == 32
+    assert dec._pyramid_jit(ctx(1)) and not dec._pyramid_jit(ctx(2))
+    assert shape(dec.pyramid_launches(ctx(1))) == [(1, 32)] * n
+    assert shape(dec.pyramid_launches(ctx(2))) == [(1, 0), (n - 1, 0)]
+    assert shape(dec.pyramid_launches(ctx(1), jit=False)) == [(1, 0), (n - 1, 0)]          # segmented graphs (mvgformer_amd.dist)
+    dec.pyramid_jit = "0"
+    assert shape(dec.pyramid_launches(ctx(1))) == [(1, 0), (n - 1, 0)]
+    dec.pyramid_jit = "1"
+    assert shape(dec.pyramid_launches(ctx(2))) == [(1, 32)] * n
+    dec.pyramid_jit = "auto"
+    fp32 = types.SimpleNamespace(B=1, feat=torch.zeros((case.V, 8, 256), dtype=torch.float32))
+    assert dec.pyramid_launches(fp32) is None                                              # fp32: one launch per layer (project_pyramid)
+    # every layer of a launch is a distinct layer, in order
+    seen = [l for g, _ in dec.pyramid_launches(ctx(2)) for l in g]
+    assert [id(l) for l in seen] == [id(l) for l in dec.layers]
