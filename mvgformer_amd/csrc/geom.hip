@@ -880,23 +880,15 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __res
   __shared__ int out_sums[2];           // outside pairs of the images before this one | of all images
   const int n = blockIdx.x / BIN_PARTS, part = blockIdx.x % BIN_PARTS, tid = threadIdx.x;
   const int n_img = gridDim.x / BIN_PARTS;
-  if (tid < 2) out_sums[tid] = 0;
-  __syncthreads();
-  {
-    int before = 0, all = 0;
-    for (int i = tid; i < n_img * BIN_PARTS; i += 1024) {
-      const int v = (int)cnt[(long)i * BIN_CNT_STRIDE + BIN_KEYS];
-      all += v;
-      before += (i / BIN_PARTS < n) ? v : 0;
-    }
+  // (the first wavefront fetches the other images' "outside" counters here and adds them up behind the loads below: no extra barrier,
+  // no round trip in front of the key loads)
+  constexpr int OVN = 16;               // x 64 lanes = 1024 (image, part) counters; more images: the loop below continues
+  int ov[OVN];
+  if (tid < 64) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      before += __shfl_xor(before, off, 64);
-      all += __shfl_xor(all, off, 64);
-    }
-    if ((tid & 63) == 0 && all) {
-      atomicAdd(&out_sums[0], before);
-      atomicAdd(&out_sums[1], all);
+    for (int j = 0; j < OVN; ++j) {
+      const int i = tid + 64 * j;
+      ov[j] = i < n_img * BIN_PARTS ? (int)cnt[(long)i * BIN_CNT_STRIDE + BIN_KEYS] : 0;
     }
   }
   const int q0 = part * Lp, nq = max(0, min(Lp, Lq - q0));
@@ -926,6 +918,28 @@ __global__ __launch_bounds__(1024) void bin_scatter_kernel(const unsigned* __res
     if ((tid & 63) >= d) incl += up;
   }
   if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+  if (tid < 64) {
+    int ob = 0, oa = 0;
+#pragma unroll
+    for (int j = 0; j < OVN; ++j) {
+      oa += ov[j];
+      ob += ((tid + 64 * j) / BIN_PARTS < n) ? ov[j] : 0;
+    }
+    for (int i = tid + 64 * OVN; i < n_img * BIN_PARTS; i += 64) {      // (more than 128 images)
+      const int v = (int)cnt[(long)i * BIN_CNT_STRIDE + BIN_KEYS];
+      oa += v;
+      ob += (i / BIN_PARTS < n) ? v : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ob += __shfl_xor(ob, off, 64);
+      oa += __shfl_xor(oa, off, 64);
+    }
+    if (tid == 0) {
+      out_sums[0] = ob;
+      out_sums[1] = oa;
+    }
+  }
   __syncthreads();
   int base = 0, total = 0;
 #pragma unroll
