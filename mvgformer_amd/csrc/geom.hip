@@ -467,6 +467,50 @@ __device__ __forceinline__ void jacobi_round_lanes(double (&col)[4], const int j
 }
 
 
+// Probe build only (-DTRI_STAMPS, tools/probes/stamps_tri.py): thread 0 of every workgroup appends [blockIdx, start, end (s_memrealtime),
+// HW_ID | XCC_ID << 32, s_memtime at: start, phase 1 done, barrier passed, Jacobi + divide done, next projection done].
+#ifdef TRI_STAMPS
+__device__ unsigned long long tri_stamps[4096 * 12];
+__device__ unsigned int tri_stamp_count;
+#define TSTAMP_DECL unsigned long long tst_[12]; tst_[0] = 0
+#define TSTAMP_REAL(i) tst_[i] = __builtin_amdgcn_s_memrealtime()
+#define TSTAMP(i) tst_[i] = __builtin_amdgcn_s_memtime()
+#define TSTAMP_FLUSH()                                                                                                    \
+  do {                                                                                                                    \
+    if (threadIdx.x == 0) {                                                                                               \
+      const unsigned slot_ = atomicAdd(&tri_stamp_count, 1u);                                                             \
+      if (slot_ < 4096) {                                                                                                 \
+        unsigned hw_, xcc_;                                                                                               \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                                 \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                               \
+        tst_[0] = blockIdx.x;                                                                                             \
+        tst_[3] = ((unsigned long long)xcc_ << 32) | hw_;                                                                 \
+        for (int i_ = 0; i_ < 12; ++i_) tri_stamps[slot_ * 12 + i_] = tst_[i_];                                           \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  } while (0)
+extern "C" int mvg_tri_read_stamps(unsigned long long* host, int max_records, int reset) {
+  unsigned n = 0;
+  hipError_t e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(tri_stamp_count), sizeof(n));
+  if (e != hipSuccess) return -(int)e;
+  if (n > 4096) n = 4096;
+  if ((int)n > max_records) n = max_records;
+  if (host && n) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(tri_stamps), sizeof(unsigned long long) * 12 * n);
+  if (e != hipSuccess) return -(int)e;
+  if (reset) {
+    const unsigned z = 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(tri_stamp_count), &z, sizeof(z));
+    if (e != hipSuccess) return -(int)e;
+  }
+  return (int)n;
+}
+#else
+#define TSTAMP_DECL
+#define TSTAMP_REAL(i)
+#define TSTAMP(i)
+#define TSTAMP_FLUSH()
+#endif
+
 template <bool LANES>
 __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restrict__ r, const float* __restrict__ o,
                                                           const float* __restrict__ cams,
@@ -479,6 +523,9 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
                                                           uint8_t* __restrict__ inside_next) {
   __shared__ double gram[10][TRI_PROBS][TRI_PAD];
   __shared__ float xnew[TRI_PROBS][3];
+  TSTAMP_DECL;
+  TSTAMP_REAL(1);
+  TSTAMP(4);
   const int tid = threadIdx.x, pl = tid >> 3, sub = tid & 7;
   const int Lq = NQ * J;
   const long nprob = (long)B * Lq;
@@ -580,7 +627,9 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 10; ++e) gram[e][pl][sub] = G[e];
   }
+  TSTAMP(5);
   __syncthreads();
+  TSTAMP(6);
   if constexpr (LANES) {
     // ---- phase 2, lane-parallel: see jacobi_round_lanes
     const long idx = min((long)blockIdx.x * TRI_PROBS + pl, nprob - 1);
@@ -704,7 +753,12 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
   xnew[tid][1] = X1;
   xnew[tid][2] = X2;
   }
-  if (!r_next) return;                  // uniform: the caller does not want the next layer's projections
+  TSTAMP(7);
+  if (!r_next) {
+    TSTAMP_REAL(2);
+    TSTAMP_FLUSH();
+    return;                             // uniform: the caller does not want the next layer's projections
+  }
   // ---- phase 3: the NEXT layer's projection of the new points (project_kernel's arithmetic on new_ref, which is what the
   //      next layer receives as reference_points: zeros for queries that did not pass, dq_decoder.py:1013-1029), by the
   //      8 lanes of each problem: lane `sub` takes views sub, sub + 8, ...
@@ -720,6 +774,9 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
       }
     }
   }
+  TSTAMP(8);
+  TSTAMP_REAL(2);
+  TSTAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------
