@@ -70,6 +70,10 @@ struct LevelTable {
   int start[MVG_MAX_LEVELS];
   float invH[MVG_MAX_LEVELS];   // 1.0f / H, 1.0f / W (IEEE fp32 division on the host: what the kernels used to compute)
   float invW[MVG_MAX_LEVELS];
+  float Hf[MVG_MAX_LEVELS];     // (float)H, (float)W and the upper bounds H + 1, W + 1 of index_safe: per-sample conversions / adds
+  float Wf[MVG_MAX_LEVELS];     // of the samplers' inner loops otherwise (wave-uniform: scalar loads from the kernel arguments)
+  float Hp1[MVG_MAX_LEVELS];
+  float Wp1[MVG_MAX_LEVELS];
   int L;
 };
 
@@ -82,6 +86,10 @@ static inline int mvg_fill_levels(LevelTable* t, const int64_t* shapes_host, con
     t->start[l] = (int)starts_host[l];
     t->invH[l] = 1.0f / (float)t->H[l];
     t->invW[l] = 1.0f / (float)t->W[l];
+    t->Hf[l] = (float)t->H[l];
+    t->Wf[l] = (float)t->W[l];
+    t->Hp1[l] = (float)t->H[l] + 1.f;
+    t->Wp1[l] = (float)t->W[l] + 1.f;
   }
   return 0;
 }

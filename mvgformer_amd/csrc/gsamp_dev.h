@@ -15,12 +15,34 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 template <int S>   // value of lane S of every quad (v_mov_b32_dpp quad_perm:[S,S,S,S])
 __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S * 0x55, 0xf, 0xf, false);
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, S * 0x55, 0xf, 0xf, true);
+}
+
+// acc += w.lo * d.lo + w.hi * d.hi with w read from lane S of the quad: the quad broadcast of the packed blend weights is a DPP
+// operand of the v_dot2c itself (hipcc keeps a v_mov_b32_dpp per broadcast: the DPP combiner does not touch tied-accumulator VOP2s).
+// The compiler does not see the DPP read: the 2 wait states a DPP source needs behind the VALU write of that register hold by
+// construction (the weights are converted a batch ahead) and are checked on the built ISA by tools/check_dpp_hazard.py.
+template <int S>
+__device__ __forceinline__ void dot2c_quad(float& acc, unsigned w, unsigned d) {
+  asm("v_dot2c_f32_bf16_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(d), "n"(S));
+}
+
+// clamp to [0, hi] in one instruction (hipcc cannot prove 0 <= hi and emits v_max + v_min)
+__device__ __forceinline__ int clamp0_i32(int x, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
 }
 
 // One lane's sample of gather batch `it` of a (pair, head): sample index it*4 + sub, level (it*4)/8.  Branch-free:
 // packed (left, right) bf16 weights of the top / bottom pixel pair, the byte offsets of the top-left / bottom-left
 // pixels inside the head plane and the byte distance to the right-hand pixel (0 at the image border, else 64).
+// Round 6 (instruction diet, same results bit for bit): the reference's bounds test (cuh:298) and the zero padding of the
+// four corners (cuh:66-88) are ONE unsigned compare per row / column of the 2 x 2 footprint, applied to the 1-D factors
+// before the products -- a location outside the map lands on row / column -2, n or n + 1 through index_safe and fails both
+// compares of its axis (h_raw == -1 exactly: row -1 fails, row 0 passes with factor lh == 0).  It was 4 float compares for
+// the bounds test + 4 integer ones for the corners + 7 mask combinations + 5 selects on the products.  Pixel indices: one
+// v_med3_i32 per clamp, rows through v_mad_u32_u24 on the pre-shifted row pitch.
 template <int L>
 __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ sc, float mx, const LevelTable& lv,
                                              int sub, unsigned& wt, unsigned& wb, unsigned& ot, unsigned& ob,
@@ -28,43 +50,72 @@ __device__ __forceinline__ void gsamp_coords(int it, const float* __restrict__ s
   constexpr int P = 8, NB = 4, LP = L * P;
   const int l = (it * NB) / P;
   const int H = lv.H[l], W = lv.W[l];
-  const float Wf = (float)W, Hf = (float)H;
+  const float Wf = lv.Wf[l], Hf = lv.Hf[l];
   const float2 rr = *reinterpret_cast<const float2*>(sc + 3 * LP + 2 * l);   // the pair's reference point at level l
   const float rx = rr.x, ry = rr.y;
   const float lgs = sc[it * NB + sub];
   const float2 of = *reinterpret_cast<const float2*>(sc + LP + (it * NB + sub) * 2);
   const float lx = rx + of.x * lv.invW[l], ly = ry + of.y * lv.invH[l];               // projattn.py:186-191
   const float h_raw = ly * Hf - 0.5f, w_raw = lx * Wf - 0.5f;                         // cuh:295-296
-  const bool inside = (h_raw > -1.f) & (w_raw > -1.f) & (h_raw < Hf) & (w_raw < Wf);  // cuh:298
-  const float h_im = index_safe(h_raw, Hf), w_im = index_safe(w_raw, Wf);
+  const float h_im = __builtin_amdgcn_fmed3f(h_raw, -2.f, lv.Hp1[l]), w_im = __builtin_amdgcn_fmed3f(w_raw, -2.f, lv.Wp1[l]);
   const float hl_f = floorf(h_im), wl_f = floorf(w_im);
-  const int h_low = (int)hl_f, w_low = (int)wl_f;
+  const int h_low = (int)hl_f, w_low = (int)wl_f, h_hi = h_low + 1, w_hi = w_low + 1;
   const float lh = h_im - hl_f, lw = w_im - wl_f, hh = 1.f - lh, hw = 1.f - lw;
   const float e = __expf(lgs - mx);                                                   // <= 1: safe to evaluate always
-  const float a = inside ? e : 0.f;
-  const bool hl_ok = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl_ok = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-  const float t0 = hh * hw * a, t1 = hh * lw * a, t2 = lh * hw * a, t3 = lh * lw * a;
-  const float c0 = (hl_ok & wl_ok) ? t0 : 0.f, c1 = (hl_ok & wh_ok) ? t1 : 0.f;       // cuh:66-88 zero padding
-  const float c2 = (hh_ok & wl_ok) ? t2 : 0.f, c3 = (hh_ok & wh_ok) ? t3 : 0.f;
-  wt = pack_bf16x2(c0, c1);
-  wb = pack_bf16x2(c2, c3);
+  // cuh:298 + cuh:66-88 (see above): a row / column factor survives iff its pixel row / column exists
+  const float hh_m = (unsigned)h_low < (unsigned)H ? hh : 0.f, lh_m = (unsigned)h_hi < (unsigned)H ? lh : 0.f;
+  const float hw_m = (unsigned)w_low < (unsigned)W ? hw : 0.f, lw_m = (unsigned)w_hi < (unsigned)W ? lw : 0.f;
+  wt = pack_bf16x2(hh_m * hw_m * e, hh_m * lw_m * e);
+  wb = pack_bf16x2(lh_m * hw_m * e, lh_m * lw_m * e);
   // clamped pixel indices: a clamped corner always carries weight 0
-  const int hl_c = min(max(h_low, 0), H - 1), hh_c = min(max(h_low + 1, 0), H - 1);
-  const int wl_c = min(max(w_low, 0), W - 1), wr_c = min(max(w_low + 1, 0), W - 1);
-  const unsigned base = (unsigned)lv.start[l];
-  ot = (base + (unsigned)(hl_c * W + wl_c)) * 64u;
-  ob = (base + (unsigned)(hh_c * W + wl_c)) * 64u;
+  const int hl_c = clamp0_i32(h_low, H - 1), hh_c = clamp0_i32(h_hi, H - 1);
+  const int wl_c = clamp0_i32(w_low, W - 1), wr_c = clamp0_i32(w_hi, W - 1);
+  const unsigned col = ((unsigned)wl_c << 6) + (unsigned)lv.start[l] * 64u;
+  const unsigned pitch = (unsigned)W * 64u;
+  ot = __umul24((unsigned)hl_c, pitch) + col;                                         // < 2^32: checked by the host
+  ob = __umul24((unsigned)hh_c, pitch) + col;
   dx = (unsigned)(wr_c - wl_c) * 64u;
 }
 
-typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
-
-#ifndef MVG_GSAMP_NT0
-#define MVG_GSAMP_NT0 0
-#endif
-__device__ __forceinline__ uint4 gs_load_nt(const char* p) {
-  const gs_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(p));      // global_load_dwordx4 ... nt
-  return uint4{v.x, v.y, v.z, v.w};
+// The footprint of a pair's reference point on the G map of level l (projattn.py:134,148-153: grid_sample, bilinear, zeros
+// padding, align_corners = False): the 4 corner weights and the byte offsets of the 4 corners' G rows (192 bf16 columns) of image
+// row0 / S.  l must be wave-uniform.
+struct GFoot {
+  float w00, w10, w01, w11;
+  unsigned o00, o10, o01, o11;
+};
+template <int L>
+__device__ __forceinline__ GFoot g_footprint(const float2 (&rr)[L], int l, const LevelTable& lv, int row0) {
+  const int H = lv.H[l], W = lv.W[l];
+  float refx = rr[0].x, refy = rr[0].y;
+#pragma unroll
+  for (int ll = 1; ll < L; ++ll) {
+    refx = l == ll ? rr[ll].x : refx;
+    refy = l == ll ? rr[ll].y : refy;
+  }
+  const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);          // projattn.py:134
+  const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
+  const float ix = ((gx + 1.f) * lv.Wf[l] - 1.f) * 0.5f, iy = ((gy + 1.f) * lv.Hf[l] - 1.f) * 0.5f;
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  const float tx = ix - x0f, ty = iy - y0f;
+  // zeros padding on the 1-D factors (a product with a masked factor is the 0 the reference adds)
+  const float ax0 = (unsigned)x0 < (unsigned)W ? 1.f - tx : 0.f, ax1 = (unsigned)x1 < (unsigned)W ? tx : 0.f;
+  const float ay0 = (unsigned)y0 < (unsigned)H ? 1.f - ty : 0.f, ay1 = (unsigned)y1 < (unsigned)H ? ty : 0.f;
+  GFoot f;
+  f.w00 = ax0 * ay0;
+  f.w10 = ax1 * ay0;
+  f.w01 = ax0 * ay1;
+  f.w11 = ax1 * ay1;
+  const int x0c = clamp0_i32(x0, W - 1), x1c = clamp0_i32(x1, W - 1);
+  const int y0c = clamp0_i32(y0, H - 1), y1c = clamp0_i32(y1, H - 1);
+  const unsigned base = (unsigned)(row0 + lv.start[l]);
+  const unsigned r0 = __umul24((unsigned)y0c, (unsigned)W) + base, r1 = __umul24((unsigned)y1c, (unsigned)W) + base;
+  f.o00 = __umul24(r0 + (unsigned)x0c, 384u);                            // pixel index < 2^24: the host checks N_img*S*384 < 2^32
+  f.o10 = __umul24(r0 + (unsigned)x1c, 384u);
+  f.o01 = __umul24(r1 + (unsigned)x0c, 384u);
+  f.o11 = __umul24(r1 + (unsigned)x1c, 384u);
+  return f;
 }
 
 // One (image-query pair, head) of the G-sampling kernel, computed by the 4 lanes of a quad (lane `sub` owns channels
@@ -94,10 +145,20 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
   // first one is used (lanes without a last chunk fetch chunk NCHK - 1 again and do not store it).  As a loop of "if (chunk <
   // NCHK) { load, blend, store }" every iteration was its own exec region and round trip: s_memtime showed phase A at 13 400 of
   // a wavefront's 35 000 cycles, as long as the six gather batches together.  Same arithmetic per chunk: bit-identical.
+  // Round 6: the footprint of the pair on a level's G map (4 weights, 4 row offsets) is computed once per LEVEL THE HEAD TOUCHES
+  // instead of once per chunk: head m owns the flat groups m*L .. m*L + L - 1 of the reinterpreted (level, column) view, i.e. at
+  // most two level rows, and m is uniform in the workgroup -- so are the level indices (scalar loads of H / W / start instead of
+  // vector loads from the kernel arguments in front of the first gather) and the branch for the second level (taken by heads 2 and
+  // 5 of 8 at L = 3).  Same arithmetic per corner: bit-identical.
   constexpr int NK = (NCHK + 3) / 4;
   uint4 c00[NK], c10[NK], c01[NK], c11[NK];
   f32x4 xa[NK], xb[NK];
   float w00[NK], w10[NK], w01[NK], w11[NK];
+  const int fg0 = m * L, l_lo = fg0 >> 3, l_hi = (fg0 + L - 1) >> 3;
+  const GFoot fa = g_footprint<L>(rr, l_lo, lv, n * S);
+  GFoot fb = fa;
+  if (l_hi != l_lo) fb = g_footprint<L>(rr, l_hi, lv, n * S);
+  const char* g_bytes = reinterpret_cast<const char*>(G);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int ci = min(sub + 4 * k, NCHK - 1);
@@ -105,37 +166,19 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
     // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
     // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
     const int t = ci / 3, part = ci - 3 * t;
-    const int fg = m * L + t;
-    const int l = fg >> 3;                                               // level row of the reinterpreted view
+    const int fg = fg0 + t;
+    const bool second = (fg >> 3) != l_lo;                               // level row of the reinterpreted view
     const int col = 24 * (fg & 7) + 8 * part;
-    const int H = lv.H[l], W = lv.W[l];
-    const float Wf = (float)W, Hf = (float)H;
-    float refx = rr[0].x, refy = rr[0].y;
-#pragma unroll
-    for (int ll = 1; ll < L; ++ll) {
-      refx = l == ll ? rr[ll].x : refx;
-      refy = l == ll ? rr[ll].y : refy;
-    }
-    const float gx = fminf(fmaxf(refx * 2.f - 1.f, -1.1f), 1.1f);        // projattn.py:134
-    const float gy = fminf(fmaxf(refy * 2.f - 1.f, -1.1f), 1.1f);
-    const float ix = ((gx + 1.f) * Wf - 1.f) * 0.5f, iy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-    const float tx = ix - x0f, ty = iy - y0f;
-    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
-    w00[k] = (x0ok && y0ok) ? (1.f - tx) * (1.f - ty) : 0.f;
-    w10[k] = (x1ok && y0ok) ? tx * (1.f - ty) : 0.f;
-    w01[k] = (x0ok && y1ok) ? (1.f - tx) * ty : 0.f;
-    w11[k] = (x1ok && y1ok) ? tx * ty : 0.f;
-    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
-    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+    w00[k] = second ? fb.w00 : fa.w00;
+    w10[k] = second ? fb.w10 : fa.w10;
+    w01[k] = second ? fb.w01 : fa.w01;
+    w11[k] = second ? fb.w11 : fa.w11;
     // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
-    const char* g_bytes = reinterpret_cast<const char*>(G);
-    const unsigned gb = ((unsigned)(n * S + lv.start[l]) * 192u + (unsigned)col) * 2u;
-    c00[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x0c) * 384u));
-    c10[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y0c * W + x1c) * 384u));
-    c01[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x0c) * 384u));
-    c11[k] = *reinterpret_cast<const uint4*>(g_bytes + (gb + (unsigned)(y1c * W + x1c) * 384u));
+    const unsigned cb = (unsigned)col * 2u;
+    c00[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o00 : fa.o00) + cb));
+    c10[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o10 : fa.o10) + cb));
+    c01[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o01 : fa.o01) + cb));
+    c11[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o11 : fa.o11) + cb));
     const float* xq = xw + ((long)b * Lq + q) * 192 + col;
     xa[k] = *reinterpret_cast<const f32x4*>(xq);
     xb[k] = *reinterpret_cast<const f32x4*>(xq + 4);
@@ -215,53 +258,27 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
         raw[SS][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                    \
         raw[SS][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                            \
       }
-#define MVG_QS_NT(SS)                                                                                   \
-      {                                                                                                 \
-        const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;      \
-        const unsigned dxs = quad_bcast<SS>(co_x);                                                      \
-        raw[SS][0] = gs_load_nt(vp_bytes + ot);                                                         \
-        raw[SS][1] = gs_load_nt(vp_bytes + (ot + dxs));                                                 \
-        raw[SS][2] = gs_load_nt(vp_bytes + ob);                                                         \
-        raw[SS][3] = gs_load_nt(vp_bytes + (ob + dxs));                                                 \
-      }
-#if MVG_GSAMP_NT0
-      // measurement variant: the level-0 gathers (3 x reuse) with the nt policy, so that they do not evict the
-      // high-reuse level-1 / 2 and G lines from the 32-KB L1
-      if (it * NB < P) {
-        MVG_QS_NT(0) MVG_QS_NT(1) MVG_QS_NT(2) MVG_QS_NT(3)
-      } else {
-        MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
-      }
-#else
       MVG_QS(0) MVG_QS(1) MVG_QS(2) MVG_QS(3)
-#endif
 #undef MVG_QS
-#undef MVG_QS_NT
       const unsigned pw_t = cw_t, pw_b = cw_b;        // this batch's weights, broadcast at blend time (fewer live VGPRs)
       __builtin_amdgcn_sched_barrier(0);
       // next batch's coordinates while the gathers are in flight (the last iteration recomputes batch 0: branch-free)
       gsamp_coords<L>(it + 1 < LP / NB ? it + 1 : 0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
       __builtin_amdgcn_sched_barrier(0);
-      unsigned wt[NB], wb[NB];
-      wt[0] = quad_bcast<0>(pw_t); wt[1] = quad_bcast<1>(pw_t); wt[2] = quad_bcast<2>(pw_t); wt[3] = quad_bcast<3>(pw_t);
-      wb[0] = quad_bcast<0>(pw_b); wb[1] = quad_bcast<1>(pw_b); wb[2] = quad_bcast<2>(pw_b); wb[3] = quad_bcast<3>(pw_b);
-#pragma unroll
-      for (int s = 0; s < NB; ++s)
-#pragma unroll
-        for (int row = 0; row < 2; ++row) {
-          // left / right pixel (8 channels each) -> per channel the word (left[ch], right[ch]) = the v_dot2c operand for
-          // the packed weights (w_left, w_right): 2 v_perm + 2 v_dot2c per pair of channels
-          const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wb[s] : wt[s]);
-          const unsigned l4[4] = {raw[s][2 * row].x, raw[s][2 * row].y, raw[s][2 * row].z, raw[s][2 * row].w};
-          const unsigned r4[4] = {raw[s][2 * row + 1].x, raw[s][2 * row + 1].y, raw[s][2 * row + 1].z, raw[s][2 * row + 1].w};
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);     // (left[2t],   right[2t])
-            const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);     // (left[2t+1], right[2t+1])
-            acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);
-            acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false);
-          }
-        }
+#define MVG_BLEND0(SS)                                                                                  \
+      _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                             \
+        /* left / right pixel (8 channels each) -> per channel the word (left[ch], right[ch]) = the v_dot2c operand for */ \
+        /* the packed weights (w_left, w_right): 2 v_perm + 2 v_dot2c per pair of channels */           \
+        const unsigned wv = row ? pw_b : pw_t;                                                          \
+        const unsigned l4[4] = {raw[SS][2 * row].x, raw[SS][2 * row].y, raw[SS][2 * row].z, raw[SS][2 * row].w};             \
+        const unsigned r4[4] = {raw[SS][2 * row + 1].x, raw[SS][2 * row + 1].y, raw[SS][2 * row + 1].z, raw[SS][2 * row + 1].w}; \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+          dot2c_quad<SS>(acc[2 * t], wv, __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u));     /* (left[2t],   right[2t]) */   \
+          dot2c_quad<SS>(acc[2 * t + 1], wv, __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u)); /* (left[2t+1], right[2t+1]) */ \
+        }                                                                                               \
+      }
+      MVG_BLEND0(0) MVG_BLEND0(1) MVG_BLEND0(2) MVG_BLEND0(3)
+#undef MVG_BLEND0
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -272,7 +289,11 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
     // per (pair, head)); vmcnt is in order, so "half A arrived" is s_waitcnt vmcnt(8).  Same 64 gather VGPRs.
     const unsigned lane_off = (unsigned)((((long)n * 8 + m) * S) * 64 + sub * 16);
     const char* vp_bytes = reinterpret_cast<const char*>(vp);
+#ifdef GSAMP_ABLATE_LAST_LEVEL   // timing probe only (results garbage): the last level is not gathered
+    constexpr int NIT = LP / NB - 2;
+#else
     constexpr int NIT = LP / NB;
+#endif
     unsigned cw_t, cw_b, co_t, co_b, co_x;
     gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
     uint4 ra[2][4], rb[2][4];
@@ -286,18 +307,13 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
       BUF[J][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                               \
     }
 #define MVG_BLEND(BUF, J, SS)                                                                           \
-    {                                                                                                   \
-      const unsigned wts = quad_bcast<SS>(pw_t), wbs = quad_bcast<SS>(pw_b);                            \
-      _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                             \
-        const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, row ? wbs : wts);                              \
-        const unsigned l4[4] = {BUF[J][2 * row].x, BUF[J][2 * row].y, BUF[J][2 * row].z, BUF[J][2 * row].w};                 \
-        const unsigned r4[4] = {BUF[J][2 * row + 1].x, BUF[J][2 * row + 1].y, BUF[J][2 * row + 1].z, BUF[J][2 * row + 1].w}; \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
-          const unsigned lo = __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u);                         \
-          const unsigned hi = __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u);                         \
-          acc[2 * t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lo), wv, acc[2 * t], false);             \
-          acc[2 * t + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hi), wv, acc[2 * t + 1], false);     \
-        }                                                                                               \
+    _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                               \
+      const unsigned wv = row ? pw_b : pw_t;                                                            \
+      const unsigned l4[4] = {BUF[J][2 * row].x, BUF[J][2 * row].y, BUF[J][2 * row].z, BUF[J][2 * row].w};                 \
+      const unsigned r4[4] = {BUF[J][2 * row + 1].x, BUF[J][2 * row + 1].y, BUF[J][2 * row + 1].z, BUF[J][2 * row + 1].w}; \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+        dot2c_quad<SS>(acc[2 * t], wv, __builtin_amdgcn_perm(r4[t], l4[t], 0x05040100u));               \
+        dot2c_quad<SS>(acc[2 * t + 1], wv, __builtin_amdgcn_perm(r4[t], l4[t], 0x07060302u));           \
       }                                                                                                 \
     }
     MVG_ISSUE(ra, 0, 0) MVG_ISSUE(ra, 1, 1)

@@ -934,6 +934,7 @@ int g_auto_small = 1;              // tuning knob "auto_small": small launches p
 static int g_gsamp_map = 4;        // tuning knob "gsamp_map": 0 = head per XCD (159 us), n > 0 = chunks of n slot blocks per
                                    // XCD with their 8 heads back to back (1..4: 155 us, 8: 159, 16: 168, 64: 243)
 static int g_gfused_chunk = 4;     // tuning knob "gfused_chunk": hp kernel, 0 = one head per XCD (270 us at cfg-2), n > 0 = chunks of n pair blocks per XCD with their 8 heads back to back (1..4: 252 us, 16: 263)
+static int g_gsamp_lds_pad = 0;    // probe knob "gsamp_lds_pad": bytes of unused dynamic LDS per workgroup (caps the workgroups per CU)
 static int g_gsamp_threads = 256;  // tuning knob "gsamp_threads": workgroup size of msda_gsamp_kernel (256 | 512 | 1024)
 
 template <typename T, int CPL, int NB>
@@ -1177,11 +1178,11 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
     int npb = (int)((pairs + NT / 4 - 1) / (NT / 4));                                                             \
     if (map > 0) npb = (npb + 8 * map - 1) / (8 * map) * (8 * map);                                               \
     if (pipe)                                                                                                 \
-      hipLaunchKernelGGL((msda_gsamp_pipe_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,     \
+      hipLaunchKernelGGL((msda_gsamp_pipe_kernel<LL, NT>), dim3(8 * npb), dim3(NT), g_gsamp_lds_pad, st, (const bf16_t*)vp,     \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
     else                                                                                                          \
-      hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), 0, st, (const bf16_t*)vp,          \
+      hipLaunchKernelGGL((msda_gsamp_kernel<LL, NT>), dim3(8 * npb), dim3(NT), g_gsamp_lds_pad, st, (const bf16_t*)vp,          \
                          (const bf16_t*)G, xw, ref_lvl, lv, (bf16_t*)samp, pair_mask, order, (int)pairs, Lq, S,   \
                          B, map);                                                                                 \
   }
@@ -1221,6 +1222,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "fwd_map") && (value >= 0 && value <= 2)) { g_fwd_map = value; return 0; }
   if (!strcmp(key, "gfused_chunk") && value >= 0 && value <= 4096) { g_gfused_chunk = value; return 0; }
   if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
+  if (!strcmp(key, "gsamp_lds_pad") && value >= 0 && value <= 120 * 1024) { g_gsamp_lds_pad = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
 }

@@ -1644,8 +1644,8 @@ def test_differentiable_dlt_matches_svd_autograd():
 
 _KNOBS = [("gsamp_pipe", 1, True), ("linear_tiles", 0, True), ("linear_tiles", 2, True), ("gsamp_threads", 128, True), ("gsamp_threads", 512, True),
           ("gsamp_threads", 1024, True), ("gsamp_map", 0, True), ("gsamp_map", 8, True), ("bin_multi", 0, True), ("auto_small", 0, False),
-          ("wreg_grid", 256, True), ("wreg_grid", 64, True), ("chain_rm", 64, True), ("chain_rm", 256, False)]
-_KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, chain_rm=128)
+          ("wreg_grid", 256, True), ("wreg_grid", 64, True), ("chain_rm", 64, True), ("chain_rm", 256, False), ("gsamp_lds_pad", 22528, True)]
+_KNOB_DEFAULTS = dict(gsamp_pipe=0, linear_tiles=1, gsamp_threads=256, gsamp_map=4, bin_multi=1, auto_small=1, wreg_grid=512, chain_rm=128, gsamp_lds_pad=0)
 
 
 @pytest.mark.parametrize("key,value,exact", _KNOBS, ids=["%s=%d" % (k, v) for k, v, _ in _KNOBS])

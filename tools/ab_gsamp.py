@@ -46,7 +46,9 @@ with torch.no_grad():
             torch.cuda.synchronize()
             if base is None:
                 base = out.clone()
-            print("%-40s %8.1f us   identical to first: %s" % (v or "default", s_.elapsed_time(e_) / 50 * 1e3, bool(torch.equal(out, base))))
+            import hashlib
+            tag = hashlib.sha256(out.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16] if os.environ.get("AB_HASH") else ""
+            print("%-40s %8.1f us   identical to first: %s  %s" % (v or "default", s_.elapsed_time(e_) / 50 * 1e3, bool(torch.equal(out, base)), tag))
 
 # ---- cache residency probe (round 3): the same launch with (a) one (vh, G) set re-used (warm Infinity Cache: 180 MB < 256 MB),
 # (b) four sets in rotation like the four layers of a forward (720 MB), (c) each launch preceded by the two pyramid GEMMs that
