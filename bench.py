@@ -68,10 +68,9 @@ def sampler_source_hash():
     return h.hexdigest()[:16]
 
 
-def measure_traffic_live(argv_tail, kernel_prefix):
-    """HBM-side bytes per launch of the sampling kernel, measured NOW: two rocprofv3 --pmc child passes over a few eager
-    forwards of this very configuration (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md, "rocprofv3 PMC
-    slots"), FETCH_SIZE doubled per the guide's gfx950 correction.  Returns (bytes, detail) or (None, reason)."""
+def pmc_child_pass(counters, argv_tail, kernel_prefix):
+    """One rocprofv3 --pmc child pass (its own run: --pmc with --kernel-trace only) over a few eager forwards of this very
+    configuration -> ({counter: mean per launch of the kernels whose name contains kernel_prefix}, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -80,32 +79,59 @@ def measure_traffic_live(argv_tail, kernel_prefix):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="mvg_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
+                                                 sys.executable, os.path.abspath(__file__), "--pmc-child", "1"] + argv_tail
+        env = dict(os.environ, TMPDIR="/tmp", MVG_OVERLAP_PYRAMID="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        got = {c: [] for c in counters}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if r["Counter_Name"] in got and kernel_prefix in r["Kernel_Name"]:
+                        got[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        missing = [c for c, v in got.items() if not v]
+        if missing:
+            return None, "no %s samples for %s (rc %d: %s)" % ("/".join(missing), kernel_prefix, p.returncode, p.stderr[-300:])
+        return {c: sum(v) / len(v) for c, v in got.items()}, None
+    except Exception as e:      # profiler trouble must never cost the bench line
+        return None, "%s pass failed: %s: %s" % ("/".join(counters), type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic_live(argv_tail, kernel_prefix):
+    """HBM-side bytes per launch of the sampling kernel, measured NOW: two rocprofv3 --pmc child passes (FETCH_SIZE and WRITE_SIZE
+    do not fit one pass; MI355X_MICROARCH.md, "rocprofv3 PMC slots"), FETCH_SIZE doubled per the guide's gfx950 correction.
+    Returns (bytes, detail) or (None, reason)."""
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        tmp = tempfile.mkdtemp(prefix="mvg_pmc_", dir="/tmp")
-        try:
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "1"] + argv_tail
-            env = dict(os.environ, TMPDIR="/tmp", MVG_OVERLAP_PYRAMID="0")
-            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-                env.pop(k, None)
-            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-            got = []
-            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for r in csv.DictReader(fh):
-                        if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"]:
-                            got.append(float(r["Counter_Value"]))
-            if not got:
-                return None, "no %s samples for %s (rc %d: %s)" % (counter, kernel_prefix, p.returncode, p.stderr[-300:])
-            vals[counter] = sum(got) / len(got)
-        except Exception as e:      # profiler trouble must never cost the bench line
-            return None, "%s pass failed: %s: %s" % (counter, type(e).__name__, e)
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+        got, why = pmc_child_pass([counter], argv_tail, kernel_prefix)
+        if got is None:
+            return None, why
+        vals.update(got)
     total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     return int(total), {"FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
                         "fetch_correction": 2.0}
+
+
+def measure_issue_shares(argv_tail, kernel_prefix, n_cu=256):
+    """What the sampling kernel's launch keeps busy (a third PMC child pass): the vector ALUs -- SQ_ACTIVE_INST_VALU counts
+    quad-cycles, x 4 / (GRBM_GUI_ACTIVE / 8 XCDs) / (4 SIMDs x n_cu) -- and the texture-address path, which accepts the lane
+    addresses of one 64-lane 16-byte load in ~18.3 clk per CU (tools/probes/l1_gather_probe: 56 B/clk/CU): SQ_INSTS_VMEM_RD x 18.3 /
+    n_cu / (GRBM_GUI_ACTIVE / 8).  Returns ({valu_busy, l1_addr_busy, ...}, None) or (None, reason)."""
+    got, why = pmc_child_pass(["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "GRBM_GUI_ACTIVE"], argv_tail, kernel_prefix)
+    if got is None:
+        return None, why
+    clk = got["GRBM_GUI_ACTIVE"] / 8.0
+    return {"valu_busy": round(got["SQ_ACTIVE_INST_VALU"] * 4.0 / clk / (4 * n_cu), 4),
+            "l1_addr_busy": round(got["SQ_INSTS_VMEM_RD"] * 18.3 / n_cu / clk, 4),
+            "valu_insts_per_wave": round(got["SQ_INSTS_VALU"] / got["SQ_WAVES"], 1),
+            "vmem_rd_per_wave": round(got["SQ_INSTS_VMEM_RD"] / got["SQ_WAVES"], 2),
+            "launch_clk": round(clk, 0)}, None
 
 
 def measure_sampler_in_forward(argv_tail, kernel_prefix, launches_per_forward, replays=8):
@@ -165,7 +191,7 @@ def sampler_kernel_name(key, n_pairs):
 SECONDARY = (("cfg2_fp32", "cfg2", "fp32", "grid", 1), ("cfg4_fp32", "cfg4", "fp32", "grid", 1),
              ("cfg2_bf16_inside_all", "cfg2", "bf16", "all", 1), ("cfg5_bf16", "cfg5", "bf16", "grid", 1),
              ("cfg2_bf16_batch2", "cfg2", "bf16", "grid", 2), ("cfg2_bf16_batch4", "cfg2", "bf16", "grid", 4),
-             ("cfg2_bf16_valid10", "cfg2", "bf16", "valid10", 1))
+             ("cfg2_bf16_valid10", "cfg2", "bf16", "valid10", 1), ("cfg2_bf16_producer_inplace", "cfg2", "bf16", "inplace", 1))
 FP32_FORM = "2xfp16x3"      # fp32 kernels: operands as two fp16 parts x a power-of-two scale, three fp16 MFMA products, fp32 accumulation
 
 
@@ -223,10 +249,11 @@ def measure_train_step(dev, steps=5, warmup=2):
     return rec
 
 
-def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3, profile_steps=2):
+def measure_secondary(config, dtype_name, inside, batch, dev, steps=20, warmup=3, profile_steps=2):
     """One more workload in this process, after the headline's timed region: `steps` graph-replayed forwards of a batch of
     `batch` samples (barrier-free single GPU: synchronize on both sides), then `profile_steps` eager forwards with the side
-    stream off for the sampling kernel's own duration.  No PMC passes, no CPU leg."""
+    stream off for the sampling kernel's own duration.  No PMC passes, no CPU leg.  inside = "inplace": the default poses with the
+    pyramid produced in the packed layout (DecoderContext.pyramid_buffers(): SURVEY 8 f3's hand-off, no per-step pack)."""
     import gc
     from mvgformer_amd import ops
     from mvgformer_amd.decoder import DecoderContext
@@ -239,10 +266,15 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3
     dec = build_decoder_for_case(case, dev, dtype)
     g = case_to_device(case, dev)
     ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, dtype, batch, dev)
+    src_views = g.src_views
+    if inside == "inplace":
+        src_views = ctx.pyramid_buffers(channels=g.src_views[0].shape[1])
+        for dst, s_ in zip(src_views, g.src_views):
+            dst.copy_(s_)
 
     def forward():
         ctx.feat = None
-        return dec(g.tgt, g.reference_points, g.src_views, g.meta, g.spatial_shapes, g.level_start_index, None,
+        return dec(g.tgt, g.reference_points, src_views, g.meta, g.spatial_shapes, g.level_start_index, None,
                    query_pos=g.query_pos, threshold=0.1, context=ctx)
     with torch.no_grad():
         for _ in range(2):
@@ -278,11 +310,14 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=10, warmup=3
     key = next((k for k in SAMPLER_KERNELS if k in prof), None)
     rec = {"workload": "%s: %d views, %d queries x 15 joints, %d layers, maps %s x 256ch, batch %d, initial poses %s"
                        % (config, case.V, case.NQ, case.layers, case.shapes, batch,
-                          "grid, ~10 % of the queries pass the 0.1 threshold" if inside == "valid10" else inside),
+                          "grid, ~10 % of the queries pass the 0.1 threshold" if inside == "valid10" else
+                          "grid, pyramid handed over in the packed layout (no per-step pack)" if inside == "inplace" else inside),
            "dtype": dtype_name, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
            "ms_per_step_median": round(median, 4),
-           "ms_per_sample": round(elapsed / steps / batch * 1e3, 4), "value": round(batch * steps / elapsed, 3),
-           "unit": "samples/s", "hip_graph": True, "valid_query_share_last_layer": round(valid_share, 4)}
+           "ms_per_sample": round(median / batch, 4), "value": round(batch * steps / elapsed, 3),
+           "unit": "samples/s", "hip_graph": True, "valid_query_share_last_layer": round(valid_share, 4),
+           "note": "ms_per_step = wall clock / steps (what `value` is computed from); ms_per_step_median and ms_per_sample from the "
+                   "median of the per-replay HIP-event intervals"}
     if dtype_name == "fp32":
         rec["fp32_form"] = FP32_FORM
     if key is not None:
@@ -765,6 +800,7 @@ def main():
     # quoted only for the kernel sources (hash) and configuration it was measured on; the line says which.
     traffic, traffic_source = None, None
     in_forward = None
+    issue_shares = None
     # the dominant kernel: the G-sampling kernel (bf16), its fp32 twin or the generic fused sampling kernel; its algorithmic
     # bytes are SURVEY 8(d)'s sampling figure in all three cases
     kernel_names = {"msda_gsamp": "msda_gsamp_kernel",
@@ -797,6 +833,7 @@ def main():
                 tail += ["--valid-fraction", str(args.valid_fraction)]
             traffic, detail = measure_traffic_live(tail, samp_name)
             in_forward = measure_sampler_in_forward(tail, samp_name, Ly) if args.batch == 1 else None
+            issue_shares = measure_issue_shares(tail, samp_name)
             traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, %s" % json.dumps(detail)
                               if traffic is not None else "unavailable: %s" % detail)
         elif traffic is None:
@@ -823,8 +860,16 @@ def main():
                                       "achieved": round(bytes_launch / (in_forward[0] * 1e-6) / 1e9, 1),
                                       "frac": round(bytes_launch / (in_forward[0] * 1e-6) / 1e9 / 8000.0, 4),
                                       "source": "rocprofv3 --kernel-trace child pass over 8 graph replays of this configuration"}
+                # flat copies: a parser that keeps scalars only must not lose them
+                roof["in_forward_us"] = roof["in_forward"]["avg_launch_us"]
+                roof["in_forward_frac"] = roof["in_forward"]["frac"]
             else:
                 roof["in_forward"] = {"unavailable": in_forward[1]}
+        if issue_shares is not None:
+            if issue_shares[0] is not None:
+                roof.update(issue_shares[0])      # valu_busy, l1_addr_busy (the share that binds: profiles/r06_experiments.txt), ...
+            else:
+                roof["issue_shares_unavailable"] = issue_shares[1]
         if samp_key == "msda_gsamp":
             # The roof this kernel actually runs against: its gathers are served by the L1s, which deliver
             # 55-57 B/clk/CU = ~35 TB/s to loads of this shape (tools/probes/l1_gather_probe).  Bytes delivered to the lanes per
@@ -929,6 +974,9 @@ def main():
                 secondary[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
+        if roof is not None and "frac" in secondary.get("cfg2_bf16_inside_all", {}):
+            # the sampler's figure with nothing skipped (every pair inside its image), next to the headline's: VERDICT r5 weak 10a
+            roof["frac_inside_all"] = secondary["cfg2_bf16_inside_all"]["frac"]
         try:
             t_sec = time.perf_counter()
             secondary["train_step_cfg2_fp32"] = measure_train_step(dev)

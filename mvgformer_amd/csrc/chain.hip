@@ -251,6 +251,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
   // everything behind them in flight (vmcnt counts in order).  Lane j holds the flag of row slot j >> 3 (chunk (j >> 4), half
   // wavefront (j >> 3) & 1) and view v0 + (j & 7).
   constexpr int NCHUNK = RM * 32 / NT;
+  static_assert(2 * NCHUNK <= 8 && NCHUNK % 2 == 0, "flag layout: 8 lanes per (row slot, view) flag, at most 8 row slots in the 64-bit ballot; the V > 5 path steps two chunks at a time");
   auto load_flag = [&](int v0) -> unsigned {
     const int slot = lane >> 3, view = v0 + (lane & 7);
     const int trow = (slot >> 1) * (NT / 32) + wave * 2 + (slot & 1);

@@ -18,6 +18,16 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
   return (unsigned)__builtin_amdgcn_mov_dpp((int)v, S * 0x55, 0xf, 0xf, true);
 }
 
+// quad_bcast with the source lane as an unrolled loop index (the DPP control must be an immediate)
+__device__ __forceinline__ unsigned quad_bcast_rt(unsigned v, int lane) {
+  switch (lane) {
+    case 0: return quad_bcast<0>(v);
+    case 1: return quad_bcast<1>(v);
+    case 2: return quad_bcast<2>(v);
+    default: return quad_bcast<3>(v);
+  }
+}
+
 // acc += w.lo * d.lo + w.hi * d.hi with w read from lane S of the quad: the quad broadcast of the packed blend weights is a DPP
 // operand of the v_dot2c itself (hipcc keeps a v_mov_b32_dpp per broadcast: the DPP combiner does not touch tied-accumulator VOP2s).
 // The compiler does not see the DPP read: the 2 wait states a DPP source needs behind the VALU write of that register hold by
@@ -126,20 +136,21 @@ template <int L, int PIPE = 0>
 __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const bf16_t* __restrict__ G,
                                            const float* __restrict__ xw, const float* __restrict__ r,
                                            const LevelTable& lv, float* __restrict__ sc, int pair, int m, int sub,
-                                           int Lq, int S, int B, float (&acc)[8], const float2* __restrict__ rpre = nullptr) {
+                                           int Lq, int S, int B, float (&acc)[8], float2 mine) {
   constexpr int P = 8, LP = L * P, NCHK = 3 * L, NB = 4;
+  static_assert(L <= 4, "lane `sub` of the quad carries the reference point of level `sub`");
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
 
-  // the pair's L reference points: preloaded by the caller (rpre, requested together with the pair's mask byte) or read here
+  // the pair's L reference points: lane l < L of the quad loaded level l's (`mine`, requested by the caller together with the
+  // pair's mask byte), the other lanes get them by quad broadcast -- a load instruction costs the address path one clock per 4
+  // ACTIVE lanes, and the quad's lanes would all fetch the same L x 8 bytes (profiles/r06_experiments.txt section 5)
   float2 rr[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) rr[l] = rpre ? rpre[l] : *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
-  if (sub < L) {
-    float2 mine = rr[0];
-#pragma unroll
-    for (int l = 1; l < L; ++l) mine = sub == l ? rr[l] : mine;
-    *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = mine;
+  for (int l = 0; l < L; ++l) {
+    rr[l].x = __uint_as_float(quad_bcast_rt(__float_as_uint(mine.x), l));
+    rr[l].y = __uint_as_float(quad_bcast_rt(__float_as_uint(mine.y), l));
   }
+  if (sub < L) *reinterpret_cast<float2*>(sc + 3 * LP + 2 * sub) = mine;
   // ---- phase A: this head's L*P logits and 2*L*P offsets = bilinear(G) + xw, 8 columns per chunk.
   // Round 3: ALL its loads -- 4 G corners + 2 xw vectors for each of the lane's (NCHK + 3) / 4 chunks -- are requested before the
   // first one is used (lanes without a last chunk fetch chunk NCHK - 1 again and do not store it).  As a loop of "if (chunk <
@@ -161,7 +172,7 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
   const char* g_bytes = reinterpret_cast<const char*>(G);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const int ci = min(sub + 4 * k, NCHK - 1);
+    const int ci = min(sub + 4 * k, NCHK - 1);       // (lanes past the last chunk: a valid address they do not use)
     // G / xw columns are grouped per (16 offsets | 8 logits): group g of a level row = columns [24g, 24g+24) =
     // offsets 16g..16g+15 then logits 8g..8g+7 of that row, so the 3 chunks of a group -- and the L groups of a
     // head, flat groups m*L .. m*L+L-1 -- are contiguous bytes of a pixel's G row (ops.gsamp_column_order)
@@ -175,13 +186,20 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
     w11[k] = second ? fb.w11 : fa.w11;
     // uniform base + 32-bit byte offsets (the host checks that G is smaller than 4 GB)
     const unsigned cb = (unsigned)col * 2u;
-    c00[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o00 : fa.o00) + cb));
-    c10[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o10 : fa.o10) + cb));
-    c01[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o01 : fa.o01) + cb));
-    c11[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o11 : fa.o11) + cb));
     const float* xq = xw + ((long)b * Lq + q) * 192 + col;
-    xa[k] = *reinterpret_cast<const f32x4*>(xq);
-    xb[k] = *reinterpret_cast<const f32x4*>(xq + 4);
+    // the last round has chunks for NCHK % 4 lanes of the quad only: the others do not load (their blend below runs on whatever the
+    // registers hold and is not stored) -- 16 instead of 64 lane addresses for each of the round's 6 loads at L = 3
+    if (4 * k + 4 <= NCHK || sub + 4 * k < NCHK) {
+      c00[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o00 : fa.o00) + cb));
+      c10[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o10 : fa.o10) + cb));
+      c01[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o01 : fa.o01) + cb));
+      c11[k] = *reinterpret_cast<const uint4*>(g_bytes + ((second ? fb.o11 : fa.o11) + cb));
+      xa[k] = *reinterpret_cast<const f32x4*>(xq);
+      xb[k] = *reinterpret_cast<const f32x4*>(xq + 4);
+    } else {
+      c00[k] = c10[k] = c01[k] = c11[k] = uint4{0u, 0u, 0u, 0u};
+      xa[k] = xb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -195,10 +213,12 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
     float v[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      v[2 * u] = w00[k] * __uint_as_float(a4[u] << 16) + w10[k] * __uint_as_float(b4[u] << 16) +
-                 w01[k] * __uint_as_float(c4[u] << 16) + w11[k] * __uint_as_float(d4[u] << 16);
-      v[2 * u + 1] = w00[k] * __uint_as_float(a4[u] & 0xffff0000u) + w10[k] * __uint_as_float(b4[u] & 0xffff0000u) +
-                     w01[k] * __uint_as_float(c4[u] & 0xffff0000u) + w11[k] * __uint_as_float(d4[u] & 0xffff0000u);
+      // explicit fma chain (the product of corner 10 is the plain multiply, as hipcc contracted it through round 5): "a*b + c*d + ..." leaves the choice of which product stays a plain multiply to
+      // hipcc's contraction, and that choice moved with unrelated edits (17 of 614 400 output units off by one bf16 ulp)
+      v[2 * u] = fmaf(w11[k], __uint_as_float(d4[u] << 16), fmaf(w01[k], __uint_as_float(c4[u] << 16),
+                      fmaf(w00[k], __uint_as_float(a4[u] << 16), w10[k] * __uint_as_float(b4[u] << 16))));
+      v[2 * u + 1] = fmaf(w11[k], __uint_as_float(d4[u] & 0xffff0000u), fmaf(w01[k], __uint_as_float(c4[u] & 0xffff0000u),
+                          fmaf(w00[k], __uint_as_float(a4[u] & 0xffff0000u), w10[k] * __uint_as_float(b4[u] & 0xffff0000u))));
     }
     if (ci < NCHK) {
       float* dst = sc + (is_logit ? 8 * t : LP + 16 * t + 8 * part);

@@ -890,18 +890,29 @@ __device__ __forceinline__ void msda_gsamp_body(const bf16_t* __restrict__ vp, c
   };
 #endif
   if (slot >= n_pairs) return;
-  const int pair = order ? order[slot] : slot;
-  // the pair's reference points are requested WITH its mask byte, not after it (one round trip less in front of phase A;
-  // wasted for the masked pairs: 24 bytes each)
-  float2 rpre[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) rpre[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
-  if (pair_mask && !pair_mask[pair]) {
-    *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
-    return;
+  // One lane of the quad reads the slot's pair, its mask byte (lane 0) and level `sub`'s reference point (lanes < L), the others get
+  // them by quad broadcast: the texture-address path takes one clock per 4 ACTIVE lanes of a load, and this kernel runs at the rate
+  // of that path (profiles/r06_experiments.txt sections 2, 5) -- 16 + 16 + 48 lane addresses per wavefront instead of 5 x 64.
+  // The reference points are requested WITH the mask byte, not after it (one round trip less in front of phase A; wasted for the
+  // masked pairs: 24 bytes each).
+  int pair = slot;
+  if (order) {
+    int p0 = 0;
+    if (sub == 0) p0 = order[slot];
+    pair = (int)quad_bcast<0>((unsigned)p0);
+  }
+  float2 mine = float2{0.f, 0.f};
+  if (sub < L) mine = *reinterpret_cast<const float2*>(r + ((long)pair * L + sub) * 2);
+  if (pair_mask) {
+    unsigned mk = 0;
+    if (sub == 0) mk = pair_mask[pair];
+    if (!quad_bcast<0>(mk)) {
+      *reinterpret_cast<uint4*>(samp + (long)pair * 256 + m * 32 + sub * 8) = uint4{0u, 0u, 0u, 0u};
+      return;
+    }
   }
   float acc[8];
-  gsamp_unit<L, PIPE>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc, rpre);
+  gsamp_unit<L, PIPE>(vp, G, xw, r, lv, &scratch[wave][pl][0], pair, m, sub, Lq, S, B, acc, mine);
   store_acc<bf16_t, 8>(samp + (long)pair * 256 + m * 32 + sub * 8, acc);
 #ifdef GSAMP_STAMPS
   gs_flush(true);

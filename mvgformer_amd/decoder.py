@@ -522,6 +522,11 @@ class DQDecoderLayer(MvPDecoderLayer):
         pose_layers = self.pose_embed.MLP.layers
         fuse_a, fuse_b = self._fuses_chains(dt)
         o = None
+        if self.proj_attn._vp_event is None and getattr(ctx, "_packed_event", None) is not None:
+            # this layer's pyramid products run inline on THIS stream (no side-stream launch reached it) while the pyramid was packed
+            # on the side stream (DQDecoder.pack_pyramid): order the read behind the pack and keep the allocator informed
+            torch.cuda.current_stream().wait_event(ctx._packed_event)
+            ctx.feat.record_stream(torch.cuda.current_stream())
         if fuse_a:
             # processing order of the (image, query) pairs: image-space (Morton) order, pairs outside the image last
             # (mvg_bin_pairs); shared by the sampler (L1 locality, masked pairs skipped) and chain A (all-masked
@@ -704,9 +709,23 @@ class DQDecoder(MvPDecoder):
         # per forward (profiles/r05_experiments.txt section 10).  MVG_PYRAMID_JIT = 0 | 1 overrides the choice.
         self.pyramid_jit = os.environ.get("MVG_PYRAMID_JIT", "auto")
         self.pyramid_jit_slots = int(os.environ.get("MVG_PYRAMID_JIT_SLOTS", "32"))
+        self._share_f32_pool()
+
+    def _share_f32_pool(self):
+        """the inline fp32 pyramid products share one (value, G) pair per stream -- of THIS decoder (a ProjAttn used on its own, or a
+        deep copy of one, has a private, empty pool: ProjAttn.__deepcopy__)"""
         pool = {}
-        for layer in self.layers:       # the inline fp32 pyramid products share one (value, G) pair per stream -- of THIS decoder
+        for layer in self.layers:
             layer.proj_attn._f32_pool = pool
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._share_f32_pool()           # the copy's layers share ONE fresh pool again, not one each
+        return new
 
     def set_compute_dtype(self, dtype):
         for layer in self.layers:
@@ -742,6 +761,8 @@ class DQDecoder(MvPDecoder):
         the forward / the captured graph ends) or None when the projections run inline.  forked: `side` already waits for
         whatever produced ctx.feat (pack_pyramid).  jit: the caller runs the whole forward inside ONE fork / join of `side` (not the
         segmented graphs of mvgformer_amd.dist) -- the just-in-time schedule may be used."""
+        for layer in self.layers:
+            layer._after_chain_b = None       # hooks of an earlier forward that did not reach its layer (an exception in between)
         if side is None:
             side = self.fork_side_stream(ctx.feat.device)
             if side is None:
@@ -788,9 +809,14 @@ class DQDecoder(MvPDecoder):
         """ctx.pack(src_views) -- on the side stream (forked from the current one) when every consumer of the packed pyramid runs
         there (bf16: the pyramid products), so that the first layer's prologue does not queue behind the 46-us pack; follow it
         with launch_pyramid_projections(ctx, side, forked=True)."""
+        ctx._packed_event = None
         if side is not None and self.pack_on_side and ctx.dtype == torch.bfloat16:
             with torch.cuda.stream(side):
                 ctx.pack(src_views)
+                # a consumer on ANOTHER stream (ProjAttn.native_sample's inline products, when a layer's just-in-time hook did not
+                # fire) waits on this event; ctx.feat was allocated on `side`
+                ctx._packed_event = torch.cuda.Event()
+                ctx._packed_event.record()
         else:
             ctx.pack(src_views)
             if side is not None:

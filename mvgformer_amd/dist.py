@@ -214,6 +214,7 @@ class GraphedShardedDecoder:
             layer._next_layer = None
             layer._xw_in = None
             layer._proj_in = None
+            layer._after_chain_b = None
             layer.proj_attn._vp_event = None
         self.send, self.geo = res
         self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
@@ -287,6 +288,7 @@ class SpeculativeShardedDecoder:
                 layer._next_layer = None
                 layer._xw_in = None
                 layer._proj_in = None
+                layer._after_chain_b = None     # a hook left by a body that raised must not fire in a later forward
                 layer.proj_attn._vp_event = None
         self.recv = self.send.new_empty((self.world * self.geo["nq_max"],) + tuple(self.send.shape[1:]))
         self.unpack = torch.cuda.CUDAGraph()

@@ -125,6 +125,23 @@ class ProjAttn(nn.Module):
         # hands its layers a common dict); it dies with its owner
         self._f32_pool = {}
 
+    def __deepcopy__(self, memo):
+        """copies (EMA / checkpoint copies of a decoder) get fresh, empty run-time state: the pooled fp32 (value, G) buffers
+        (0.36 GB per pair at cfg-2), the weight cache and the side-stream hand-off are not part of the module's state"""
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        skip = {"_f32_pool": dict, "_wc": WeightCache}
+        for k, v in self.__dict__.items():
+            if k in skip:
+                new.__dict__[k] = skip[k]()
+            elif k in ("_vp", "_G", "_vp_event"):
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _reset_parameters(self):
         constant_(self.sampling_offsets.weight.data, 0.)
         thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
@@ -179,6 +196,7 @@ class ProjAttn(nn.Module):
         (bench.py --f32-gemm exact, mvg_set_tuning("f32_split", 0)) both select them; with either off the fp32 path is the
         reference-arithmetic decomposition (fmaf-chain GEMMs, one launch each)"""
         from . import _lib
+        _lib.load()         # applies MVG_TUNE: before that TUNING reads as the library's defaults
         return bool(self.f32_fused) and _lib.TUNING.get("f32_split", 1) != 0
 
     def f32_g_form(self, Lq, L, S):

@@ -149,3 +149,23 @@ def test_only_the_product_and_checker_libraries_ship():
             if name.endswith(".so") or ".so." in name:
                 found.add(os.path.relpath(os.path.join(base, name), root))
     assert found <= allowed, sorted(found - allowed)
+
+
+def test_deepcopy_of_a_decoder_does_not_copy_run_time_buffers():
+    """copy.deepcopy(decoder) (EMA / checkpoint copies): parameters are copied, the pooled fp32 (value, G) buffers, weight caches and
+    side-stream hand-offs are not; the copy's layers share ONE fresh pool again."""
+    import copy
+    from mvgformer_amd.factory import build_decoder_for_case
+    from mvgformer_amd.synthetic import build_case
+    dec = build_decoder_for_case(build_case("cfg1", seed=0, layers=2), "cpu", torch.float32)
+    pa0 = dec.layers[0].proj_attn
+    pa0._f32_pool["slot"] = (torch.zeros(4), torch.zeros(4))
+    pa0._vp, pa0._G = torch.zeros(3), torch.zeros(3)
+    dec.layers[0]._after_chain_b = None
+    cp = copy.deepcopy(dec)
+    assert cp.layers[0].proj_attn._f32_pool == {} and cp.layers[0].proj_attn._f32_pool is cp.layers[1].proj_attn._f32_pool
+    assert cp.layers[0].proj_attn._f32_pool is not pa0._f32_pool and cp.layers[0].proj_attn._vp is None
+    a, b = dec.state_dict(), cp.state_dict()
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) and a[k].data_ptr() != b[k].data_ptr() for k in a)
+    single = copy.deepcopy(pa0)
+    assert single._f32_pool == {} and single._f32_pool is not pa0._f32_pool

@@ -60,3 +60,47 @@ with torch.no_grad():
     ones = torch.ones_like(msk)
     print("E3 no pair mask (all %d pairs sampled), binned order: %7.1f us" % (msk.numel(), timed(lambda: run(G, xw, ones, order))))
     print("E3b in-image pairs only, no order (pair order = query order): %7.1f us" % timed(lambda: run(G, xw, msk, None)))
+
+# ---- E4: which share of the samples of in-image pairs lies outside its map (all four corner weights zero)?
+with torch.no_grad():
+    shapes = [(int(h), int(w)) for h, w in ctx.levels.shapes]
+    starts = [int(v) for v in ctx.levels.starts]
+    Lq = ref_lvl.shape[1]
+    tot = out = border = 0
+    for n in range(ctx.V):
+        Gn = G.view(ctx.V, -1, 192)[n].float()
+        keep = inside[n].bool().view(-1)
+        ref = ref_lvl[n][keep]
+        xwq = xw.view(1, Lq, 192)[0][keep]
+        for m in range(8):
+            offs = []
+            for t in range(3):
+                fg = m * 3 + t
+                l, g_ = fg >> 3, fg & 7
+                H, W = shapes[l]
+                gx = (ref[:, l, 0] * 2 - 1).clamp(-1.1, 1.1)
+                gy = (ref[:, l, 1] * 2 - 1).clamp(-1.1, 1.1)
+                px, py = ((gx + 1) * W - 1) * 0.5, ((gy + 1) * H - 1) * 0.5
+                x0, y0 = torch.floor(px), torch.floor(py)
+                acc = 0
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        xi, yi = x0 + dx, y0 + dy
+                        w = (1 - (px - xi).abs()) * (1 - (py - yi).abs())
+                        ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                        idx = starts[l] + yi.clamp(0, H - 1).long() * W + xi.clamp(0, W - 1).long()
+                        acc = acc + (w * ok)[:, None] * Gn[idx][:, 24 * g_:24 * g_ + 16]
+                offs.append(acc + xwq[:, 24 * g_:24 * g_ + 16])
+            offs = torch.cat(offs, 1).view(-1, 24, 2)
+            for i in range(24):
+                l2 = i // 8
+                H, W = shapes[l2]
+                w_im = (ref[:, l2, 0] + offs[:, i, 0] / W) * W - 0.5
+                h_im = (ref[:, l2, 1] + offs[:, i, 1] / H) * H - 0.5
+                ins = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+                full = (h_im >= 0) & (w_im >= 0) & (h_im <= H - 1) & (w_im <= W - 1)
+                tot += ins.numel()
+                out += int((~ins).sum())
+                border += int((ins & ~full).sum())
+    print("E4 samples of in-image pairs: %d; outside their map (4 zero corners) %.2f %%; on the border (1-2 zero rows / columns) %.2f %%"
+          % (tot, 100.0 * out / tot, 100.0 * border / tot))
