@@ -378,11 +378,80 @@ __device__ __forceinline__ void jacobi_rotate2(double (&a)[4][4], double (&v)[4]
   jacobi_apply(a, v, p2, q2, c2, s2);
 }
 
+// ---- the null direction of the DLT's Gram matrix by inverse iteration (round 6; multiview.py:208-221 takes the right singular
+// vector of the smallest singular value of the row matrix A = the eigenvector of the smallest eigenvalue of G = A^T A).
+// G = L D L^T without pivoting (G is a Gram matrix: positive semi-definite), then x <- G^-1 x: the component along the smallest
+// eigenvalue grows by lambda_3 / lambda_4 per solve -- 1e3 ... 1e10 for rays that meet, so 3 solves settle 16 digits -- and a
+// solve is 12 fma + 4 multiplies where a Jacobi sweep is ~350 dependent fp64 instructions (the cyclic Jacobi was 60 % of the
+// triangulation kernel: ~2 100 dependent instructions on ONE wavefront per workgroup, profiles/r05_experiments.txt).  Accuracy:
+// Cholesky-type factors inherit the scaling D0 G D0 of the matrix (the homogeneous column of P is 1e3 x the others), so the
+// vector is exact to cond(scaled G) x eps -- measured 1e-8 mm against the fp64 SVD of the row matrix where LAPACK's eigh on G
+// itself is off by up to millimetres (profiles/r06_experiments.txt section 6).
+// Per lane and deterministic: rounds of 4 solves from x = (1,1,1,1); a round ends with the test "last two iterates parallel to
+// 1e-11"; a lane that passed keeps its vector whatever its wavefront neighbours still do (so a problem's result does not depend
+// on which problems share its wavefront: query-sharded and single-rank runs agree bit for bit).  Returns false -- the caller
+// falls back to the Jacobi -- for a matrix whose first three pivots are not safely positive (fewer than 2 useful views) or
+// whose iteration has not settled after 4 rounds (lambda_4 / lambda_3 > ~0.2: rays that do not meet at all).
+__device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], double (&ev)[4]) {
+  const double g10 = G[0][1], g20 = G[0][2], g30 = G[0][3], g21 = G[1][2], g31 = G[1][3], g32 = G[2][3];
+  const double d0 = G[0][0];
+  const double i0 = 1.0 / d0;
+  const double l10 = g10 * i0, l20 = g20 * i0, l30 = g30 * i0;
+  const double d1 = G[1][1] - l10 * g10;
+  const double i1 = 1.0 / d1;
+  const double t21 = g21 - l20 * g10, t31 = g31 - l30 * g10;
+  const double l21 = t21 * i1, l31 = t31 * i1;
+  const double d2 = G[2][2] - l20 * g20 - l21 * t21;
+  const double i2 = 1.0 / d2;
+  const double t32 = g32 - l30 * g20 - l31 * t21;
+  const double l32 = t32 * i2;
+  double d3 = G[3][3] - l30 * g30 - l31 * t31 - l32 * t32;
+  // rays that meet exactly: d3 is rounding noise of either sign -- any tiny positive pivot makes the solve return the null direction
+  d3 = fmax(d3, 1e-18 * G[3][3]);
+  const double i3 = 1.0 / d3;
+  const bool pivots_ok = d0 > 0.0 && d1 > 1e-13 * G[1][1] && d2 > 1e-13 * G[2][2];       // (false for NaN)
+  double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
+  bool done = false;
+  for (int round = 0; round < 4; ++round) {
+    double p0 = x0, p1 = x1, p2 = x2, p3 = x3, w0 = x0, w1 = x1, w2 = x2, w3 = x3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      p0 = w0; p1 = w1; p2 = w2; p3 = w3;
+      const double y1 = w1 - l10 * w0;                        // L y = w
+      const double y2 = w2 - l20 * w0 - l21 * y1;
+      const double y3 = w3 - l30 * w0 - l31 * y1 - l32 * y2;
+      const double z0 = w0 * i0, z1 = y1 * i1, z2 = y2 * i2;  // D z = y
+      w3 = y3 * i3;                                           // L^T w = z
+      w2 = z2 - l32 * w3;
+      w1 = z1 - l21 * w2 - l31 * w3;
+      w0 = z0 - l10 * w1 - l20 * w2 - l30 * w3;
+    }
+    // parallel?  every 2 x 2 minor of (w | p) against the product of the two largest components
+    const double mw = fmax(fmax(fabs(w0), fabs(w1)), fmax(fabs(w2), fabs(w3)));
+    const double mp = fmax(fmax(fabs(p0), fabs(p1)), fmax(fabs(p2), fabs(p3)));
+    const double c01 = fabs(w0 * p1 - w1 * p0), c02 = fabs(w0 * p2 - w2 * p0), c03 = fabs(w0 * p3 - w3 * p0);
+    const double c12 = fabs(w1 * p2 - w2 * p1), c13 = fabs(w1 * p3 - w3 * p1), c23 = fabs(w2 * p3 - w3 * p2);
+    const double cmax = fmax(fmax(fmax(c01, c02), fmax(c03, c12)), fmax(c13, c23));
+    const bool parallel = cmax <= 1e-11 * mw * mp;            // (false for NaN / Inf)
+    // rescale by a power of two (exact) so that 16 solves cannot overflow
+    const int ex = ilogb(mw);
+    const double s0 = scalbn(w0, -ex), s1 = scalbn(w1, -ex), s2 = scalbn(w2, -ex), s3 = scalbn(w3, -ex);
+    if (!done) {
+      x0 = s0; x1 = s1; x2 = s2; x3 = s3;
+      done = parallel;
+    }
+    if (__all(done || !pivots_ok)) break;
+  }
+  ev[0] = x0; ev[1] = x1; ev[2] = x2; ev[3] = x3;
+  return done && pivots_ok;
+}
+
 // Two phases per workgroup of 512 threads = 64 (batch, query, joint) problems:
 //   1. 8 lanes per problem: lane `sub` handles views sub, sub+8, ... (view-softmax, un-crop, undistortion, its two
 //      DLT rows and their contribution to the 4x4 Gram matrix) -- one load round trip for the whole problem;
 //      the partial Gram matrices (upper triangle, fp64) go to LDS.
-//   2. one lane per problem (the first wavefront): sums the 8 partials and runs the fp64 Jacobi.
+//   2. one lane per problem (the first wavefront): sums the 8 partials and takes the null direction of the Gram matrix by inverse
+//      iteration (null_vector_invit; the fp64 Jacobi of rounds 1-5 is the fallback for matrices it declines).
 // (All 8 lanes of a problem running the Jacobi redundantly made the kernel fp64-VALU-bound: 14 of its 22 us at
 // cfg-2; one thread per problem for BOTH phases took 27 us: 240 wavefronts, each a chain of dependent loads.)
 constexpr int TRI_PROBS = 64;           // problems per workgroup
@@ -718,7 +787,7 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
   }
 
   double ev[4];
-  {
+  if (!null_vector_invit(G, ev)) {
     double Vm[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)

@@ -477,6 +477,39 @@ def test_triangulation_known_answer_noise_free():
         assert torch.equal(ref2d, proj2d)                                     # zero offsets
 
 
+def test_triangulation_result_does_not_depend_on_the_wavefront_neighbours():
+    """The DLT's null vector is taken by inverse iteration (rounds of 4 solves, a lane stops when ITS iterates are parallel) with the
+    fp64 Jacobi as the fallback for rays that do not meet: a problem's bits must not depend on which problems share its wavefront
+    (query-sharded runs are compared bit for bit with single-rank runs).  Persons with exact projections, persons with 2D points
+    thrown off by up to 300 px (slow convergence / fallback) and persons seen by one useful view (degenerate pivots), in two
+    different orders; and every finite result is the null direction of its own fp64 row matrix."""
+    from mvgformer_amd import ops
+    from mvgformer_amd.synthetic import CONFIGS, make_meta, ring_cameras
+    c = dict(CONFIGS["cfg4"])                                                # k = p = 0: the undistortion is exact
+    V, NQ, J = 5, 64, 15
+    cams_np = ring_cameras(V, c["orig_wh"], c["focal"], c["radius"], c["space_center"], c["k"], c["p"], seed=3)
+    meta = make_meta(cams_np, 1, c["orig_wh"], c["img_wh"])
+    cams = ops.pack_cameras(meta, c["img_wh"], DEV)
+    rs = np.random.RandomState(9)
+    X = torch.from_numpy((np.asarray(c["space_center"]) + rs.uniform(-1500, 1500, (1, NQ * J, 3))).astype(np.float32))
+    r, _, _ = ops.project(X.to(DEV), cams, ops.Levels([[8, 8]], [0]), V, 1)
+    o = torch.zeros((V, NQ, J, 3))
+    o[:, 16:40, :, :2] = torch.from_numpy(rs.uniform(-300, 300, (V, 24, J, 2)).astype(np.float32))      # rays that do not meet
+    o[1:, 40:48, :, 2] = -60.0                                                                           # one view carries all the weight
+    o = o.view(V, NQ * J, 3).to(DEV)
+    valid = torch.ones((1, NQ), dtype=torch.uint8, device=DEV)
+    anyv = torch.ones((1,), dtype=torch.int32, device=DEV)
+    Xa = ops.triangulate(r, o, cams, valid, anyv, V, 1, NQ, J)[0].view(NQ, J, 3)
+    perm = torch.from_numpy(rs.permutation(NQ)).to(DEV)
+    rp = r.view(V, NQ, J, 2)[:, perm].reshape(V, NQ * J, 2).contiguous()
+    op = o.view(V, NQ, J, 3)[:, perm].reshape(V, NQ * J, 3).contiguous()
+    Xb = ops.triangulate(rp, op, cams, valid, anyv, V, 1, NQ, J)[0].view(NQ, J, 3)
+    assert torch.equal(Xa[perm].view(torch.int32), Xb.view(torch.int32))
+    err = (Xa[:16].cpu().view(-1, 3) - X[0, :16 * J]).norm(dim=-1).max()
+    assert float(err) < 0.2, float(err)                                       # mm: the persons with exact projections
+    assert torch.isfinite(Xa[:40]).all()
+
+
 # ------------------------------------------------------------------------- the decoder layer(s)
 TOL = dict(hs=1e-4, px=2e-3, mm=1.5, cls=5e-6)
 
