@@ -380,51 +380,75 @@ __device__ __forceinline__ void jacobi_rotate2(double (&a)[4][4], double (&v)[4]
 
 // ---- the null direction of the DLT's Gram matrix by inverse iteration (round 6; multiview.py:208-221 takes the right singular
 // vector of the smallest singular value of the row matrix A = the eigenvector of the smallest eigenvalue of G = A^T A).
-// G = L D L^T without pivoting (G is a Gram matrix: positive semi-definite), then x <- G^-1 x: the component along the smallest
-// eigenvalue grows by lambda_3 / lambda_4 per solve -- 1e3 ... 1e10 for rays that meet, so 3 solves settle 16 digits -- and a
-// solve is 12 fma + 4 multiplies where a Jacobi sweep is ~350 dependent fp64 instructions (the cyclic Jacobi was 60 % of the
-// triangulation kernel: ~2 100 dependent instructions on ONE wavefront per workgroup, profiles/r05_experiments.txt).  Accuracy:
-// Cholesky-type factors inherit the scaling D0 G D0 of the matrix (the homogeneous column of P is 1e3 x the others), so the
-// vector is exact to cond(scaled G) x eps -- measured 1e-8 mm against the fp64 SVD of the row matrix where LAPACK's eigh on G
-// itself is off by up to millimetres (profiles/r06_experiments.txt section 6).
-// Per lane and deterministic: rounds of 4 solves from x = (1,1,1,1); a round ends with the test "last two iterates parallel to
-// 1e-11"; a lane that passed keeps its vector whatever its wavefront neighbours still do (so a problem's result does not depend
-// on which problems share its wavefront: query-sharded and single-rank runs agree bit for bit).  Returns false -- the caller
-// falls back to the Jacobi -- for a matrix whose first three pivots are not safely positive (fewer than 2 useful views) or
-// whose iteration has not settled after 4 rounds (lambda_4 / lambda_3 > ~0.2: rays that do not meet at all).
-__device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], double (&ev)[4]) {
+// G - sigma I = L D L^T without pivoting (positive definite as long as sigma < lambda_4), then x <- (G - sigma I)^-1 x: the component
+// along the smallest eigenvalue grows by (lambda_3 - sigma) / (lambda_4 - sigma) per solve, and a solve is 12 fma + 4 multiplies
+// where a Jacobi sweep is ~350 dependent fp64 instructions (the cyclic Jacobi was 60 % of the triangulation kernel: ~2 100 dependent
+// instructions on ONE wavefront per workgroup, profiles/r05_experiments.txt).
+//   * sigma = 0 first: rays that meet have lambda_4 / lambda_3 = 1e-10 ... 1e-3 and settle in one or two rounds of 4 solves;
+//   * rays that do not meet (a view whose projection was clamped at the image border contributes a wrong ray: a third of the
+//     (view, query) pairs at cfg-2's synthetic poses) have ratios up to ~1: after every round that has not settled the shift moves
+//     to sigma = rho - |G x - rho x| (Rayleigh quotient minus residual: an eigenvalue lies within the residual of rho, so sigma stays
+//     below lambda_4 once x leans towards it -- and the new factors are only taken if all four pivots are positive, i.e. sigma
+//     IS below lambda_4).  Convergence becomes superlinear: <= 3 rounds for > 99 % of such matrices (numpy model of this routine,
+//     profiles/r06_experiments.txt section 6); what has not settled after MAXR rounds goes to the Jacobi.
+// Accuracy: Cholesky-type factors inherit the scaling D0 G D0 of the matrix (the homogeneous column of P is 1e3 x the others), so the
+// vector is exact to cond(scaled G) x eps -- 1e-6 mm against the fp64 SVD of the row matrix in the model, where LAPACK's eigh on G
+// itself is off by up to millimetres.
+// Per lane and deterministic: a round ends with the test "last two iterates parallel to 1e-11"; a lane that passed keeps its vector
+// whatever its wavefront neighbours still do (a problem's result does not depend on which problems share its wavefront: query-
+// sharded and single-rank runs agree bit for bit).  Returns false -- the caller falls back to the Jacobi -- for a matrix whose
+// first three pivots are not safely positive (fewer than 2 useful views) or that has not settled.
+struct Ldl4 {
+  double i0, i1, i2, i3, l10, l20, l30, l21, l31, l32;
+};
+template <bool FIRST>
+__device__ __forceinline__ bool ldl4_factor(const double (&G)[4][4], double sigma, Ldl4& f) {
   const double g10 = G[0][1], g20 = G[0][2], g30 = G[0][3], g21 = G[1][2], g31 = G[1][3], g32 = G[2][3];
-  const double d0 = G[0][0];
+  const double d0 = G[0][0] - sigma;
   const double i0 = 1.0 / d0;
   const double l10 = g10 * i0, l20 = g20 * i0, l30 = g30 * i0;
-  const double d1 = G[1][1] - l10 * g10;
+  const double d1 = G[1][1] - sigma - l10 * g10;
   const double i1 = 1.0 / d1;
   const double t21 = g21 - l20 * g10, t31 = g31 - l30 * g10;
   const double l21 = t21 * i1, l31 = t31 * i1;
-  const double d2 = G[2][2] - l20 * g20 - l21 * t21;
+  const double d2 = G[2][2] - sigma - l20 * g20 - l21 * t21;
   const double i2 = 1.0 / d2;
   const double t32 = g32 - l30 * g20 - l31 * t21;
   const double l32 = t32 * i2;
-  double d3 = G[3][3] - l30 * g30 - l31 * t31 - l32 * t32;
-  // rays that meet exactly: d3 is rounding noise of either sign -- any tiny positive pivot makes the solve return the null direction
-  d3 = fmax(d3, 1e-18 * G[3][3]);
-  const double i3 = 1.0 / d3;
-  const bool pivots_ok = d0 > 0.0 && d1 > 1e-13 * G[1][1] && d2 > 1e-13 * G[2][2];       // (false for NaN)
+  double d3 = G[3][3] - sigma - l30 * g30 - l31 * t31 - l32 * t32;
+  bool ok;
+  if (FIRST) {
+    // rays that meet exactly: d3 is rounding noise of either sign -- any tiny positive pivot makes the solve return the null direction
+    d3 = fmax(d3, 1e-18 * G[3][3]);
+    ok = d0 > 0.0 && d1 > 1e-13 * G[1][1] && d2 > 1e-13 * G[2][2];          // (false for NaN)
+  } else {
+    ok = d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0;                       // sigma < lambda_4
+  }
+  f.i0 = i0; f.i1 = i1; f.i2 = i2; f.i3 = 1.0 / d3;
+  f.l10 = l10; f.l20 = l20; f.l30 = l30; f.l21 = l21; f.l31 = l31; f.l32 = l32;
+  return ok;
+}
+
+__device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], double (&ev)[4]) {
+  constexpr int MAXR = 8;
+  Ldl4 f;
+  const bool pivots_ok = ldl4_factor<true>(G, 0.0, f);
+  double sigma = 0.0;
   double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
   bool done = false;
-  for (int round = 0; round < 4; ++round) {
+  for (int round = 0; round < MAXR; ++round) {
     double p0 = x0, p1 = x1, p2 = x2, p3 = x3, w0 = x0, w1 = x1, w2 = x2, w3 = x3;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       p0 = w0; p1 = w1; p2 = w2; p3 = w3;
-      const double y1 = w1 - l10 * w0;                        // L y = w
-      const double y2 = w2 - l20 * w0 - l21 * y1;
-      const double y3 = w3 - l30 * w0 - l31 * y1 - l32 * y2;
-      const double z0 = w0 * i0, z1 = y1 * i1, z2 = y2 * i2;  // D z = y
-      w3 = y3 * i3;                                           // L^T w = z
-      w2 = z2 - l32 * w3;
-      w1 = z1 - l21 * w2 - l31 * w3;
-      w0 = z0 - l10 * w1 - l20 * w2 - l30 * w3;
+      const double y1 = w1 - f.l10 * w0;                            // L y = w
+      const double y2 = w2 - f.l20 * w0 - f.l21 * y1;
+      const double y3 = w3 - f.l30 * w0 - f.l31 * y1 - f.l32 * y2;
+      const double z0 = w0 * f.i0, z1 = y1 * f.i1, z2 = y2 * f.i2;  // D z = y
+      w3 = y3 * f.i3;                                               // L^T w = z
+      w2 = z2 - f.l32 * w3;
+      w1 = z1 - f.l21 * w2 - f.l31 * w3;
+      w0 = z0 - f.l10 * w1 - f.l20 * w2 - f.l30 * w3;
     }
     // parallel?  every 2 x 2 minor of (w | p) against the product of the two largest components
     const double mw = fmax(fmax(fabs(w0), fabs(w1)), fmax(fabs(w2), fabs(w3)));
@@ -432,8 +456,8 @@ __device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], doubl
     const double c01 = fabs(w0 * p1 - w1 * p0), c02 = fabs(w0 * p2 - w2 * p0), c03 = fabs(w0 * p3 - w3 * p0);
     const double c12 = fabs(w1 * p2 - w2 * p1), c13 = fabs(w1 * p3 - w3 * p1), c23 = fabs(w2 * p3 - w3 * p2);
     const double cmax = fmax(fmax(fmax(c01, c02), fmax(c03, c12)), fmax(c13, c23));
-    const bool parallel = cmax <= 1e-11 * mw * mp;            // (false for NaN / Inf)
-    // rescale by a power of two (exact) so that 16 solves cannot overflow
+    const bool parallel = cmax <= 1e-11 * mw * mp;                  // (false for NaN / Inf)
+    // rescale by a power of two (exact): no overflow however many rounds follow
     const int ex = ilogb(mw);
     const double s0 = scalbn(w0, -ex), s1 = scalbn(w1, -ex), s2 = scalbn(w2, -ex), s3 = scalbn(w3, -ex);
     if (!done) {
@@ -441,6 +465,25 @@ __device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], doubl
       done = parallel;
     }
     if (__all(done || !pivots_ok)) break;
+    if (!done) {
+      // not settled: lambda_4 / lambda_3 is not small.  Shift to just below the Rayleigh quotient for the next round.
+      const double n2 = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+      const double a0 = G[0][0] * x0 + G[0][1] * x1 + G[0][2] * x2 + G[0][3] * x3;
+      const double a1 = G[0][1] * x0 + G[1][1] * x1 + G[1][2] * x2 + G[1][3] * x3;
+      const double a2 = G[0][2] * x0 + G[1][2] * x1 + G[2][2] * x2 + G[2][3] * x3;
+      const double a3 = G[0][3] * x0 + G[1][3] * x1 + G[2][3] * x2 + G[3][3] * x3;
+      const double in2 = 1.0 / n2;
+      const double rho = (x0 * a0 + x1 * a1 + x2 * a2 + x3 * a3) * in2;
+      const double r0 = a0 - rho * x0, r1 = a1 - rho * x1, r2 = a2 - rho * x2, r3 = a3 - rho * x3;
+      const double cand = rho - sqrt((r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) * in2);
+      if (cand > sigma) {
+        Ldl4 f2;
+        if (ldl4_factor<false>(G, cand, f2)) {
+          f = f2;
+          sigma = cand;
+        }
+      }
+    }
   }
   ev[0] = x0; ev[1] = x1; ev[2] = x2; ev[3] = x3;
   return done && pivots_ok;
@@ -787,7 +830,12 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
   }
 
   double ev[4];
-  if (!null_vector_invit(G, ev)) {
+  const bool need_jacobi = !null_vector_invit(G, ev);
+#ifdef TRI_STAMPS
+  tst_[9] = __popcll(__ballot(need_jacobi));      // lanes of the solving wavefront that fall back to the Jacobi
+  TSTAMP(10);
+#endif
+  if (need_jacobi) {
     double Vm[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)

@@ -491,7 +491,7 @@ def test_triangulation_result_does_not_depend_on_the_wavefront_neighbours():
     meta = make_meta(cams_np, 1, c["orig_wh"], c["img_wh"])
     cams = ops.pack_cameras(meta, c["img_wh"], DEV)
     rs = np.random.RandomState(9)
-    X = torch.from_numpy((np.asarray(c["space_center"]) + rs.uniform(-1500, 1500, (1, NQ * J, 3))).astype(np.float32))
+    X = torch.from_numpy((np.asarray(c["space_center"]) + rs.uniform(-800, 800, (1, NQ * J, 3))).astype(np.float32))
     r, _, _ = ops.project(X.to(DEV), cams, ops.Levels([[8, 8]], [0]), V, 1)
     o = torch.zeros((V, NQ, J, 3))
     o[:, 16:40, :, :2] = torch.from_numpy(rs.uniform(-300, 300, (V, 24, J, 2)).astype(np.float32))      # rays that do not meet

@@ -56,4 +56,7 @@ for li, idx in enumerate(np.split(order, cuts)):
     clk = (t[idx, last] - t[idx, 4]) / np.maximum((en - st) * 1e3, 1)
     print("launch %d: %d workgroups; span %.1f us; start median %.1f max %.1f; life median %.1f max %.1f us; clock %.2f GHz" % (
         li, len(idx), en.max(), np.median(st), st.max(), np.median(en - st), (en - st).max(), np.median(clk)))
-    print("   cycles (thread 0 = the Jacobi wavefront): " + " | ".join("%s %d" % (nm, np.median(d[:, i])) for i, nm in enumerate(names[: d.shape[1]])))
+    print("   cycles (thread 0 = the solving wavefront): " + " | ".join("%s %d" % (nm, np.median(d[:, i])) for i, nm in enumerate(names[: d.shape[1]])))
+    fb = t[idx, 9]
+    print("   inverse iteration: %d cycles (median, barrier -> vector); wavefronts with a Jacobi fallback lane: %d of %d, fallback lanes %d of %d"
+          % (np.median(t[idx, 10] - t[idx, 6]), int((fb > 0).sum()), len(idx), int(fb.sum()), 64 * len(idx)))
