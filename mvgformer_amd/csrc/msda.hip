@@ -623,10 +623,26 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
   const int g = lane >> 3, sub = lane & 7;
   const int slot = pb * 32 + wave * 8 + g;
   if (slot >= n_pairs) return;                         // whole 8-lane groups leave (the exchanges below stay inside a group)
-  const int pair = order ? order[slot] : slot;
-  if (pair_mask && !pair_mask[pair]) {
-    *reinterpret_cast<f32x4*>(samp + (long)pair * C + m * D + sub * CPL) = f32x4{0.f, 0.f, 0.f, 0.f};
-    return;
+  // Round 6: lane 0 of the group reads the slot's pair and its mask byte, lanes 0..L-1 the reference point of level `lane`; the
+  // others get them through the swizzle crossbar.  The texture-address path takes a clock per 4 ACTIVE lanes of a load and this
+  // kernel runs at its rate (profiles/r06_experiments.txt sections 2, 5): 8 + 8 + 8 L lane addresses per wavefront for 5 x 64.
+#define MVG_GRP8(K, X) __builtin_amdgcn_ds_swizzle((X), 24 | ((K) << 5))      /* value of lane K of every group of 8 lanes */
+  static_assert(L <= 8, "lane `sub` of a group carries the reference point of level `sub`");
+  int pair = slot;
+  if (order) {
+    int p0 = 0;
+    if (sub == 0) p0 = order[slot];
+    pair = MVG_GRP8(0, p0);
+  }
+  float2 mine = float2{0.f, 0.f};
+  if (sub < L) mine = *reinterpret_cast<const float2*>(r + ((long)pair * L + sub) * 2);
+  if (pair_mask) {
+    int mk = 0;
+    if (sub == 0) mk = pair_mask[pair];
+    if (!MVG_GRP8(0, mk)) {
+      *reinterpret_cast<f32x4*>(samp + (long)pair * C + m * D + sub * CPL) = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
   }
   const bool live = true;
   const int n = pair / Lq, q = pair - n * Lq, b = n % B;
@@ -639,7 +655,20 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
   constexpr int NPC = 6 * L, NK = (NPC + 7) / 8;
   float2 rr[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const float2*>(r + ((long)pair * L + l) * 2);
+  for (int l = 0; l < L; ++l) {
+    const int mx_ = __float_as_int(mine.x), my_ = __float_as_int(mine.y);
+    switch (l) {          // (the swizzle pattern is an immediate)
+      case 0: rr[l] = float2{__int_as_float(MVG_GRP8(0, mx_)), __int_as_float(MVG_GRP8(0, my_))}; break;
+      case 1: rr[l] = float2{__int_as_float(MVG_GRP8(1, mx_)), __int_as_float(MVG_GRP8(1, my_))}; break;
+      case 2: rr[l] = float2{__int_as_float(MVG_GRP8(2, mx_)), __int_as_float(MVG_GRP8(2, my_))}; break;
+      case 3: rr[l] = float2{__int_as_float(MVG_GRP8(3, mx_)), __int_as_float(MVG_GRP8(3, my_))}; break;
+      case 4: rr[l] = float2{__int_as_float(MVG_GRP8(4, mx_)), __int_as_float(MVG_GRP8(4, my_))}; break;
+      case 5: rr[l] = float2{__int_as_float(MVG_GRP8(5, mx_)), __int_as_float(MVG_GRP8(5, my_))}; break;
+      case 6: rr[l] = float2{__int_as_float(MVG_GRP8(6, mx_)), __int_as_float(MVG_GRP8(6, my_))}; break;
+      default: rr[l] = float2{__int_as_float(MVG_GRP8(7, mx_)), __int_as_float(MVG_GRP8(7, my_))}; break;
+    }
+  }
+#undef MVG_GRP8
   f32x4 ga[NK], gb[NK], gc[NK], gd[NK], gx4[NK];
   float w00[NK], w10[NK], w01[NK], w11[NK];
 #pragma unroll
@@ -672,11 +701,16 @@ __global__ __launch_bounds__(256, MVG_GFUSED_HP_OCC) void msda_gfused_f32_hp_ker
     const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1);
     const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
     const float* gp = G + ((long)n * S + lv.start[l]) * 192 + col;
-    ga[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y0c * W + x0c) * 192);
-    gb[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y0c * W + x1c) * 192);
-    gc[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y1c * W + x0c) * 192);
-    gd[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y1c * W + x1c) * 192);
-    gx4[k] = *reinterpret_cast<const f32x4*>(xw + ((long)b * Lq + q) * 192 + col);
+    // the last round has pieces for NPC % 8 lanes of the group only: the others do not load (nor store below)
+    if (8 * k + 8 <= NPC || sub + 8 * k < NPC) {
+      ga[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y0c * W + x0c) * 192);
+      gb[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y0c * W + x1c) * 192);
+      gc[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y1c * W + x0c) * 192);
+      gd[k] = *reinterpret_cast<const f32x4*>(gp + (long)(y1c * W + x1c) * 192);
+      gx4[k] = *reinterpret_cast<const f32x4*>(xw + ((long)b * Lq + q) * 192 + col);
+    } else {
+      ga[k] = gb[k] = gc[k] = gd[k] = gx4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
