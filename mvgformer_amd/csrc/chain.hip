@@ -548,6 +548,7 @@ __global__ __launch_bounds__(NT) void chain_b_kernel(
 }  // namespace
 
 extern int g_auto_small;   // tuning knob "auto_small" (msda.hip): launches with few rows pick smaller tiles (bit-identical rows)
+int g_chain_a_lds_pad = 0;   // probe knob "chain_a_lds_pad": unused dynamic LDS per chain-A workgroup (caps the workgroups per CU)
 int g_chain_rm = 128;  // tuning knob "chain_rm": rows per workgroup of chain A (64 | 128 | 256); 128: 65 -> 55 us (half the weight
                        // bytes per row).  Geometries measured and deleted (rounds 1-4, Appendix A of DESIGN.md): 8 wavefronts for
                        // chain A (93 vs 79 us), 4 wavefronts / row-block split / fragment rings of 8 and 16 for chain B.
@@ -556,14 +557,14 @@ template <int RM, int NT, int JN>
 static int launch_chain_a(const void* samp, const uint8_t* inside, const void* Wp, const float* bp, const void* W0,
                           const float* b0, const void* W1, const float* b1, const float* W2, const float* b2, void* attn,
                           float* o, const int* order, const float* o_masked, int rows, hipStream_t st) {
-  const size_t lds = RM * ACT_PITCH + 2 * RM * sizeof(int) + 768 * sizeof(float);
+  const size_t lds = RM * ACT_PITCH + 2 * RM * sizeof(int) + 768 * sizeof(float) + (size_t)g_chain_a_lds_pad;
   // the attribute is per DEVICE: a process that drives several GPUs configures the > 64-KB LDS kernels on each of them
   static bool configured[MVG_MAX_DEVICES] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVG_MAX_DEVICES) return MVG_E_BADARG;
   if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_a_kernel<RM, NT, JN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return (int)e;
     configured[dev] = true;
   }

@@ -1248,6 +1248,7 @@ int mvg_msda_gsamp(const void* vp, const void* G, const float* xw, const float* 
 }
 
 extern int g_chain_rm;
+extern int g_chain_a_lds_pad;
 extern int g_linear_tiles;
 extern int g_f32_split;
 extern int g_wreg_grid;
@@ -1267,6 +1268,7 @@ int mvg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "fwd_map") && (value >= 0 && value <= 2)) { g_fwd_map = value; return 0; }
   if (!strcmp(key, "gfused_chunk") && value >= 0 && value <= 4096) { g_gfused_chunk = value; return 0; }
   if (!strcmp(key, "gsamp_pipe") && value >= 0 && value <= 2) { g_gsamp_pipe = value; return 0; }
+  if (!strcmp(key, "chain_a_lds_pad") && value >= 0 && value <= 120 * 1024) { g_chain_a_lds_pad = value; return 0; }
   if (!strcmp(key, "gsamp_lds_pad") && value >= 0 && value <= 120 * 1024) { g_gsamp_lds_pad = value; return 0; }
   if (!strcmp(key, "gsamp_threads") && (value == 128 || value == 256 || value == 512 || value == 1024)) { g_gsamp_threads = value; return 0; }
   return MVG_E_BADARG;
