@@ -128,6 +128,10 @@ __device__ __forceinline__ GFoot g_footprint(const float2 (&rr)[L], int l, const
   return f;
 }
 
+#ifdef GSAMP_EMUL_LDS_WINDOW
+__shared__ __attribute__((aligned(16))) char gsamp_emul_window[32768];
+#endif
+
 // One (image-query pair, head) of the G-sampling kernel, computed by the 4 lanes of a quad (lane `sub` owns channels
 // [8 sub, 8 sub + 8) of the head): phase A gathers the head's L*P logits + 2*L*P offsets = bilinear(G) + xw into the
 // quad-private LDS row `sc` (3*L*P + 8 floats), pass 1 takes the softmax denominator, pass 2 samples the head plane.
@@ -317,6 +321,17 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
     unsigned cw_t, cw_b, co_t, co_b, co_x;
     gsamp_coords<L>(0, sc, mx, lv, sub, cw_t, cw_b, co_t, co_b, co_x);
     uint4 ra[2][4], rb[2][4];
+#ifdef GSAMP_EMUL_LDS_WINDOW   // timing probe only (results garbage): the value gathers as ds_read_b128 from a 64-KB LDS window
+#define MVG_ISSUE(BUF, J, SS)                                                                           \
+    {                                                                                                   \
+      const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;        \
+      const unsigned dxs = quad_bcast<SS>(co_x);                                                        \
+      BUF[J][0] = *reinterpret_cast<const uint4*>(gsamp_emul_window + (ot & 0x7ff0u));                  \
+      BUF[J][1] = *reinterpret_cast<const uint4*>(gsamp_emul_window + ((ot + dxs) & 0x7ff0u));          \
+      BUF[J][2] = *reinterpret_cast<const uint4*>(gsamp_emul_window + (ob & 0x7ff0u));                  \
+      BUF[J][3] = *reinterpret_cast<const uint4*>(gsamp_emul_window + ((ob + dxs) & 0x7ff0u));          \
+    }
+#else
 #define MVG_ISSUE(BUF, J, SS)                                                                           \
     {                                                                                                   \
       const unsigned ot = quad_bcast<SS>(co_t) + lane_off, ob = quad_bcast<SS>(co_b) + lane_off;        \
@@ -326,6 +341,7 @@ __device__ __forceinline__ void gsamp_unit(const bf16_t* __restrict__ vp, const 
       BUF[J][2] = *reinterpret_cast<const uint4*>(vp_bytes + ob);                                       \
       BUF[J][3] = *reinterpret_cast<const uint4*>(vp_bytes + (ob + dxs));                               \
     }
+#endif
 #define MVG_BLEND(BUF, J, SS)                                                                           \
     _Pragma("unroll") for (int row = 0; row < 2; ++row) {                                               \
       const unsigned wv = row ? pw_b : pw_t;                                                            \
