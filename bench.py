@@ -312,12 +312,13 @@ def measure_secondary(config, dtype_name, inside, batch, dev, steps=20, warmup=3
                        % (config, case.V, case.NQ, case.layers, case.shapes, batch,
                           "grid, ~10 % of the queries pass the 0.1 threshold" if inside == "valid10" else
                           "grid, pyramid handed over in the packed layout (no per-step pack)" if inside == "inplace" else inside),
-           "dtype": dtype_name, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "ms_per_step_median": round(median, 4),
+           "dtype": dtype_name, "steps": steps, "ms_per_step": round(median, 4),
+           "ms_per_step_median": round(median, 4), "ms_per_step_mean": round(elapsed / steps * 1e3, 4),
+           "ms_per_step_min_max": [round(per_step[0], 4), round(per_step[-1], 4)],
            "ms_per_sample": round(median / batch, 4), "value": round(batch * steps / elapsed, 3),
            "unit": "samples/s", "hip_graph": True, "valid_query_share_last_layer": round(valid_share, 4),
-           "note": "ms_per_step = wall clock / steps (what `value` is computed from); ms_per_step_median and ms_per_sample from the "
-                   "median of the per-replay HIP-event intervals"}
+           "note": "as in the headline: ms_per_step (= ms_per_step_median) and ms_per_sample from the median of the per-replay HIP-event "
+                   "intervals, ms_per_step_mean = wall clock / steps, which `value` is computed from"}
     if dtype_name == "fp32":
         rec["fp32_form"] = FP32_FORM
     if key is not None:

@@ -92,6 +92,9 @@ def test_bench_line_has_the_contract_fields():
         assert rec["dtype"] == ("fp32" if name.endswith("fp32") else "bf16")
     assert sec["cfg2_bf16_producer_inplace"]["ms_per_step_median"] < 1.02 * d["ms_per_step"]     # no per-step pack
     assert sec["cfg5_bf16"]["ms_per_step"] > sec["cfg2_fp32"]["ms_per_step"] > d["ms_per_step"]
+    for name, rec in sec.items():
+        lo, hi = rec["ms_per_step_min_max"]
+        assert lo <= rec["ms_per_step"] <= hi and rec["ms_per_step"] == rec["ms_per_step_median"], name
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
