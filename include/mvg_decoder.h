@@ -60,7 +60,8 @@ const char* mvg_version(void);
  * while nothing is in flight), never as per-request state.  Host-only.  Env MVG_TUNE="key=value,..." sets them at load time.
  *   "gsamp_threads" = 128 | 256 | 512 | 1024, "gsamp_map" = 0 | n : workgroup size and XCD block mapping of the G-sampling kernel
  *       (chunks of n slot blocks per XCD, 0 = one head per XCD);  "gsamp_pipe" = 0 | 1 | 2 : its gather loop double-buffered from 32 768 pairs per launch on / always / never;
- *       "gsamp_lds_pad" = bytes (probe): unused dynamic LDS per sampler workgroup, caps the workgroups per CU (occupancy sweeps);
+ *       "gsamp_lds_pad" / "chain_a_lds_pad" = bytes (probes): unused dynamic LDS per sampler / chain-A workgroup, caps the workgroups per
+ *       CU (occupancy sweeps: tools/r06_sampler_probe.py, tools/r06_fusion_emul.py);
  *   "gfused_chunk" = 0 | n : the same mapping for the fp32 G-sampling kernel;  "fwd_map" = 0 | 1 | 2 : decomposition of mvg_msda_forward;
  *   "auto_small" = 1 | 0 : launches with few rows (a rank's shard of a query-sharded run) use smaller workgroups / tiles in the
  *       sampler, chain A (64-row tiles up to 320 tiles of 128 rows) and chain B (32-row tiles up to 128 tiles of 64 rows);
