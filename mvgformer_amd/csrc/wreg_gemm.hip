@@ -141,6 +141,23 @@ __device__ __forceinline__ void wreg2_body(const WregParams& p, char* smem, cons
                  "global_load_lds_dwordx4 %3, off offset:3072"
                  :: "v"(dsrc[0]), "v"(dsrc[1]), "v"(dsrc[2]), "v"(dsrc[3]), "s"(dst) : "memory");
   };
+  // The same four pieces one per k-step (round 6: s_memtime stamps inside the k loop showed the quarter that carried the four
+  // stores and this block at 744 cycles for 256 of MFMA issue -- a vector-memory instruction takes 60-90 cycles to issue and the
+  // MFMAs behind it in program order wait).  Piece 0 writes M0; pieces 1-3 rely on it: nothing the compiler emits between them
+  // (MFMA, ds_read, VALU, global_store) touches M0 on gfx950.
+  auto dma_piece = [&](int slot, auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    if constexpr (Q == 0) {
+      const unsigned dst = abuf_lds + slot * W2_ABYTES + wn * 4096;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(dsrc[0]), "s"(dst) : "memory");
+    } else if constexpr (Q == 1) {
+      asm volatile("global_load_lds_dwordx4 %0, off offset:1024" :: "v"(dsrc[1]) : "memory");
+    } else if constexpr (Q == 2) {
+      asm volatile("global_load_lds_dwordx4 %0, off offset:2048" :: "v"(dsrc[2]) : "memory");
+    } else {
+      asm volatile("global_load_lds_dwordx4 %0, off offset:3072" :: "v"(dsrc[3]) : "memory");
+    }
+  };
   // operand reads: chunk 2 ks + h of row rl sits at slot chunk (2 ks + h) ^ (rl & 15) = (((ks & 7) ^ (rl >> 1 & 7)) << 1 | (h ^ rl & 1))
   // + 16 (ks >> 3): 8 lane-dependent addresses, ks >= 8 through the instruction's offset field
   unsigned aoff[8];
@@ -157,33 +174,31 @@ __device__ __forceinline__ void wreg2_body(const WregParams& p, char* smem, cons
     if (PLANES) sv[i] = *reinterpret_cast<const f32x4*>(stage + min(16 * (i & 1) + (lane >> 2), last_row) * W2_STP + (i >> 1) * 64 + (lane & 3) * 16);
     else sv[i] = *reinterpret_cast<const f32x4*>(stage + min(8 * i + (lane >> 3), last_row) * W2_STP + (lane & 7) * 16);
   };
-  auto st_addr = [&](int tile) {
+  // (one address per call: the ~25 vector instructions of an address are hidden by one k-step's MFMAs, the four together were not)
+  auto st_addr1 = [&](int tile, int i) {
     const int r0 = tile * RM;
     const int last_row = p.M - 1 - r0;
     if (PLANES) {
-      // image / pixel of the tile's first row once per tile (wave-uniform); a 32-row tile crosses at most one image boundary
+      // image / pixel of the tile's first row (wave-uniform); a 32-row tile crosses at most one image boundary
       // when an image has >= 32 pixels (else: the division per lane)
-      const int img0 = r0 / p.S_img, sp0 = r0 - img0 * p.S_img;
       if (!SMALL_S) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = min(16 * (i & 1) + (lane >> 2), last_row);
-          const bool over = sp0 + row >= p.S_img;
-          const int sp = over ? sp0 + row - p.S_img : sp0 + row, img = over ? img0 + 1 : img0;
-          sdst[i] = outp + (((long)img * 8 + 2 * wn + (i >> 1)) * p.S_img + sp) * 32 + (lane & 3) * 8;
-        }
+        const int img0 = r0 / p.S_img, sp0 = r0 - img0 * p.S_img;
+        const int row = min(16 * (i & 1) + (lane >> 2), last_row);
+        const bool over = sp0 + row >= p.S_img;
+        const int sp = over ? sp0 + row - p.S_img : sp0 + row, img = over ? img0 + 1 : img0;
+        sdst[i] = outp + (((long)img * 8 + 2 * wn + (i >> 1)) * p.S_img + sp) * 32 + (lane & 3) * 8;
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int grow = r0 + min(16 * (i & 1) + (lane >> 2), last_row);
-          const int img = grow / p.S_img, sp = grow - img * p.S_img;
-          sdst[i] = outp + (((long)img * 8 + 2 * wn + (i >> 1)) * p.S_img + sp) * 32 + (lane & 3) * 8;
-        }
+        const int grow = r0 + min(16 * (i & 1) + (lane >> 2), last_row);
+        const int img = grow / p.S_img, sp = grow - img * p.S_img;
+        sdst[i] = outp + (((long)img * 8 + 2 * wn + (i >> 1)) * p.S_img + sp) * 32 + (lane & 3) * 8;
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sdst[i] = outp + (long)(r0 + min(8 * i + (lane >> 3), last_row)) * p.N + wn * 64 + (lane & 7) * 8;
+      sdst[i] = outp + (long)(r0 + min(8 * i + (lane >> 3), last_row)) * p.N + wn * 64 + (lane & 7) * 8;
     }
+  };
+  auto st_addr = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_addr1(tile, i);
   };
   auto st_store = [&](int i) { *reinterpret_cast<f32x4*>(sdst[i]) = sv[i]; };
 
@@ -227,17 +242,20 @@ __device__ __forceinline__ void wreg2_body(const WregParams& p, char* smem, cons
         if (ks + 4 < 16) a[ks & 3] = *reinterpret_cast<const f32x4*>(ab + aoff[(ks + 4) & 7] + ((ks + 4) >> 3) * 256);
         // fillers, issued in the shadow of this step's MFMAs
         if (WITH_PREV) {
-          if (ks == 0) { st_read(prev_tile, 0); st_read(prev_tile, 1); }
-          if (ks == 1) { st_read(prev_tile, 2); st_read(prev_tile, 3); }
-          if (ks == 2) st_addr(prev_tile);
-          if (ks == 4) { st_store(0); st_store(1); }
-          if (ks == 5) { st_store(2); st_store(3); }
+          if (ks < 4) { st_read(prev_tile, ks); st_addr1(prev_tile, ks); }
+          if (ks >= 4 && ks < 8) st_store(ks - 4);
         }
-        if (ks == 6) dma_addr(tile + 2 * G);
-        if (ks == 7) dma_issue(nslot);
-        if (ks >= 8 && ks < 12) {
-          bv[2 * (ks - 8)] = *reinterpret_cast<const f32x4*>(bias_s + wn * 64 + ((ks - 8) >> 1) * 32 + 8 * (2 * ((ks - 8) & 1)) + 4 * h);
-          bv[2 * (ks - 8) + 1] = *reinterpret_cast<const f32x4*>(bias_s + wn * 64 + ((ks - 8) >> 1) * 32 + 8 * (2 * ((ks - 8) & 1) + 1) + 4 * h);
+        if (ks == 3) W2STAMP(3);           // (probe build only: the k loop in quarters)
+        if (ks == 7) W2STAMP(4);
+        if (ks == 11) W2STAMP(7);
+        if (ks == 7) dma_addr(tile + 2 * G);
+        if (ks == 8) dma_piece(nslot, std::integral_constant<int, 0>{});
+        if (ks == 9) dma_piece(nslot, std::integral_constant<int, 1>{});
+        if (ks == 10) dma_piece(nslot, std::integral_constant<int, 2>{});
+        if (ks == 11) dma_piece(nslot, std::integral_constant<int, 3>{});
+        if (ks >= 12) {
+          bv[2 * (ks - 12)] = *reinterpret_cast<const f32x4*>(bias_s + wn * 64 + ((ks - 12) >> 1) * 32 + 8 * (2 * ((ks - 12) & 1)) + 4 * h);
+          bv[2 * (ks - 12) + 1] = *reinterpret_cast<const f32x4*>(bias_s + wn * 64 + ((ks - 12) >> 1) * 32 + 8 * (2 * ((ks - 12) & 1) + 1) + 4 * h);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

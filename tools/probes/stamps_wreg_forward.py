@@ -48,4 +48,8 @@ w = t[(t[:, 6] > 0) & (t[:, 12] > 0)]
 d = np.diff(w[:, [0, 1, 2, 5, 6]], axis=1)
 for i, nm in enumerate(("vmcnt wait", "barrier", "k loop", "epilogue")):
     print("  %-12s %6.0f (%6.0f .. %6.0f)" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+kq = w[(w[:, 3] > 0) & (w[:, 4] > 0) & (w[:, 7] > 0)]
+if len(kq):
+    dq = np.diff(kq[:, [2, 3, 4, 7, 5]], axis=1)
+    print("  k loop in quarters (4 k-steps = 8 MFMAs = 256 cycles of issue each): " + " | ".join("%d" % np.median(dq[:, i]) for i in range(4)))
 print("  tiles per wavefront: %s" % dict(zip(*np.unique(live[:, 12], return_counts=True))))
