@@ -90,7 +90,9 @@ def test_bench_line_has_the_contract_fields():
         assert rec["steps"] >= 20 and rec["hip_graph"] is True and 0.02 < rec["frac"] < 1.0
         assert abs(rec["ms_per_sample"] * int(rec["workload"].split("batch ")[1].split(",")[0]) - rec["ms_per_step_median"]) < 1e-3
         assert rec["dtype"] == ("fp32" if name.endswith("fp32") else "bf16")
-    assert sec["cfg2_bf16_producer_inplace"]["ms_per_step_median"] < 1.02 * d["ms_per_step"]     # no per-step pack
+    # no per-step pack: not slower than the headline beyond what two segments of one process differ by (+-3 %: the pack is off the
+    # critical path, profiles/r06_experiments.txt)
+    assert sec["cfg2_bf16_producer_inplace"]["ms_per_step_median"] < 1.06 * d["ms_per_step"]
     assert sec["cfg5_bf16"]["ms_per_step"] > sec["cfg2_fp32"]["ms_per_step"] > d["ms_per_step"]
     for name, rec in sec.items():
         lo, hi = rec["ms_per_step_min_max"]
