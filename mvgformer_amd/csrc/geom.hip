@@ -390,7 +390,7 @@ __device__ __forceinline__ void jacobi_rotate2(double (&a)[4][4], double (&v)[4]
 //     to sigma = rho - |G x - rho x| (Rayleigh quotient minus residual: an eigenvalue lies within the residual of rho, so sigma stays
 //     below lambda_4 once x leans towards it -- and the new factors are only taken if all four pivots are positive, i.e. sigma
 //     IS below lambda_4).  Convergence becomes superlinear: <= 3 rounds for > 99 % of such matrices (numpy model of this routine,
-//     profiles/r06_experiments.txt section 6); what has not settled after MAXR rounds goes to the Jacobi.
+//     profiles/r06_experiments.txt section 6); what has not settled after MAXR = 12 rounds goes to the Jacobi.
 // Accuracy: Cholesky-type factors inherit the scaling D0 G D0 of the matrix (the homogeneous column of P is 1e3 x the others), so the
 // vector is exact to cond(scaled G) x eps -- 1e-6 mm against the fp64 SVD of the row matrix in the model, where LAPACK's eigh on G
 // itself is off by up to millimetres.
@@ -429,13 +429,15 @@ __device__ __forceinline__ bool ldl4_factor(const double (&G)[4][4], double sigm
   return ok;
 }
 
-__device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], double (&ev)[4]) {
-  constexpr int MAXR = 8;
+// wanted == false: the caller discards this problem's result (a query that did not pass the filter: its output is zero,
+// dq_decoder.py:887-967 triangulates the queries that passed only) -- the lane does not iterate and does not hold its wavefront.
+__device__ __forceinline__ bool null_vector_invit(const double (&G)[4][4], double (&ev)[4], const bool wanted = true) {
+  constexpr int MAXR = 12;
   Ldl4 f;
-  const bool pivots_ok = ldl4_factor<true>(G, 0.0, f);
+  const bool pivots_ok = ldl4_factor<true>(G, 0.0, f) || !wanted;
   double sigma = 0.0;
   double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
-  bool done = false;
+  bool done = !wanted;
   for (int round = 0; round < MAXR; ++round) {
     double p0 = x0, p1 = x1, p2 = x2, p3 = x3, w0 = x0, w1 = x1, w2 = x2, w3 = x3;
 #pragma unroll
@@ -830,9 +832,13 @@ __global__ __launch_bounds__(512) void triangulate_kernel(const float* __restric
   }
 
   double ev[4];
-  const bool need_jacobi = !null_vector_invit(G, ev);
+  const bool need_jacobi = !null_vector_invit(G, ev, ok);
 #ifdef TRI_STAMPS
   tst_[9] = __popcll(__ballot(need_jacobi));      // lanes of the solving wavefront that fall back to the Jacobi
+  {   // ... of them with unsafe pivots (the rest did not settle)
+    Ldl4 f_;
+    tst_[11] = __popcll(__ballot(need_jacobi && !ldl4_factor<true>(G, 0.0, f_)));
+  }
   TSTAMP(10);
 #endif
   if (need_jacobi) {

@@ -17,7 +17,7 @@ lib = _lib.load()
 lib.mvg_tri_read_stamps.argtypes = [C.c_void_p, C.c_int, C.c_int]
 lib.mvg_tri_read_stamps.restype = C.c_int
 dev = torch.device("cuda", 0)
-case = build_case("cfg2", B=1, seed=0)
+case = build_case("cfg2", B=1, seed=0, valid_fraction=(float(os.environ["VALID_FRACTION"]) if "VALID_FRACTION" in os.environ else None))
 dec = build_decoder_for_case(case, dev, torch.bfloat16)
 g = case_to_device(case, dev)
 ctx = DecoderContext.prepare(g.spatial_shapes, g.level_start_index, g.meta, case.img_size, torch.bfloat16, 1, dev)
@@ -60,3 +60,4 @@ for li, idx in enumerate(np.split(order, cuts)):
     fb = t[idx, 9]
     print("   inverse iteration: %d cycles (median, barrier -> vector); wavefronts with a Jacobi fallback lane: %d of %d, fallback lanes %d of %d"
           % (np.median(t[idx, 10] - t[idx, 6]), int((fb > 0).sum()), len(idx), int(fb.sum()), 64 * len(idx)))
+    print("   fallback lanes with unsafe pivots: %d" % int(t[idx, 11].sum()))
